@@ -1,0 +1,501 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/*.npz by running
+the reference's own Python (loaded unmodified from /root/reference through
+_ref_shim.py) on seeded synthetic inputs.  Container-only; re-run with
+
+    python tests/golden/make_golden.py
+
+Fixtures hold data only: seeds, the inputs that cannot be regenerated from a
+seed (recorded torch.rand draws), and the reference's outputs.  Network weights
+are regenerated from (name, shape, seed) by s2d_amd.utils.seeded.
+Each case cites the reference file:line it exercises.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_shim as R  # noqa: E402
+from s2d_amd.utils.seeded import seeded_state  # noqa: E402
+from s2d_amd.utils import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def load_seeded(module, seed):
+    sd = seeded_state([(k, tuple(v.shape)) for k, v in module.state_dict().items()], seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+
+
+class RandRecorder:
+    """Record (and seed) every torch.rand draw made inside the reference."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.log = []
+
+    def __enter__(self):
+        self._orig = torch.rand
+
+        def fn(*size, **kw):
+            kw.pop("device", None)
+            t = self._orig(*size, generator=self.g, **kw)
+            self.log.append(t.clone())
+            return t
+
+        torch.rand = fn
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+
+
+# ----------------------------------------------------------------------------
+def g_msda():
+    F_ = R.ref("mask2former.modeling.pixel_decoder.ops.functions.ms_deform_attn_func")
+    core = F_.ms_deform_attn_core_pytorch
+    # (a) the ops/test.py fixture (test.py:24-31, 35-47, 51-63), on CPU
+    N, M, D = 1, 2, 2
+    Lq, L, P = 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = torch.rand(N, S, M, D) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    w = torch.rand(N, Lq, M, L, P) + 1e-5
+    w /= w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    out64 = core(value.double(), shapes, loc.double(), w.double())
+    out32 = core(value, shapes, loc, w)
+    save("msda_optest", value=value, loc=loc, w=w, shapes=shapes, out64=out64, out32=out32)
+
+    # (b) S2D geometry: M=8, D=32, L=3, P=4 (msdeformattn.py:232-239); locations
+    # spill outside [0,1] to exercise the zero-padding corner tests (.cuh:61-83,293)
+    N, M, D, L, P = 2, 8, 32, 3, 4
+    shapes = torch.as_tensor([(2, 3), (4, 6), (8, 12)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    Lq = S
+    g = torch.Generator().manual_seed(11)
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15
+    w = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    value.requires_grad_(True); loc.requires_grad_(True); w.requires_grad_(True)
+    out = core(value, shapes, loc, w)
+    go = torch.randn(out.shape, generator=g)
+    gv, gl, gw = torch.autograd.grad(out, (value, loc, w), go)
+    save("msda_core", value=value, loc=loc, w=w, shapes=shapes, out=out, grad_out=go,
+         grad_value=gv, grad_loc=gl, grad_w=gw)
+
+    # (c) the module (ms_deform_attn.py:82-125)
+    Mod = R.ref("mask2former.modeling.pixel_decoder.ops.modules.ms_deform_attn").MSDeformAttn
+    mod = Mod(256, 3, 8, 4)
+    load_seeded(mod, 21)
+    N = 2
+    query = torch.from_numpy(synth.randn(21, 1, (N, S, 256)))
+    src = torch.from_numpy(synth.randn(21, 2, (N, S, 256)))
+    Enc = R.ref("mask2former.modeling.pixel_decoder.msdeformattn").MSDeformAttnTransformerEncoder
+    ref_pts = Enc.get_reference_points(shapes, torch.ones(N, 3, 2), "cpu")
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    with torch.no_grad():
+        out = mod(query, ref_pts, src, shapes, lsi, None)
+    save("msda_module", seed=21, shapes=shapes, ref_pts=ref_pts, out=out)
+
+
+def g_pe():
+    pe2 = R.ref("mask2former.modeling.transformer_decoder.position_encoding").PositionEmbeddingSine(128, normalize=True)
+    pe3 = R.ref("mask2former_video.modeling.transformer_decoder.position_encoding").PositionEmbeddingSine3D(128, normalize=True)
+    save("pe", pe2=pe2(torch.zeros(1, 4, 5, 7)), pe3=pe3(torch.zeros(1, 3, 4, 4, 6)))
+
+
+def feature_inputs(seed, BT, h4, w4):
+    return {
+        "res2": synth.randn(seed, 2, (BT, 256, h4, w4)),
+        "res3": synth.randn(seed, 3, (BT, 512, h4 // 2, w4 // 2)),
+        "res4": synth.randn(seed, 4, (BT, 1024, h4 // 4, w4 // 4)),
+        "res5": synth.randn(seed, 5, (BT, 2048, h4 // 8, w4 // 8)),
+    }
+
+
+def build_pixel_decoder(seed):
+    m = R.ref("mask2former.modeling.pixel_decoder.msdeformattn")
+    SS = sys.modules["detectron2.layers"].ShapeSpec
+    shp = {"res2": SS(channels=256, stride=4), "res3": SS(channels=512, stride=8),
+           "res4": SS(channels=1024, stride=16), "res5": SS(channels=2048, stride=32)}
+    pd = m.MSDeformAttnPixelDecoder(shp, transformer_dropout=0.0, transformer_nheads=8,
+                                    transformer_dim_feedforward=1024, transformer_enc_layers=6,
+                                    conv_dim=256, mask_dim=256, norm="GN",
+                                    transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    load_seeded(pd, seed)
+    return pd
+
+
+def g_pixel_decoder():
+    # msdeformattn.py:314-358 (+ encoder :61-131, reference points :141-153)
+    seed = 31
+    pd = build_pixel_decoder(seed)
+    feats = {k: torch.from_numpy(v) for k, v in feature_inputs(seed, 2, 16, 24).items()}
+    with torch.no_grad():
+        mf, enc0, ms = pd.forward_features(feats)
+    save("pixel_decoder", seed=seed, BT=2, h4=16, w4=24, mask_features=mf, ms0=ms[0], ms1=ms[1], ms2=ms[2])
+
+
+def build_video_decoder(seed, Q, T):
+    v = R.ref("mask2former_video.modeling.transformer_decoder.video_mask2former_transformer_decoder")
+    dec = v.VideoMultiScaleMaskedTransformerDecoder(
+        256, True, num_classes=1, hidden_dim=256, num_queries=Q, nheads=8, dim_feedforward=2048,
+        dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=T)
+    load_seeded(dec, seed)
+    dec.train()
+    return dec
+
+
+def decoder_inputs(seed, BT, h4, w4):
+    ms = [synth.randn(seed, 10, (BT, 256, h4 // 8, w4 // 8)),
+          synth.randn(seed, 11, (BT, 256, h4 // 4, w4 // 4)),
+          synth.randn(seed, 12, (BT, 256, h4 // 2, w4 // 2))]
+    mf = synth.randn(seed, 13, (BT, 256, h4, w4), 0.5)
+    # second half of the frames (= last clip): one dominant constant channel, so about half
+    # the queries get all-negative masks there, which exercises the "fully masked row ->
+    # unmask" fix (video_...decoder.py:413); the first clip keeps mixed masks.
+    mf[BT // 2:] *= 0.1
+    mf[BT // 2:, 0] += 3.0
+    return ms, mf
+
+
+def g_video_decoder():
+    # video_mask2former_transformer_decoder.py:374-467
+    seed, B, T, Q, h4, w4 = 41, 2, 2, 16, 16, 24
+    dec = build_video_decoder(seed, Q, T)
+    ms, mf = decoder_inputs(seed, B * T, h4, w4)
+    # count how often the all-masked fix fires (proves the fixture exercises it)
+    fired = []
+    v = R.ref("mask2former_video.modeling.transformer_decoder.video_mask2former_transformer_decoder")
+    orig = v.VideoMultiScaleMaskedTransformerDecoder.forward_prediction_heads
+
+    def spy(self, output, mask_features, attn_mask_target_size):
+        a, b, am = orig(self, output, mask_features, attn_mask_target_size)
+        fired.append(int((am.sum(-1) == am.shape[-1]).sum()))
+        return a, b, am
+
+    v.VideoMultiScaleMaskedTransformerDecoder.forward_prediction_heads = spy
+    with torch.no_grad():
+        out = dec([torch.from_numpy(x) for x in ms], torch.from_numpy(mf))
+    v.VideoMultiScaleMaskedTransformerDecoder.forward_prediction_heads = orig
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])
+    masks = torch.stack([a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]])
+    print("   all-masked rows per head call:", fired)
+    assert sum(fired) > 0
+    save("video_decoder", seed=seed, B=B, T=T, Q=Q, h4=h4, w4=w4, logits=logits, masks=masks,
+         all_masked_rows=np.array(fired))
+
+
+def make_targets(seed, tag, ns, T, H, W):
+    tg = []
+    for b, n in enumerate(ns):
+        m, ids = synth.ellipse_targets(seed, tag + b, n, T, H, W)
+        tg.append({"labels": torch.zeros(n, dtype=torch.int64), "masks": torch.from_numpy(m).float(),
+                   "ids": torch.from_numpy(ids)})
+    return tg
+
+
+def g_matcher():
+    # matcher.py:225-294 (+ batch_dice_loss :15-30, batch_sigmoid_ce_loss :38-62)
+    mt = R.ref("mask2former_video.modeling.matcher")
+    for name, (B, Q, T, h, w, H, W, ns, P, seed) in {
+        "matcher_small": (2, 16, 2, 16, 24, 64, 96, [3, 5], 256, 51),
+        "matcher_q100": (1, 100, 2, 30, 54, 120, 216, [10], 1024, 52),
+        "matcher_empty": (2, 16, 2, 16, 24, 64, 96, [0, 4], 256, 53),
+        "matcher_wide": (1, 12, 2, 16, 24, 64, 96, [20], 256, 54),  # more targets than queries
+    }.items():
+        logits = torch.from_numpy(synth.randn(seed, 1, (B, Q, 2)))
+        masks = torch.from_numpy(synth.smooth_logits(seed, 2, (B, Q, T), (h, w)))
+        tg = make_targets(seed, 100, ns, T, H, W)
+        m = mt.VideoHungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=P)
+        Cs = []
+        orig = mt.linear_sum_assignment
+
+        def rec(C):
+            Cs.append(np.asarray(C).copy())
+            return orig(C)
+
+        mt.linear_sum_assignment = rec
+        with RandRecorder(seed) as rr:
+            idx = m({"pred_logits": logits, "pred_masks": masks}, tg)
+        mt.linear_sum_assignment = orig
+        arrs = dict(seed=seed, dims=np.array([B, Q, T, h, w, H, W, P]), ns=np.array(ns),
+                    cost_weights=np.array([2.0, 5.0, 5.0]))
+        for b in range(B):
+            arrs[f"coords{b}"] = rr.log[b]
+            arrs[f"C{b}"] = Cs[b]
+            arrs[f"i{b}"] = idx[b][0]
+            arrs[f"j{b}"] = idx[b][1]
+        save(name, **arrs)
+
+
+def g_loss():
+    # criterion.py:227-251 (loss_labels), :292-356 (loss_masks), point_features.py:63-116
+    cr = R.ref("mask2former_video.modeling.criterion")
+    B, Q, T, h, w, H, W, P, seed = 2, 16, 2, 16, 24, 64, 96, 256, 61
+    ns = [3, 5]
+    logits = torch.from_numpy(synth.randn(seed, 1, (B, Q, 2)))
+    masks = torch.from_numpy(synth.smooth_logits(seed, 2, (B, Q, T), (h, w)))
+    tg = make_targets(seed, 100, ns, T, H, W)
+    crit = cr.VideoSetCriterion(1, matcher=None, weight_dict={}, eos_coef=0.1, losses=["labels", "masks"],
+                                num_points=P, oversample_ratio=3.0, importance_sample_ratio=0.75,
+                                loss_strategy="masks-only", distillation_loss_strategy="masks-only")
+    rng = np.random.default_rng(seed)
+    indices = []
+    for b, n in enumerate(ns):
+        qi = np.sort(rng.choice(Q, n, replace=False))
+        tj = rng.permutation(n)
+        indices.append((torch.as_tensor(qi), torch.as_tensor(tj)))
+    outputs = {"pred_logits": logits, "pred_masks": masks}
+    num_masks = float(sum(ns))
+    ll = crit.loss_labels(outputs, tg, indices, num_masks, False)
+    with RandRecorder(seed) as rr:
+        lm = crit.loss_masks(outputs, tg, indices, num_masks, False)
+    # rows kept by DropLoss, in order (criterion.py:307-322)
+    tm = torch.cat([t["masks"][i] for t, (_, i) in zip(tg, indices)]).flatten(0, 1)
+    keep = np.array([i for i in range(tm.shape[0]) if tm[i].sum() != 0])
+    arrs = dict(seed=seed, dims=np.array([B, Q, T, h, w, H, W, P]), ns=np.array(ns), num_masks=num_masks,
+                loss_ce=ll["loss_ce"], loss_mask=lm["loss_mask"], loss_dice=lm["loss_dice"],
+                coords_over=rr.log[0], coords_rand=rr.log[1], keep=keep)
+    for b in range(B):
+        arrs[f"i{b}"] = indices[b][0]
+        arrs[f"j{b}"] = indices[b][1]
+    save("loss", **arrs)
+    # all-empty targets -> zeros (criterion.py:315-318)
+    tg0 = [{"labels": t["labels"], "masks": torch.zeros_like(t["masks"])} for t in tg]
+    lm0 = crit.loss_masks(outputs, tg0, indices, num_masks, False)
+    assert float(lm0["loss_mask"]) == 0.0 and float(lm0["loss_dice"]) == 0.0
+
+
+class _FakeSelf:
+    pass
+
+
+def g_kd_and_criterion():
+    """End-to-end loss golden: the call order of criterion.py:390-427 (matcher ->
+    loss_labels -> loss_masks -> per aux layer: matcher -> loss_masks), once with
+    ground-truth targets and once with distillation targets built by the
+    reference's own prepare_distillation_targets (kd_video_maskformer_model.py:
+    418-528), then the renaming/weighting of :314-326.  VideoSetCriterion.forward
+    itself raises AttributeError as shipped (criterion.py:380-385 references
+    undefined loss_*_drop), so the harness walks the same order by hand."""
+    cr = R.ref("mask2former_video.modeling.criterion")
+    mt = R.ref("mask2former_video.modeling.matcher")
+    kd = R.ref("mask2former_video.kd_video_maskformer_model")
+    B, Q, T, h, w, H, W, P, seed = 2, 16, 2, 16, 24, 64, 96, 256, 71
+    NL = 10
+    ns = [3, 4]
+    s_logits = torch.from_numpy(synth.randn(seed, 1, (NL, B, Q, 2)))
+    s_masks = torch.from_numpy(synth.smooth_logits(seed, 2, (NL, B, Q, T), (h, w)))
+    t_logits = torch.from_numpy(synth.randn(seed, 3, (B, Q, 2), 2.0))
+    t_masks = torch.from_numpy(synth.smooth_logits(seed, 4, (B, Q, T), (h, w)))
+    tg = make_targets(seed, 100, ns, T, H, W)
+
+    fs = _FakeSelf()
+    fs.teacher = [None, _FakeSelf()]
+    fs.teacher[1].num_classes = 1
+    fs.device = torch.device("cpu")
+    fs.num_queries = Q
+    fs.num_predictions_distillation = 100 if Q >= 100 else Q
+    fs.num_frames = T
+    images = _FakeSelf()
+    images.tensor = torch.zeros(B * T, 3, H, W)
+    kd_t = kd.KDVideoMaskFormer.prepare_distillation_targets(
+        fs, {"pred_logits": t_logits, "pred_masks": t_masks}, images, None, nms=False, score_threshold=0.75)
+    kd_save = {}
+    for b in range(B):
+        kd_save[f"kd_masks{b}"] = np.packbits(kd_t[b]["masks"].numpy().astype(np.uint8), axis=-1)
+        kd_save[f"kd_n{b}"] = kd_t[b]["masks"].shape[0]
+        # which queries were kept, in the reference's (implementation-defined, sorted=False) order
+        sc = F.softmax(t_logits[b], -1)[:, 0]
+        kept = [int(q) for q in range(Q) if sc[q] >= 0.75]
+        # recover order by matching masks
+        order = []
+        up = F.interpolate(t_masks[b], size=(H, W), mode="bilinear", align_corners=False) > 0
+        for k in range(kd_t[b]["masks"].shape[0]):
+            for q in kept:
+                if q not in order and torch.equal(up[q], kd_t[b]["masks"][k]):
+                    order.append(q)
+                    break
+        kd_save[f"kd_order{b}"] = np.array(order, dtype=np.int64)
+    print("   KD targets kept per clip:", [kd_save[f"kd_n{b}"] for b in range(B)])
+
+    weight_dict = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 5.0,
+                   "kd_loss_ce": 0.0, "kd_loss_mask": 5.0, "kd_loss_dice": 5.0}
+    aux = {}
+    for i in range(NL - 1):
+        aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+    weight_dict.update(aux)
+    matcher = mt.VideoHungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=P)
+    crit = cr.VideoSetCriterion(1, matcher=matcher, weight_dict=weight_dict, eos_coef=0.1,
+                                losses=["labels", "masks"], num_points=P, oversample_ratio=3.0,
+                                importance_sample_ratio=0.75, loss_strategy="masks-only",
+                                distillation_loss_strategy="masks-only")
+
+    def run(targets, distillation, rr_seed):
+        with RandRecorder(rr_seed) as rr:
+            outputs = {"pred_logits": s_logits[-1], "pred_masks": s_masks[-1]}
+            all_idx = []
+            indices = matcher(outputs, targets)
+            all_idx.append(indices)
+            num_masks = max(float(sum(len(t["labels"]) for t in targets)), 1.0)
+            losses = {}
+            losses.update(crit.loss_labels(outputs, targets, indices, num_masks, distillation))
+            losses.update(crit.loss_masks(outputs, targets, indices, num_masks, distillation))
+            for i in range(NL - 1):
+                auxo = {"pred_logits": s_logits[i], "pred_masks": s_masks[i]}
+                indices = matcher(auxo, targets)
+                all_idx.append(indices)
+                ld = crit.loss_masks(auxo, targets, indices, num_masks, False)
+                losses.update({k + f"_{i}": v for k, v in ld.items()})
+        return losses, rr.log, all_idx
+
+    losses, log_gt, idx_gt = run(tg, False, seed)
+    kd_targets = [{"labels": t["labels"], "masks": t["masks"]} for t in kd_t]
+    dl, log_kd, idx_kd = run(kd_targets, True, seed + 1)
+    for k in list(dl.keys()):
+        if k.startswith("loss_"):
+            dl[k.replace("loss_", "kd_loss_")] = dl.pop(k)
+    losses.update(dl)
+    for k in list(losses.keys()):
+        if k in weight_dict:
+            losses[k] = losses[k] * weight_dict[k]
+        else:
+            losses.pop(k)
+    arrs = dict(seed=seed, dims=np.array([B, Q, T, h, w, H, W, P, NL]), ns=np.array(ns))
+    arrs.update(kd_save)
+    for k, v in losses.items():
+        arrs["L_" + k] = np.float32(v)
+    for nm, log in (("gt", log_gt), ("kd", log_kd)):
+        arrs[f"nrand_{nm}"] = len(log)
+        for i, t in enumerate(log):
+            arrs[f"rand_{nm}_{i}"] = t
+    for nm, idxs in (("gt", idx_gt), ("kd", idx_kd)):
+        for li, ind in enumerate(idxs):
+            for b in range(B):
+                arrs[f"idx_{nm}_{li}_{b}_i"] = ind[b][0]
+                arrs[f"idx_{nm}_{li}_{b}_j"] = ind[b][1]
+    save("criterion_kd", **arrs)
+
+
+class _Inst:
+    """Stand-in for detectron2 Instances/BitMasks: attribute bag with the members
+    prepare_targets touches (kd_video_maskformer_model.py:358-386)."""
+
+    def __init__(self, masks, ids, classes, image_size):
+        self.gt_masks = _FakeSelf()
+        self.gt_masks.tensor = masks
+        self.gt_ids = ids
+        self.gt_classes = classes
+        self.image_size = image_size
+
+    def to(self, device):
+        return self
+
+    def __len__(self):
+        return self.gt_ids.shape[0]
+
+
+def g_prepare_targets():
+    kd = R.ref("mask2former_video.kd_video_maskformer_model")
+    seed, T, H0, W0, Hp, Wp, n = 81, 3, 60, 90, 64, 96, 4
+    m, ids = synth.ellipse_targets(seed, 1, n, T, H0, W0, sparse=0.6)
+    ids[2, :] = -1
+    m[2] = 0  # instance never present -> dropped (:376-380)
+    fs = _FakeSelf()
+    fs.num_frames = T
+    fs.device = torch.device("cpu")
+    images = _FakeSelf()
+    images.tensor = torch.zeros(T, 3, Hp, Wp)
+    inst = [_Inst(torch.from_numpy(m[:, t]).bool(), torch.from_numpy(ids[:, t]),
+                  torch.zeros(n, dtype=torch.int64), (H0, W0)) for t in range(T)]
+    out = kd.KDVideoMaskFormer.prepare_targets(fs, [{"instances": inst}], images)
+    save("prepare_targets", seed=seed, dims=np.array([T, H0, W0, Hp, Wp, n]),
+         masks=np.packbits(out[0]["masks"].numpy().astype(np.uint8), axis=-1),
+         ids=out[0]["ids"], labels=out[0]["labels"], n_out=out[0]["masks"].shape[0])
+
+
+def g_keymask():
+    # cotracker_matching.py:176-209 (K4), :453-503 (K3), :640-662 (K5), :665-719 (K6)
+    km = R.ref("cotracker_matching")
+    seed, T, H, W, Np = 91, 6, 48, 64, 200
+    rng = synth.rng_for(seed, 0)
+    # id map: 3 moving ellipse objects, ids 1..3 (0 = background); T,H,W,1 int64
+    m, _ = synth.ellipse_targets(seed, 1, 3, T, H, W, sparse=0.0, rmin=6, rmax=14)
+    idmap = np.zeros((T, H, W, 1), np.int64)
+    for o in range(3):
+        idmap[..., 0][m[o] > 0] = o + 1
+    # tracks: points inside object 1 + noise, some half-integers (round-half-even) and some out of bounds
+    ys, xs = np.nonzero(m[0, 0])
+    sel = rng.integers(0, len(ys), Np)
+    base = np.stack([xs[sel], ys[sel]], -1).astype(np.float32)
+    tracks = np.zeros((1, T, Np, 2), np.float32)
+    for t in range(T):
+        tracks[0, t] = base + rng.normal(0, 1.0, (Np, 2)).astype(np.float32) + np.float32(t * 0.7)
+    tracks[0, :, :8] = np.round(tracks[0, :, :8]) + 0.5      # exact .5 -> half-to-even
+    tracks[0, :, 8:12] = np.array([-3.0, 5.0])               # out of bounds (x<0)
+    tracks[0, :, 12:14] = np.array([W - 0.5, H - 0.5])       # rounds to W / H-? -> edge cases
+    tr = torch.from_numpy(tracks)
+    track_masks = km.pred_tracks_to_binary_masks(tr, H, W, return_mask=False)
+    # segm_mask at a different size than the id map -> exercises nearest resize (:687-689)
+    H2, W2 = 36, 50
+    segm = torch.zeros(H2, W2, dtype=torch.uint8)
+    tr2 = tr * torch.tensor([W2 / W, H2 / H])
+    ids_t = torch.from_numpy(idmap)
+    glob = {}
+    clus = {}
+    km_get_overall = km.get_overall_maskid
+    km_get_cluster = km.get_cluster_maskid
+    km.get_overall_maskid = lambda *a: -1
+    km.get_cluster_maskid = lambda *a: -1
+    matches, allc = km.extract_mask_matches(segm, tr2, ids_t, 0, (1, 4), 25, glob, clus, 0, 0.5)
+    matches_same, allc_same = km.extract_mask_matches(torch.zeros(H, W, dtype=torch.uint8), tr, ids_t, 0,
+                                                      (0, T - 1), 25, glob, clus, 0, 0.5)
+    km.get_overall_maskid = km_get_overall
+    km.get_cluster_maskid = km_get_cluster
+
+    def pack(lst):
+        return np.array([[d["frame_id"], d["mask_id"], d["iou"]] for d in lst], np.float64).reshape(-1, 3)
+
+    seg1 = km.get_segmentation_mask(ids_t, 2, 2)
+    save("keymask", seed=seed, tracks=tracks, idmap=idmap.astype(np.int16), track_masks=track_masks,
+         resized_dims=np.array([H2, W2]), allc_resized=pack(allc), matches_resized=pack(matches),
+         allc_same=pack(allc_same), matches_same=pack(matches_same), segmask_f2_o2=seg1)
+
+
+def g_visibility():
+    # identify_visibility_windows.py:108-231 needs JSON files on disk; K7 is host-side sklearn
+    # and is pinned by calling sklearn directly in the tests.  Nothing to generate.
+    pass
+
+
+def main():
+    assert R.available(), "/root/reference not present: goldens can only be generated in the build container"
+    R.install()
+    for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
+               g_prepare_targets, g_keymask):
+        print(fn.__name__)
+        fn()
+
+
+if __name__ == "__main__":
+    main()
