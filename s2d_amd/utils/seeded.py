@@ -12,6 +12,10 @@ import numpy as np
 
 def _kind(name, shape):
     last = name.rsplit(".", 1)[-1]
+    if "running_var" in name:
+        return "var"
+    if "running_mean" in name:
+        return "norm_b"
     if "norm" in name or ("input_proj" in name and (name.endswith(".1.weight") or name.endswith(".1.bias"))):
         # LayerNorm / GroupNorm / FrozenBN affine
         return "norm_w" if last == "weight" else "norm_b"
