@@ -1,0 +1,287 @@
+// Multi-scale deformable attention sampling for gfx950.
+//
+// Replaces ms_deformable_im2col_gpu_kernel (ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304, bilinear fetch
+// :38-89) and, in the fused form, also the softmax / sampling-location arithmetic of
+// MSDeformAttn.forward (ops/modules/ms_deform_attn.py:101-109).
+//
+// Mapping (wave64-native): one work item = (query, head, 4-channel group); a head's D channels are one
+// contiguous 4*D-byte run of `value`, so the D/4 lanes of a head read each bilinear corner as one coalesced
+// 128-B row (D = 32) with 16-B loads.  With M*D = 256 one wavefront is exactly one query: its 8 heads x 8
+// lanes.  The 12 (level, point) samples of a (query, head) are read once per lane as float4s (the 8 lanes
+// of a head hit the same address: one broadcast fetch), all 48 corner gathers are independent and stay in
+// flight together.  Bound: HBM/L2 gather bandwidth, no MFMA.  Blocks are renumbered so each XCD sweeps a
+// contiguous band of queries: a band's sampling footprint (~1/8 of a 20 MB value map) then stays in that
+// XCD's 4 MB L2.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_L = 8;
+
+struct Levels {
+    int H[MAX_L], W[MAX_L];
+    long start[MAX_L];
+};
+
+__device__ __forceinline__ int xcd_band(int bid, int nblk)
+{
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, within = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f32x4 T;
+};
+template <>
+struct Vec<1> {
+    typedef float T;
+};
+
+template <int V>
+__device__ __forceinline__ void sample_accum(typename Vec<V>::T &acc, const float *__restrict__ vbase, long rowstride,
+                                             int H, int W, float h_im, float w_im, float aw)
+{
+    typedef typename Vec<V>::T VT;
+    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;  // cuh:293
+    const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+    const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+    VT v1 = VT(0.f), v2 = VT(0.f), v3 = VT(0.f), v4 = VT(0.f);
+    if (h0 >= 0 && w0 >= 0) v1 = *reinterpret_cast<const VT *>(vbase + ((long)h0 * W + w0) * rowstride);
+    if (h0 >= 0 && w1 <= W - 1) v2 = *reinterpret_cast<const VT *>(vbase + ((long)h0 * W + w1) * rowstride);
+    if (h1 <= H - 1 && w0 >= 0) v3 = *reinterpret_cast<const VT *>(vbase + ((long)h1 * W + w0) * rowstride);
+    if (h1 <= H - 1 && w1 <= W - 1) v4 = *reinterpret_cast<const VT *>(vbase + ((long)h1 * W + w1) * rowstride);
+    const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+    acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
+}
+
+// Drop-in form: sampling locations and attention weights are inputs (the reference op's signature).
+template <int V>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__ value, Levels lv,
+                                                       const float *__restrict__ loc, const float *__restrict__ aw,
+                                                       int S, int M, int D, int L, int Lq, int P, int blk_per_n,
+                                                       float *__restrict__ out)
+{
+    typedef typename Vec<V>::T VT;
+    const int n = blockIdx.y;
+    const int bid = xcd_band(blockIdx.x, blk_per_n);
+    const int dv = D / V;
+    const long item = (long)bid * 256 + threadIdx.x;
+    if (item >= (long)Lq * M * dv) return;
+    const int c = (int)(item % dv);
+    const int m = (int)((item / dv) % M);
+    const int q = (int)(item / ((long)dv * M));
+    const long qm = ((long)n * Lq + q) * M + m;
+    const float *lp = loc + qm * L * P * 2;
+    const float *wp = aw + qm * L * P;
+    const long rowstride = (long)M * D;
+    VT acc = VT(0.f);
+    for (int l = 0; l < L; ++l) {
+        const int H = lv.H[l], W = lv.W[l];
+        const float *vbase = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
+        for (int p = 0; p < P; ++p) {
+            const float lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
+            sample_accum<V>(acc, vbase, rowstride, H, W, ly * H - 0.5f, lx * W - 0.5f, wp[l * P + p]);
+        }
+    }
+    *reinterpret_cast<VT *>(out + qm * D + c * V) = acc;
+}
+
+// Fused form for the pixel decoder (self-attention over the flattened pyramid: Lq == S, the query's own
+// normalised pixel centre is its reference point on every level, msdeformattn.py:141-153 with valid
+// ratios == 1).  `oa` [N,S,ldoa] holds, per query, the raw sampling offsets [M][L][P][2] followed by the raw
+// attention logits [M][L*P] (one GEMM output).  Softmax over L*P and loc = ref + off/(W_l,H_l) happen here.
+template <int LP_>
+__global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, Levels lv,
+                                                         const float *__restrict__ oa, int ldoa, int S, int M, int L,
+                                                         int P, int blk_per_n, float *__restrict__ out)
+{
+    constexpr int D = 32, V = 4, dv = D / V;
+    const int n = blockIdx.y;
+    const int bid = xcd_band(blockIdx.x, blk_per_n);
+    const long item = (long)bid * 256 + threadIdx.x;
+    if (item >= (long)S * M * dv) return;
+    const int c = (int)(item % dv);
+    const int m = (int)((item / dv) % M);
+    const int q = (int)(item / ((long)dv * M));
+    // which level does query q live on, and where
+    int lq = 0;
+    while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
+    const int qi = q - (int)lv.start[lq];
+    const int qy = qi / lv.W[lq], qx = qi - qy * lv.W[lq];
+    const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
+    const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
+
+    const float *row = oa + ((long)n * S + q) * ldoa;
+    const float *offp = row + m * (LP_ * 2);
+    const float *lgp = row + M * LP_ * 2 + m * LP_;
+    float lg[LP_];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP_; ++i) { lg[i] = lgp[i]; mx = fmaxf(mx, lg[i]); }
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+    const float inv = 1.f / den;
+    const long rowstride = (long)M * D;
+    f32x4 acc = f32x4(0.f);
+#pragma unroll
+    for (int i = 0; i < LP_; ++i) {
+        const int l = i / P;
+        const int H = lv.H[l], W = lv.W[l];
+        const float *vbase = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
+        const float lx = ref_x + offp[2 * i] / (float)W;       // ms_deform_attn.py:106-109
+        const float ly = ref_y + offp[2 * i + 1] / (float)H;
+        sample_accum<4>(acc, vbase, rowstride, H, W, ly * H - 0.5f, lx * W - 0.5f, lg[i] * inv);
+    }
+    *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
+}
+
+// Backward (ms_deform_im2col_cuda.cuh:92-164 formulas; the reference launches 32-thread blocks with a serial
+// shared-memory sum, :306-408).  Here: one lane per (query, head, channel), D == 32 lanes = half a wavefront
+// per (query, head); grad_sampling_loc / grad_attn_weight are reduced across the 32 channel lanes with
+// DPP/shuffle butterflies (no LDS, no serial loop); grad_value uses float atomics, issued as 128-B row
+// segments (two per wave-instruction).
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__ value, Levels lv,
+                                                       const float *__restrict__ loc, const float *__restrict__ aw,
+                                                       const float *__restrict__ gout, int S, int M, int L, int Lq,
+                                                       int P, float *__restrict__ gvalue, float *__restrict__ gloc,
+                                                       float *__restrict__ gaw)
+{
+    constexpr int D = 32;
+    const int n = blockIdx.y;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = item < (long)Lq * M * D;
+    const long it = live ? item : 0;
+    const int d = (int)(it % D);
+    const int m = (int)((it / D) % M);
+    const int q = (int)(it / ((long)D * M));
+    const long qm = ((long)n * Lq + q) * M + m;
+    const float tg = live ? gout[qm * D + d] : 0.f;
+    const long rowstride = (long)M * D;
+    for (int l = 0; l < L; ++l) {
+        const int H = lv.H[l], W = lv.W[l];
+        const long vb = ((long)n * S + lv.start[l]) * rowstride + m * D + d;
+        for (int p = 0; p < P; ++p) {
+            const long wi = (qm * L + l) * P + p;
+            const float lx = loc[2 * wi], ly = loc[2 * wi + 1], a = aw[wi];
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            float gw = 0.f, gx = 0.f, gy = 0.f;
+            if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+                const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+                const float tgv = tg * a;
+                float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, ghw = 0.f, gww = 0.f;
+                if (h0 >= 0 && w0 >= 0) {
+                    const long ix = vb + ((long)h0 * W + w0) * rowstride;
+                    v1 = value[ix]; ghw -= hw * v1; gww -= hh * v1; atomicAdd(gvalue + ix, hh * hw * tgv);
+                }
+                if (h0 >= 0 && w1 <= W - 1) {
+                    const long ix = vb + ((long)h0 * W + w1) * rowstride;
+                    v2 = value[ix]; ghw -= lw * v2; gww += hh * v2; atomicAdd(gvalue + ix, hh * lw * tgv);
+                }
+                if (h1 <= H - 1 && w0 >= 0) {
+                    const long ix = vb + ((long)h1 * W + w0) * rowstride;
+                    v3 = value[ix]; ghw += hw * v3; gww -= lh * v3; atomicAdd(gvalue + ix, lh * hw * tgv);
+                }
+                if (h1 <= H - 1 && w1 <= W - 1) {
+                    const long ix = vb + ((long)h1 * W + w1) * rowstride;
+                    v4 = value[ix]; ghw += lw * v4; gww += lh * v4; atomicAdd(gvalue + ix, lh * lw * tgv);
+                }
+                gw = tg * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+                gx = (float)W * gww * tgv;
+                gy = (float)H * ghw * tgv;
+            }
+            // reduce over the 32 channel lanes of this (query, head)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                gw += __shfl_xor(gw, o, 64);
+                gx += __shfl_xor(gx, o, 64);
+                gy += __shfl_xor(gy, o, 64);
+            }
+            if (live && d == 0) {
+                gaw[wi] = gw;
+                gloc[2 * wi] = gx;
+                gloc[2 * wi + 1] = gy;
+            }
+        }
+    }
+}
+
+int fill_levels(Levels &lv, const int64_t *shapes, const int64_t *lsi, int L, long S)
+{
+    if (L < 1 || L > MAX_L) return S2D_ERR_ARG;
+    long tot = 0;
+    for (int l = 0; l < L; ++l) {
+        lv.H[l] = (int)shapes[2 * l];
+        lv.W[l] = (int)shapes[2 * l + 1];
+        lv.start[l] = lsi ? (long)lsi[l] : tot;
+        if (lv.H[l] <= 0 || lv.W[l] <= 0 || lv.start[l] < 0 || lv.start[l] + (long)lv.H[l] * lv.W[l] > S) return S2D_ERR_ARG;
+        tot += (long)lv.H[l] * lv.W[l];
+    }
+    return S2D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                         const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P,
+                         float *out, hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    if ((D & 3) == 0) {
+        const long items = (long)Lq * M * (D / 4);
+        const int nb = cdiv(items, 256);
+        hipLaunchKernelGGL(msda_fwd_kernel<4>, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, S, M, D, L,
+                           Lq, P, nb, out);
+    } else {
+        const long items = (long)Lq * M * D;
+        const int nb = cdiv(items, 256);
+        hipLaunchKernelGGL(msda_fwd_kernel<1>, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, S, M, D, L,
+                           Lq, P, nb, out);
+    }
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_msda_fused_forward_f32(const float *value, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+                               int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
+    if (D != 32 || L * P != 12 || ldoa < M * L * P * 3) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
+    if (N <= 0) return S2D_OK;
+    const long items = (long)S * M * 8;
+    const int nb = cdiv(items, 256);
+    hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, lv, offs_logits, ldoa, S, M, L,
+                       P, nb, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                          const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                          int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
+                          hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
+    if (D != 32) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    if (hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipMemsetAsync(grad_loc, 0, sizeof(float) * (size_t)N * Lq * M * L * P * 2, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipMemsetAsync(grad_attn_w, 0, sizeof(float) * (size_t)N * Lq * M * L * P, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    const long items = (long)Lq * M * D;
+    hipLaunchKernelGGL(msda_bwd_kernel, dim3(cdiv(items, 256), N), dim3(256), 0, stream, value, lv, loc, attn_w,
+                       grad_out, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"
