@@ -48,6 +48,63 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
                         int KW, int stride, int pad, const float *scale, const float *bias, const float *res,
                         int relu, hipStream_t stream);
 
+/* ---- multi-scale deformable attention (HBM/L2-bound gather, no MFMA) --------------------------------- */
+
+/* Drop-in for MSDA.ms_deform_attn_forward (ops/src/ms_deform_attn.h:25-44, ops/src/vision.cpp:19; kernel
+ * ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304): value [N,S,M,D], sampling_loc [N,Lq,M,L,P,2] (x,y in
+ * [0,1]), attn_w [N,Lq,M,L,P] -> out [N,Lq,M*D].  spatial shapes [L,2]=(H,W) and level starts [L] are HOST
+ * int64 arrays (they are tiny and known on the host; the reference reads them from device memory).
+ * No im2col_step chunking is needed. */
+int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                         const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P,
+                         float *out, hipStream_t stream);
+
+/* Drop-in for MSDA.ms_deform_attn_backward (ops/src/ms_deform_attn.h:46-66; kernels cuh:306-408, formulas
+ * :119-163).  grad buffers are zero-initialised here, as the reference does (ms_deform_attn_cuda.cu:119-121). */
+int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                          const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                          int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
+                          hipStream_t stream);
+
+/* Fused pixel-decoder form: also does softmax over L*P and loc = ref + off/(W_l,H_l)
+ * (ops/modules/ms_deform_attn.py:101-109) with the query's own pixel centre as reference point
+ * (msdeformattn.py:141-153).  offs_logits [N,S,ldoa]: per query M*L*P*2 raw offsets then M*L*P raw logits.
+ * Requires D == 32, L*P == 12 (the shipped geometry, msdeformattn.py:232-239). */
+int s2d_msda_fused_forward_f32(const float *value, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+                               int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream);
+
+/* ---- bandwidth-bound glue (HBM-bound, 16-B accesses) ----------------------------------------------- */
+
+/* (x - mean)/std per frame + zero pad bottom/right to (Hp,Wp): kd_video_maskformer_model.py:263-269 and
+ * detectron2 ImageList.from_tensors.  frames u8 [F,3,H0,W0] (the mapper's layout, dataset_mapper.py:306-404)
+ * -> out f32 [F,Hp,Wp,4] (NHWC, 4th channel zero so the 7x7 stem runs as a Cin=4 implicit GEMM).
+ * mean3/std3 are HOST arrays. */
+int s2d_normalize_pad_nhwc4_f32(const uint8_t *frames, int F, int H0, int W0, int Hp, int Wp, const float *mean3_host,
+                                const float *std3_host, float *out, hipStream_t stream);
+
+/* 3x3/2 pad 1 max pool, NHWC (detectron2 BasicStem). y [N,(H+1)/2,(W+1)/2,C]. */
+int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float *y, hipStream_t stream);
+
+/* y = GroupNorm_G(x)*gamma+beta [+ bilinear_resize(up [N,hu,wu,C] -> (H,W), align_corners=False)] [relu]; x NHWC.
+ * nn.GroupNorm(32,256) at msdeformattn.py:213-226 and detectron2 get_norm("GN") at :261-281; the fused
+ * upsample-add is msdeformattn.py:349.  stats_ws: 2*N*G doubles of workspace. */
+int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, const float *gamma, const float *beta,
+                           float eps, const float *up, int hu, int wu, int relu, double *stats_ws, float *y,
+                           hipStream_t stream);
+
+/* y = LayerNorm(x + res) over the last dim (res may be NULL): the post-norm residual blocks of
+ * msdeformattn.py:116-131 and video_mask2former_transformer_decoder.py:41-51,99-111,164-168. */
+int s2d_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, long rows, int C,
+                      float eps, float *y, hipStream_t stream);
+
+/* y[i] = x[i] + b[i % bn] (n, bn multiples of 4): with_pos_embed / level-embed adds. */
+int s2d_add_bcast_f32(const float *x, const float *b, long n, long bn, float *y, hipStream_t stream);
+
+/* Sine position encoding written token-major [T*H*W, 2F] (+ add_c[2F] if not NULL).  T == 0: 2-D form
+ * (mask2former/modeling/transformer_decoder/position_encoding.py:29-52); T > 0: 3-D form
+ * (mask2former_video/modeling/transformer_decoder/position_encoding.py:29-57). */
+int s2d_pe_sine_f32(int T, int H, int W, int num_pos_feats, const float *add_c, float *out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ LIBPATH = os.path.join(_HERE, "csrc", "libs2d_hip.so")
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
            "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "hipStream_t": ctypes.c_void_p,
-           "unsigned": ctypes.c_uint}
+           "unsigned": ctypes.c_uint, "uint8_t": ctypes.c_uint8}
 
 
 def parse_header(path=HEADER):
@@ -57,6 +57,8 @@ class _Lib:
                 conv.append(None)
             elif hasattr(a, "data_ptr"):
                 conv.append(a.data_ptr())
+            elif hasattr(a, "ctypes"):  # host numpy array
+                conv.append(a.ctypes.data)
             else:
                 conv.append(a)
         rc = fn(*conv)

@@ -1,0 +1,299 @@
+// Bandwidth-bound glue kernels of the S2D forward (all HBM-bound, 16-B accesses, no MFMA):
+// input normalise+pad, max-pool, GroupNorm (NHWC), LayerNorm(+residual), broadcast adds, sine position
+// encodings, bilinear resize (+add).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// (x - mean) / std, zero-pad to (Hp, Wp), NCHW uint8 -> NHWC float with C padded 3 -> 4
+// kd_video_maskformer_model.py:263-269 (+ detectron2 ImageList.from_tensors zero padding)
+__global__ void normalize_pad_kernel(const uint8_t *__restrict__ in, int F, int H0, int W0, int Hp, int Wp, f32x4 mean,
+                                     f32x4 stdv, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)F * Hp * Wp;
+    if (i >= total) return;
+    const int x = (int)(i % Wp);
+    const int y = (int)((i / Wp) % Hp);
+    const int f = (int)(i / ((long)Wp * Hp));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y < H0 && x < W0) {
+        const uint8_t *p = in + ((long)f * 3 * H0 + y) * W0 + x;
+        const long cs = (long)H0 * W0;
+        v[0] = ((float)p[0] - mean[0]) / stdv[0];
+        v[1] = ((float)p[cs] - mean[1]) / stdv[1];
+        v[2] = ((float)p[2 * cs] - mean[2]) / stdv[2];
+    }
+    *reinterpret_cast<f32x4 *>(out + i * 4) = v;
+}
+
+// 3x3 / stride 2 / pad 1 max pool, NHWC, C % 4 == 0 (detectron2 BasicStem)
+__global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
+                               float *__restrict__ out)
+{
+    const int c4n = C / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * Ho * Wo * c4n;
+    if (i >= total) return;
+    const int c = (int)(i % c4n);
+    long t = i / c4n;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((long)n * H + iy) * W + ix) * C + c * 4);
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+    }
+    *reinterpret_cast<f32x4 *>(out + i * 4) = m;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm over NHWC tokens x [N, HW, C]: stats[n][g] = (sum, sumsq) in double via one atomic per block.
+// 256 threads: thread t owns channel quad c4 = t % (C/4) for rows r = t / (C/4) + k * (256/(C/4)).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int HW, int C, int G, int rows_per_blk,
+                                                       double *__restrict__ stats)
+{
+    extern __shared__ double sh[];  // [2][C/4]
+    const int n = blockIdx.y;
+    const int q = C / 4, tpr = 256 / q;  // threads per row-slot
+    const int c4 = threadIdx.x % q, rslot = threadIdx.x / q;
+    const long r0 = (long)blockIdx.x * rows_per_blk;
+    const long r1 = min((long)HW, r0 + rows_per_blk);
+    double s = 0., ss = 0.;
+    if (rslot < tpr) {
+        const float *base = x + ((long)n * HW) * C + c4 * 4;
+        for (long r = r0 + rslot; r < r1; r += tpr) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(base + r * C);
+            s += (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
+            ss += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * q; i += 256) sh[i] = 0.;
+    __syncthreads();
+    if (rslot < tpr) {
+        atomicAdd(&sh[c4], s);
+        atomicAdd(&sh[q + c4], ss);
+    }
+    __syncthreads();
+    const int cpg4 = (C / G) / 4;  // float4s per group
+    if (threadIdx.x < G) {
+        double a = 0., b = 0.;
+        for (int k = 0; k < cpg4; ++k) { a += sh[threadIdx.x * cpg4 + k]; b += sh[q + threadIdx.x * cpg4 + k]; }
+        atomicAdd(&stats[((long)n * G + threadIdx.x) * 2], a);
+        atomicAdd(&stats[((long)n * G + threadIdx.x) * 2 + 1], b);
+    }
+}
+
+// y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
+__global__ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, int N, int H, int W, int C, int G, float eps,
+                                const float *__restrict__ up, int hu, int wu, int relu, float *__restrict__ y)
+{
+    const int q = C / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * H * W * q;
+    if (i >= total) return;
+    const int c4 = (int)(i % q);
+    const long pix = i / q;
+    const int n = (int)(pix / ((long)H * W));
+    const int g = (c4 * 4) / (C / G);
+    const double cnt = (double)H * W * (C / G);
+    const double mu = stats[((long)n * G + g) * 2] / cnt;
+    const double var = stats[((long)n * G + g) * 2 + 1] / cnt - mu * mu;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mu;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + i * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4 * 4);
+    v = (v - mean) * rstd * ga + be;
+    if (up) {
+        // F.interpolate(bilinear, align_corners=False) source index rule (msdeformattn.py:349)
+        const int px = (int)(pix % W), py = (int)((pix / W) % H);
+        float sy = ((float)hu / H) * (py + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = ((float)wu / W) * (px + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hu - 1 ? 1 : 0), x1 = x0 + (x0 < wu - 1 ? 1 : 0);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *ub = up + (long)n * hu * wu * C + c4 * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ub + ((long)y0 * wu + x0) * C);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(ub + ((long)y0 * wu + x1) * C);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(ub + ((long)y1 * wu + x0) * C);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(ub + ((long)y1 * wu + x1) * C);
+        v += hy * (hx * a + lx * b) + ly * (hx * c + lx * d);
+    }
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    *reinterpret_cast<f32x4 *>(y + i * 4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y = LayerNorm(x + res) over the last dim C (C % 4 == 0, C <= 1024): one wavefront per row.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        long rows, int C, float eps, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = C / 4;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c4 = lane + 64 * k;
+        v[k] = f32x4(0.f);
+        if (c4 < q) {
+            v[k] = *reinterpret_cast<const f32x4 *>(x + row * C + c4 * 4);
+            if (res) v[k] += *reinterpret_cast<const f32x4 *>(res + row * C + c4 * 4);
+            s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < q) {
+            const f32x4 d = v[k] - mean;
+            ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < q) {
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4 * 4);
+            *reinterpret_cast<f32x4 *>(y + row * C + c4 * 4) = (v[k] - mean) * rstd * ga + be;
+        }
+    }
+}
+
+// y[n][r][:] = x[n][r][:] + b[r % brows][:]   (broadcast add of a [brows, C] table over the batch)
+__global__ void add_bcast_kernel(const float *__restrict__ x, const float *__restrict__ b, long n4, long b4,
+                                 float *__restrict__ y)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    *reinterpret_cast<f32x4 *>(y + i * 4) =
+        *reinterpret_cast<const f32x4 *>(x + i * 4) + *reinterpret_cast<const f32x4 *>(b + (i % b4) * 4);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sine position encodings, written token-major [T*H*W, C] (== NHWC), plus an optional per-channel addend
+// (the level embedding).  2-D: mask2former/modeling/transformer_decoder/position_encoding.py:29-52
+// (normalize=True, scale 2*pi, temperature 1e4); 3-D: mask2former_video/.../position_encoding.py:29-57
+// (z term over frames is ADDED to cat(pos_y, pos_x), :44-56).  T == 0 selects the 2-D form.
+__global__ void pe_sine_kernel(int T, int H, int W, int F, const float *__restrict__ addc, float *__restrict__ out)
+{
+    const int C = 2 * F;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tt = T > 0 ? T : 1;
+    const long total = tt * H * W * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int z = (int)(t / H);
+    const float scale = 6.283185307179586f, eps = 1e-6f;
+    const bool is_y = c < F;
+    const int j = is_y ? c : c - F;
+    const float e = is_y ? (float)(y + 1) / ((float)H + eps) * scale : (float)(x + 1) / ((float)W + eps) * scale;
+    const float dim_t = powf(10000.f, (float)(2 * (j / 2)) / (float)F);
+    const float a = e / dim_t;
+    float v = (j & 1) ? cosf(a) : sinf(a);
+    if (T > 0) {
+        const float ez = (float)(z + 1) / ((float)T + eps) * scale;
+        const float dz = powf(10000.f, (float)(2 * (c / 2)) / (float)C);
+        const float az = ez / dz;
+        v += (c & 1) ? cosf(az) : sinf(az);
+    }
+    if (addc) v += addc[c];
+    out[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_normalize_pad_nhwc4_f32(const uint8_t *frames, int F, int H0, int W0, int Hp, int Wp, const float *mean3_host,
+                                const float *std3_host, float *out, hipStream_t stream)
+{
+    if (Hp < H0 || Wp < W0) return S2D_ERR_ARG;
+    const long total = (long)F * Hp * Wp;
+    if (total == 0) return S2D_OK;
+    f32x4 m = {mean3_host[0], mean3_host[1], mean3_host[2], 0.f}, s = {std3_host[0], std3_host[1], std3_host[2], 1.f};
+    hipLaunchKernelGGL(normalize_pad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, frames, F, H0, W0, Hp, Wp, m,
+                       s, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float *y, hipStream_t stream)
+{
+    if (C & 3) return S2D_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, const float *gamma, const float *beta,
+                           float eps, const float *up, int hu, int wu, int relu, double *stats_ws, float *y,
+                           hipStream_t stream)
+{
+    if ((C & 3) || C / 4 > 256 || 256 % (C / 4) || C % G || (C / G) & 3 || G > 256) return S2D_ERR_ARG;
+    const long HW = (long)H * W;
+    if (N == 0 || HW == 0) return S2D_OK;
+    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * N * G, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    const int rows_per_blk = 256;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(HW, rows_per_blk), N), dim3(256), sizeof(double) * 2 * (C / 4), stream,
+                       x, (int)HW, C, G, rows_per_blk, stats_ws);
+    const long total = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W, C,
+                       G, eps, up, hu, wu, relu, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, long rows, int C,
+                      float eps, float *y, hipStream_t stream)
+{
+    if ((C & 3) || C > 1024) return S2D_ERR_ARG;
+    if (rows == 0) return S2D_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, res, gamma, beta, rows, C, eps, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_add_bcast_f32(const float *x, const float *b, long n, long bn, float *y, hipStream_t stream)
+{
+    if ((n & 3) || (bn & 3) || bn == 0 || n % bn) return S2D_ERR_ARG;
+    if (n == 0) return S2D_OK;
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, x, b, n / 4, bn / 4, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_pe_sine_f32(int T, int H, int W, int num_pos_feats, const float *add_c, float *out, hipStream_t stream)
+{
+    const long total = (long)(T > 0 ? T : 1) * H * W * 2 * num_pos_feats;
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(pe_sine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, T, H, W, num_pos_feats, add_c, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

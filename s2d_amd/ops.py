@@ -48,3 +48,107 @@ def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=Fal
     lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu),
                _stream())
     return y
+
+
+# ----------------------------------------------------------------------------- MSDeformAttn
+import numpy as _np
+
+
+def _host_i64(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return _np.ascontiguousarray(a, dtype=_np.int64)
+
+
+def msda_forward(value, shapes, level_start, loc, attn_w):
+    """value [N,S,M,D], loc [N,Lq,M,L,P,2], attn_w [N,Lq,M,L,P] -> [N,Lq,M*D]."""
+    for t in (value, loc, attn_w):
+        _chk(t)
+    N, S, M, D = value.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    sh, ls = _host_i64(shapes), _host_i64(level_start)
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+    lib().call("s2d_msda_forward_f32", value, sh, ls, loc, attn_w, N, S, M, D, L, Lq, P, out, _stream())
+    return out
+
+
+def msda_backward(value, shapes, level_start, loc, attn_w, grad_out):
+    for t in (value, loc, attn_w, grad_out):
+        _chk(t)
+    N, S, M, D = value.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    sh, ls = _host_i64(shapes), _host_i64(level_start)
+    gv, gl, gw = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn_w)
+    lib().call("s2d_msda_backward_f32", value, sh, ls, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw, _stream())
+    return gv, gl, gw
+
+
+def msda_fused_forward(value, shapes, offs_logits, M=8, P=4):
+    """value [N,S,M*D]; offs_logits [N,S,>=M*L*P*3] -> [N,S,M*D]."""
+    _chk(value); _chk(offs_logits)
+    N, S, C = value.shape
+    sh = _host_i64(shapes)
+    L = sh.shape[0]
+    out = torch.empty((N, S, C), device=value.device, dtype=torch.float32)
+    lib().call("s2d_msda_fused_forward_f32", value, sh, offs_logits, offs_logits.shape[-1], N, S, M, C // M, L, P, out,
+               _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- glue
+PIXEL_MEAN = _np.array([123.675, 116.28, 103.53], _np.float32)
+PIXEL_STD = _np.array([58.395, 57.12, 57.375], _np.float32)
+
+
+def normalize_pad(frames_u8, div=32, mean=PIXEL_MEAN, std=PIXEL_STD):
+    """frames u8 [F,3,H0,W0] -> f32 [F,Hp,Wp,4]."""
+    _chk(frames_u8, torch.uint8)
+    F_, _, H0, W0 = frames_u8.shape
+    Hp, Wp = (H0 + div - 1) // div * div, (W0 + div - 1) // div * div
+    out = torch.empty((F_, Hp, Wp, 4), device=frames_u8.device, dtype=torch.float32)
+    lib().call("s2d_normalize_pad_nhwc4_f32", frames_u8, F_, H0, W0, Hp, Wp, _np.ascontiguousarray(mean, _np.float32),
+               _np.ascontiguousarray(std, _np.float32), out, _stream())
+    return out
+
+
+def maxpool3x3s2(x):
+    _chk(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=torch.float32)
+    lib().call("s2d_maxpool3x3s2_nhwc_f32", x, N, H, W, C, y, _stream())
+    return y
+
+
+def groupnorm_nhwc(x, G, gamma, beta, up=None, relu=False, eps=1e-5):
+    for t in (x, gamma, beta, up):
+        _chk(t)
+    N, H, W, C = x.shape
+    ws = torch.empty((N * G * 2,), device=x.device, dtype=torch.float64)
+    y = torch.empty_like(x)
+    hu, wu = (up.shape[1], up.shape[2]) if up is not None else (0, 0)
+    lib().call("s2d_groupnorm_nhwc_f32", x, N, H, W, C, G, gamma, beta, float(eps), up, hu, wu, int(relu), ws, y, _stream())
+    return y
+
+
+def layernorm(x, gamma, beta, res=None, eps=1e-5):
+    for t in (x, gamma, beta, res):
+        _chk(t)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    lib().call("s2d_layernorm_f32", x, res, gamma, beta, x.numel() // C, C, float(eps), y, _stream())
+    return y
+
+
+def add_bcast(x, b):
+    _chk(x); _chk(b)
+    y = torch.empty_like(x)
+    lib().call("s2d_add_bcast_f32", x, b, x.numel(), b.numel(), y, _stream())
+    return y
+
+
+def pe_sine(T, H, W, num_pos_feats=128, add_c=None, device="cuda"):
+    """-> [max(T,1)*H*W, 2*num_pos_feats] token-major."""
+    _chk(add_c)
+    out = torch.empty((max(T, 1) * H * W, 2 * num_pos_feats), device=device, dtype=torch.float32)
+    lib().call("s2d_pe_sine_f32", T, H, W, num_pos_feats, add_c, out, _stream())
+    return out

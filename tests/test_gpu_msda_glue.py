@@ -1,0 +1,104 @@
+"""GPU parity: MSDeformAttn kernels and the bandwidth-bound glue kernels vs goldens / the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from s2d_amd.utils import synth
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, rtol):
+    b = np.asarray(b, np.float64)
+    np.testing.assert_allclose(np.asarray(a, np.float64), b, rtol=rtol, atol=rtol * max(np.abs(b).max(), 1e-30))
+
+
+def test_msda_optest_fixture(oracle):
+    """the reference's only known-answer test (ops/test.py:24-31,51-63), D=2 -> scalar path"""
+    from s2d_amd import ops
+    g = golden("msda_optest")
+    lsi = oracle.level_start_index(g["shapes"])
+    out = ops.msda_forward(_dev(g["value"]), g["shapes"], lsi, _dev(g["loc"]), _dev(g["w"])).cpu().numpy()
+    np.testing.assert_allclose(out, g["out32"], rtol=1e-2, atol=1e-3)     # the reference's own tolerance
+    np.testing.assert_allclose(out, g["out64"], rtol=1e-5, atol=1e-7)
+
+
+def test_msda_forward_backward_golden(oracle):
+    from s2d_amd import ops
+    g = golden("msda_core")
+    lsi = oracle.level_start_index(g["shapes"])
+    v, lo, w = _dev(g["value"]), _dev(g["loc"]), _dev(g["w"])
+    out = ops.msda_forward(v, g["shapes"], lsi, lo, w).cpu().numpy()
+    close(out, g["out"], 1e-5)
+    gv, gl, gw = ops.msda_backward(v, g["shapes"], lsi, lo, w, _dev(g["grad_out"]))
+    close(gv.cpu().numpy(), g["grad_value"], 1e-4)
+    close(gl.cpu().numpy(), g["grad_loc"], 1e-4)
+    close(gw.cpu().numpy(), g["grad_w"], 1e-4)
+
+
+def test_msda_fused_vs_oracle_720p_shapes(oracle):
+    """fused softmax+loc+gather at a mid-size pyramid, against the oracle's module arithmetic"""
+    from s2d_amd import ops
+    shapes = [(6, 10), (12, 20), (23, 40)]
+    S = sum(h * w for h, w in shapes)
+    N, M, D, L, P = 2, 8, 32, 3, 4
+    value = synth.randn(7, 1, (N, S, M * D))
+    off = synth.randn(7, 2, (N, S, M, L, P, 2), 2.0)
+    lg = synth.randn(7, 3, (N, S, M, L * P))
+    oa = np.concatenate([off.reshape(N, S, -1), lg.reshape(N, S, -1)], -1)
+    ref_pts = oracle.reference_points(shapes)
+    norm = np.array([[w_, h_] for (h_, w_) in shapes], np.float32)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = oracle.softmax(lg, -1).reshape(N, S, M, L, P)
+    ref = oracle.msda_core(value.reshape(N, S, M, D), np.array(shapes), oracle.level_start_index(shapes),
+                           loc.astype(np.float32), aw.astype(np.float32))
+    out = ops.msda_fused_forward(_dev(value), np.array(shapes), _dev(oa)).cpu().numpy()
+    close(out, ref, 1e-5)
+    # and the drop-in form on the same data
+    out2 = ops.msda_forward(_dev(value.reshape(N, S, M, D)), np.array(shapes), oracle.level_start_index(shapes),
+                            _dev(loc.astype(np.float32)), _dev(aw.astype(np.float32))).cpu().numpy()
+    close(out2, ref, 1e-5)
+
+
+def test_normalize_pad_maxpool(oracle):
+    from s2d_amd import ops
+    fr = synth.smooth_frames_u8(3, 1, 2, 45, 70)
+    ref = oracle.normalize_pad(fr)                       # [F,3,Hp,Wp]
+    out = ops.normalize_pad(_dev(fr)).cpu().numpy()
+    assert out.shape == (2, 64, 96, 4)
+    close(out[..., :3].transpose(0, 3, 1, 2), ref, 1e-6)
+    assert (out[..., 3] == 0).all()
+    x = synth.randn(3, 2, (2, 64, 17, 23))
+    y = ops.maxpool3x3s2(_dev(x.transpose(0, 2, 3, 1))).cpu().numpy().transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(y, oracle.max_pool_3x3_s2_p1(x))
+
+
+def test_groupnorm_layernorm_add_pe(oracle):
+    from s2d_amd import ops
+    x = synth.randn(4, 1, (2, 256, 12, 20)) * 3 + 1
+    ga, be = synth.randn(4, 2, (256,)) * 0.1 + 1, synth.randn(4, 3, (256,)) * 0.1
+    ref = oracle.group_norm(x, 32, ga, be)
+    xd = _dev(x.transpose(0, 2, 3, 1))
+    y = ops.groupnorm_nhwc(xd, 32, _dev(ga), _dev(be)).cpu().numpy().transpose(0, 3, 1, 2)
+    close(y, ref, 1e-5)
+    up = synth.randn(4, 4, (2, 256, 6, 10))
+    ref2 = np.maximum(ref + oracle.resize_bilinear(up, 12, 20), 0)
+    y2 = ops.groupnorm_nhwc(xd, 32, _dev(ga), _dev(be), up=_dev(up.transpose(0, 2, 3, 1)), relu=True)
+    close(y2.cpu().numpy().transpose(0, 3, 1, 2), ref2, 1e-5)
+    # layernorm(x + res)
+    a, r = synth.randn(4, 5, (3, 50, 256)), synth.randn(4, 6, (3, 50, 256))
+    close(ops.layernorm(_dev(a), _dev(ga), _dev(be), res=_dev(r)).cpu().numpy(), oracle.layer_norm(a + r, ga, be), 1e-5)
+    # broadcast add
+    b = synth.randn(4, 7, (50, 256))
+    close(ops.add_bcast(_dev(a), _dev(b)).cpu().numpy(), a + b[None], 1e-7)
+    # position encodings vs the reference goldens
+    g = golden("pe")
+    pe2 = ops.pe_sine(0, 5, 7).cpu().numpy().reshape(5, 7, 256).transpose(2, 0, 1)
+    np.testing.assert_allclose(pe2, g["pe2"][0], rtol=0, atol=2e-5)
+    pe3 = ops.pe_sine(3, 4, 6).cpu().numpy().reshape(3, 4, 6, 256).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(pe3, g["pe3"][0], rtol=0, atol=2e-5)
