@@ -105,6 +105,25 @@ int s2d_add_bcast_f32(const float *x, const float *b, long n, long bn, float *y,
  * (mask2former_video/modeling/transformer_decoder/position_encoding.py:29-57). */
 int s2d_pe_sine_f32(int T, int H, int W, int num_pos_feats, const float *add_c, float *out, hipStream_t stream);
 
+/* ---- masked cross-attention of the video decoder (fp32 MFMA QK^T / AV, streamed over keys) ----------- */
+
+/* Attention-mask builder: bilinear-resize the pixel-major mask logits [B][T*hm*wm][ldq] to the level size
+ * (hl,wl), threshold sigmoid<0.5 (== logit<0) and pack to bits [B][K=T*hl*wl][4] (bit q set = query q must NOT
+ * attend key); unmasked [B][4] gets bit q set iff query q has at least one attendable key.
+ * video_mask2former_transformer_decoder.py:460-465 (the x8 head repeat is implicit: heads share the bits). */
+int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl,
+                       uint32_t *bits, uint32_t *unmasked, hipStream_t stream);
+
+/* floats of workspace s2d_masked_attn_f32 needs */
+long s2d_attn_workspace_floats(int B, int H, int K);
+
+/* out[b][q][:] = concat_h softmax_k(q_h k_h^T / sqrt(32) + mask) v_h with q [B][Q][C], k/v [B][K][C] already
+ * projected, C = 32*H, Q <= 128.  bits/unmasked from s2d_attn_mask_bits (NULL = no mask: the self-attention
+ * of :41-51); a query with no attendable key attends everywhere (the fix at :413).  Replaces the core of
+ * nn.MultiheadAttention at :99-111 without materialising the [B*8,Q,K] mask or the scores. */
+int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *unmasked,
+                        int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

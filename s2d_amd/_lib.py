@@ -13,7 +13,7 @@ LIBPATH = os.path.join(_HERE, "csrc", "libs2d_hip.so")
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
            "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "hipStream_t": ctypes.c_void_p,
-           "unsigned": ctypes.c_uint, "uint8_t": ctypes.c_uint8}
+           "unsigned": ctypes.c_uint, "uint8_t": ctypes.c_uint8, "uint32_t": ctypes.c_uint32}
 
 
 def parse_header(path=HEADER):
@@ -21,8 +21,8 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(s2d_\w+)\s*\(([^)]*)\)\s*;", src):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|long)\s+(s2d_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":
             for a in args.split(","):
@@ -32,7 +32,7 @@ def parse_header(path=HEADER):
                 else:
                     base = a.replace("const", "").split()[0]
                     types.append(_CTYPES[base])
-        protos[name] = types
+        protos[name] = (types, ret)
     return protos
 
 
@@ -43,10 +43,10 @@ class _Lib:
         import torch  # noqa: F401  (loads the process's libamdhip64 first so both share one HIP runtime)
         self._dll = ctypes.CDLL(LIBPATH)
         self.protos = parse_header()
-        for name, types in self.protos.items():
+        for name, (types, ret) in self.protos.items():
             fn = getattr(self._dll, name)  # AttributeError if the library lacks a declared symbol
             fn.argtypes = types
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_long if ret == "long" else ctypes.c_int
             setattr(self, "_raw_" + name, fn)
 
     def call(self, name, *args):
@@ -62,6 +62,8 @@ class _Lib:
             else:
                 conv.append(a)
         rc = fn(*conv)
+        if self.protos[name][1] == "long" or name == "s2d_abi_version":
+            return rc
         if rc != 0:
             raise RuntimeError(f"{name} failed with code {rc}")
 

@@ -1,0 +1,286 @@
+// Masked cross-attention of the video decoder, streamed over the key axis (never materialises the
+// [B*8, Q, K] bool mask nor the score matrix), plus the attention-mask builder.
+//
+// Replaces, per decoder layer (video_mask2former_transformer_decoder.py):
+//   :460-465  F.interpolate(outputs_mask -> level size) ; sigmoid() < 0.5 ; repeat over 8 heads
+//   :413      rows that are entirely masked are reset to all-False
+//   :99-111   nn.MultiheadAttention core: softmax(q k^T / sqrt(d) + mask) v   (projections are GEMMs)
+//
+// Layouts: keys of clip b are the NHWC tokens of its T frames, [B][K = T*h*w][256] (t-major, matching the
+// reference's (T*hw) x B x C order at :394-397); mask logits are pixel-major [B][T*hm*wm][ldq] (the natural
+// row-major output of the mask-logit GEMM); the attention mask is a bit matrix [B][K][4 words] (bit q of a
+// key's 128-bit row = "query q may NOT attend"), 16 B per key instead of 8*Q bytes.
+//
+// Cross-attention kernel: one workgroup = (clip, head, key split); 4 waves = 4 x 32 queries.  Scores are
+// computed TRANSPOSED on the fp32 MFMA, S^T[key][q] = K . Q^T (A = K tile from LDS, B = Q in registers), so
+// a lane owns one query column: the online-softmax max/sum are per-lane scalars, and the probabilities P
+// (the accumulator registers) are directly the B operand of O^T[d][q] += V^T . P^T -- no LDS round trip
+// for P and no cross-lane rescale.  Partial (O, m, l) per key split are merged by a second tiny kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int QW = 4;            // 32-bit mask words per key (Q <= 128)
+constexpr int KT = 32;           // keys per tile
+constexpr int LSTR = 36;         // LDS row stride (floats)
+
+// ------------------------------------------------------------------------------------------------
+// attention-mask builder: 32 lanes per key, lane g owns queries 4g..4g+3
+__global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
+                                                        int hl, int wl, uint32_t *__restrict__ bits,
+                                                        uint32_t *__restrict__ unmasked)
+{
+    __shared__ uint32_t um[QW];
+    const int b = blockIdx.y;
+    const long K = (long)T * hl * wl;
+    if (threadIdx.x < QW) um[threadIdx.x] = 0u;
+    __syncthreads();
+    const int g = threadIdx.x & 31;
+    const long key = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    uint32_t nib = 0u, valid = 0u;
+    if (key < K) {
+        const int x = (int)(key % wl), y = (int)((key / wl) % hl), t = (int)(key / ((long)wl * hl));
+        // ATen bilinear source index, align_corners=False
+        float sy = ((float)hm / hl) * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = ((float)wm / wl) * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hm - 1 ? 1 : 0), x1 = x0 + (x0 < wm - 1 ? 1 : 0);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *base = ml + ((long)b * T + t) * hm * wm * ldq;
+        const int q0 = 4 * g;
+        if (q0 < Q) {
+            float v[4];
+            const float *p00 = base + ((long)y0 * wm + x0) * ldq + q0, *p01 = base + ((long)y0 * wm + x1) * ldq + q0;
+            const float *p10 = base + ((long)y1 * wm + x0) * ldq + q0, *p11 = base + ((long)y1 * wm + x1) * ldq + q0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (q0 + j < Q) {
+                    v[j] = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
+                    valid |= 1u << j;
+                    // sigmoid(v) < 0.5  <=>  v < 0   (:463)
+                    if (v[j] < 0.f) nib |= 1u << j;
+                }
+            }
+        }
+    }
+    // assemble 32-bit words from 8 lanes' nibbles
+    uint32_t w = nib << (4 * (g & 7));
+    uint32_t open = (valid & ~nib) << (4 * (g & 7));   // queries that CAN attend this key
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        w |= __shfl_xor(w, o, 64);
+        open |= __shfl_xor(open, o, 64);
+    }
+    if ((g & 7) == 0 && key < K) {
+        bits[((long)b * K + key) * QW + (g >> 3)] = w;
+        if (open) atomicOr(&um[g >> 3], open);
+    }
+    __syncthreads();
+    if (threadIdx.x < QW && um[threadIdx.x]) atomicOr(&unmasked[b * QW + threadIdx.x], um[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const float *q, *k, *v;      // q [B][Q][C] (projected, unscaled); k, v [B][K][C]
+    const uint32_t *bits;        // [B][K][QW] or null
+    const uint32_t *unmasked;    // [B][QW] or null
+    float *wo, *wm, *wl;         // partials: wo [B][H][S][32][128], wm/wl [B][H][S][128]
+    int Q, K, C, H, S, tiles_per_split;
+    float qscale;                // 1/sqrt(d) * log2(e)
+};
+
+__global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
+{
+    __shared__ __attribute__((aligned(16))) float Ks[2][KT][LSTR];
+    __shared__ __attribute__((aligned(16))) float Vs[2][KT][LSTR];
+    __shared__ uint32_t Ms[2][KT][QW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int q = wv * 32 + l32;
+    const bool qok = q < p.Q;
+
+    // Q fragment in registers, k-order matched to the K tile reads: element j of group g is dim 8g+4h+j
+    float qr[16];
+    {
+        const float *qp = p.q + ((long)b * p.Q + (qok ? q : 0)) * p.C + hd * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = qok ? *reinterpret_cast<const f32x4 *>(qp + 8 * g) : f32x4(0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qr[4 * g + j] = t[j] * p.qscale;
+        }
+    }
+    bool use_mask = p.bits != nullptr;
+    if (use_mask && p.unmasked) {
+        // a query whose every key is masked attends everywhere instead (:413)
+        const uint32_t u = p.unmasked[b * QW + wv];
+        if (!((u >> l32) & 1u)) use_mask = false;
+    }
+
+    const int tile0 = split * p.tiles_per_split;
+    const int ntiles_all = (p.K + KT - 1) / KT;
+    const int tile1 = min(ntiles_all, tile0 + p.tiles_per_split);
+
+    // staging: thread t loads float4 #(t&7) of key row (t>>3) for K and V; threads < 128 load one mask word
+    const int srow = tid >> 3, sc4 = tid & 7;
+    const float *kbase = p.k + (long)b * p.K * p.C + hd * 32 + sc4 * 4;
+    const float *vbase = p.v + (long)b * p.K * p.C + hd * 32 + sc4 * 4;
+    f32x4 rk, rv;
+    uint32_t rm = 0u;
+    auto load_tile = [&](int tile) {
+        const long key = (long)tile * KT + srow;
+        rk = f32x4(0.f); rv = f32x4(0.f);
+        if (key < p.K) {
+            rk = *reinterpret_cast<const f32x4 *>(kbase + key * p.C);
+            rv = *reinterpret_cast<const f32x4 *>(vbase + key * p.C);
+        }
+        if (p.bits && tid < KT * QW) {
+            const long mk = (long)tile * KT + (tid >> 2);
+            rm = mk < p.K ? p.bits[((long)b * p.K + mk) * QW + (tid & 3)] : 0xFFFFFFFFu;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        *reinterpret_cast<f32x4 *>(&Ks[buf][srow][sc4 * 4]) = rk;
+        *reinterpret_cast<f32x4 *>(&Vs[buf][srow][sc4 * 4]) = rv;
+        if (p.bits && tid < KT * QW) Ms[buf][tid >> 2][tid & 3] = rm;
+    };
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    if (tile0 < tile1) {
+        load_tile(tile0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        if (tile + 1 < tile1) load_tile(tile + 1);
+
+        // S^T[key][q] = sum_d K[key][d] * Q[q][d]
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 kf = *reinterpret_cast<const f32x4 *>(&Ks[cur][l32][8 * g + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qr[4 * g + j], s, 0, 0, 0);
+        }
+        // mask + tail, tile max
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            bool dead = (long)tile * KT + kr >= p.K;
+            if (use_mask) dead = dead || ((Ms[cur][kr][wv] >> l32) & 1u);
+            s[r] = dead ? -INFINITY : s[r];
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(s[r] - mn);
+            ps += s[r];
+        }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        // O^T[d][q] += sum_key V[key][d] * P[q][key];   lane half h owns keys (r&3)+8(r>>2)+4h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][kr][l32], s[r], o, 0, 0, 0);
+        }
+        if (tile + 1 < tile1) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    const long pidx = (((long)b * p.H + hd) * p.S + split);
+    if (h == 0) {
+        p.wm[pidx * 128 + q] = m;
+        p.wl[pidx * 128 + q] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+        p.wo[(pidx * 32 + d) * 128 + q] = o[r];
+    }
+}
+
+// merge the S partials: out[b][q][hd*32+d]
+__global__ void attn_merge_kernel(const float *__restrict__ wo, const float *__restrict__ wm, const float *__restrict__ wl,
+                                  int B, int Q, int C, int H, int S, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * H * 32 * 128;
+    if (i >= total) return;
+    const int q = (int)(i % 128);
+    const int d = (int)((i / 128) % 32);
+    const int hd = (int)((i / (128 * 32)) % H);
+    const int b = (int)(i / ((long)128 * 32 * H));
+    if (q >= Q) return;
+    const long base = ((long)b * H + hd) * S;
+    float M = -1e30f;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, wm[(base + s) * 128 + q]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float f = exp2f(wm[(base + s) * 128 + q] - M);
+        L += wl[(base + s) * 128 + q] * f;
+        O += wo[((base + s) * 32 + d) * 128 + q] * f;
+    }
+    out[((long)b * Q + q) * C + hd * 32 + d] = O / L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl,
+                       uint32_t *bits, uint32_t *unmasked, hipStream_t stream)
+{
+    if (Q > 128 || Q <= 0 || ldq < Q) return S2D_ERR_ARG;
+    const long K = (long)T * hl * wl;
+    if (B == 0 || K == 0) return S2D_OK;
+    if (hipMemsetAsync(unmasked, 0, sizeof(uint32_t) * QW * B, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_mask_kernel, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl, wl,
+                       bits, unmasked);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+long s2d_attn_workspace_floats(int B, int H, int K)
+{
+    const int tiles = (K + KT - 1) / KT;
+    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;
+    return (long)B * H * S * (32 * 128 + 2 * 128);
+}
+
+int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *unmasked,
+                        int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream)
+{
+    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0) return S2D_ERR_ARG;
+    if (B == 0) return S2D_OK;
+    const int tiles = (K + KT - 1) / KT;
+    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v; p.bits = bits; p.unmasked = unmasked;
+    p.Q = Q; p.K = K; p.C = C; p.H = H; p.S = S; p.tiles_per_split = (tiles + S - 1) / S;
+    p.wo = workspace;
+    p.wm = workspace + (long)B * H * S * 32 * 128;
+    p.wl = p.wm + (long)B * H * S * 128;
+    p.qscale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
+    hipLaunchKernelGGL(cross_attn_kernel, dim3(S, H, B), dim3(256), 0, stream, p);
+    const long total = (long)B * H * 32 * 128;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.wo, p.wm, p.wl, B, Q, C, H, S, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

@@ -152,3 +152,27 @@ def pe_sine(T, H, W, num_pos_feats=128, add_c=None, device="cuda"):
     out = torch.empty((max(T, 1) * H * W, 2 * num_pos_feats), device=device, dtype=torch.float32)
     lib().call("s2d_pe_sine_f32", T, H, W, num_pos_feats, add_c, out, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- masked attention
+def attn_mask_bits(mask_logits, B, Q, T, hm, wm, hl, wl):
+    """mask_logits pixel-major [B, T*hm*wm, ldq] -> (bits int32 [B,K,4], unmasked int32 [B,4])."""
+    _chk(mask_logits)
+    K = T * hl * wl
+    bits = torch.empty((B, K, 4), device=mask_logits.device, dtype=torch.int32)
+    unm = torch.empty((B, 4), device=mask_logits.device, dtype=torch.int32)
+    lib().call("s2d_attn_mask_bits", mask_logits, mask_logits.shape[-1], B, Q, T, hm, wm, hl, wl, bits, unm, _stream())
+    return bits, unm
+
+
+def masked_attn(q, k, v, bits=None, unmasked=None, H=8):
+    """q [B,Q,C], k/v [B,K,C] (projected) -> [B,Q,C]."""
+    for t in (q, k, v):
+        _chk(t)
+    B, Q, C = q.shape
+    K = k.shape[1]
+    n = lib().call("s2d_attn_workspace_floats", B, H, K)
+    ws = torch.empty((n,), device=q.device, dtype=torch.float32)
+    out = torch.empty_like(q)
+    lib().call("s2d_masked_attn_f32", q, k, v, bits, unmasked, B, Q, K, C, H, ws, out, _stream())
+    return out
