@@ -124,6 +124,61 @@ long s2d_attn_workspace_floats(int B, int H, int K);
 int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *unmasked,
                         int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream);
 
+/* ---- VideoHungarianMatcher on the device -------------------------------------------------------------- */
+/* A criterion pass handles NL prediction layers x B clips = NL*B independent "problems" (problem = layer*B +
+ * clip) in one call.  Targets of the pass: tgt u8 [B][Nmax][T][H][W] with the per-clip count in DEVICE memory
+ * (tgt_count[B]) so that distillation targets, whose number depends on teacher scores, need no host sync.
+ * mask_logits are pixel-major [NL][B][T*hm*wm][ldq]; class_logits [NL][B][Q][2]. */
+
+long s2d_matcher_workspace_floats(int NL, int B);
+
+/* C[problem][Q][Nmax] (columns >= tgt_count[clip] are zero) = w_mask*cost_mask + w_class*cost_class +
+ * w_dice*cost_dice at P shared random points per problem: matcher.py:236-287 (batch_sigmoid_ce_loss :38-62,
+ * batch_dice_loss :15-30, point_sample).  coords [NL][B][P][2] injects the torch.rand(1,P,2) draws of :252
+ * (parity mode); NULL = counter-based device RNG keyed by (seed, problem, point). */
+int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
+                         const float *coords, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                         int W, int Nmax, int P, float w_class, float w_mask, float w_dice, float *workspace, float *C,
+                         hipStream_t stream);
+
+/* scipy.optimize.linear_sum_assignment (matcher.py:289) for nprob cost matrices C[problem][Q][Nmax] using the
+ * first tgt_count[problem % B] columns.  idx_q/idx_t [nprob][min(Q,Nmax)] receive (query, target) pairs in scipy's
+ * order (queries ascending), n_match[nprob] their number = min(Q, N).  Q <= 128, Nmax <= 128, Q*Nmax <= 12800. */
+int s2d_lsap_f32(const float *C, const int *tgt_count, int nprob, int B, int Q, int Nmax, int *idx_q, int *idx_t,
+                 int *n_match, hipStream_t stream);
+
+/* ---- VideoSetCriterion on the device + distillation targets ------------------------------------------ */
+
+/* prepare_distillation_targets (kd_video_maskformer_model.py:436-468, nms off): per clip keep the queries whose
+ * teacher score softmax(logits)[q][0] is among the top `topk` and >= score_thr, in ascending query order, and
+ * write masks = bilinear(teacher mask logits [B][T*hm*wm][ldq] -> (H,W), align_corners=False) > 0 as u8 planes
+ * tgt [B][Nmax][T][H][W]; count[B], kept_q[B][Nmax], nonempty[B][Nmax][T] (DropLoss predicate) on the device. */
+int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, float score_thr, int topk, int B, int Q,
+                      int ldq, int T, int hm, int wm, int H, int W, int Nmax, uint8_t *tgt, int *count, int *kept_q,
+                      int *nonempty, hipStream_t stream);
+
+/* nonempty[b][n][t] = any(tgt[b][n][t]) for ground-truth targets (criterion.py:310-313). H*W % 16 == 0. */
+int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, int T, int H, int W, int *nonempty,
+                        hipStream_t stream);
+
+long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm);
+
+/* loss_masks for NL layers at once (criterion.py:292-356, point_features.py:63-116): losses[layer][0] = loss_mask,
+ * [1] = loss_dice, both already divided by num_masks = max(sum_b tgt_count[b] / world_size, 1) (:404-409).
+ * idx_q/idx_t/n_match from s2d_lsap_f32.  coords_over [NL][B*maxm*T][int(P*oversample)][2] and
+ * coords_rand [NL][B*maxm*T][P - int(importance*P)][2] inject the two torch.rand draws of
+ * point_features.py:90,112, indexed by the row's rank among the kept rows of its layer (parity mode);
+ * NULL = device RNG.  drop_empty = temporal DropLoss ("masks-only" strategy, criterion.py:307-322). */
+int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                       const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
+                       const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                       int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
+                       float world_size, void *workspace, float *losses, hipStream_t stream);
+
+/* loss_labels (criterion.py:227-251) for one layer: class_logits [B][Q][2], idx_q [B][maxm], n_match [B]. */
+int s2d_class_loss_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,
+                       float eos_coef, float *loss_ce, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

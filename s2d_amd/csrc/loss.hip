@@ -1,0 +1,513 @@
+// VideoSetCriterion on the device (model_training/mask2former_video/modeling/criterion.py) and the
+// distillation-target preparation (kd_video_maskformer_model.py:418-528), batched over all prediction layers
+// and clips of a criterion pass, with no device->host synchronisation (the reference syncs once per target
+// row in the DropLoss loop, criterion.py:310-322, and materialises [R,3P] point tensors + a full topk).
+//
+// loss_masks (criterion.py:292-356 + point_features.py:63-116) only needs SUMS over the selected points, so:
+//   1. matched query maps are gathered once from the pixel-major logits into query-major rows (L2-resident);
+//   2. the 0.75P most-uncertain of 3P uniform points (smallest |logit|) are found EXACTLY by a 3-level radix
+//      select on the float bits of |x| (11+10+10 bits, LDS-privatised histograms) -- no sort, no [R,3P] tensor;
+//   3. one more pass re-samples the points, keeps those under the threshold, samples the target there and
+//      accumulates BCE / dice sums; the 0.25P extra uniform points are added in the same pass.
+// Points come from an injected coordinate buffer (parity mode: the recorded torch.rand draws) or from a
+// counter-based RNG keyed by (seed, row, index), so re-sampling in every pass is free of HBM traffic.
+// All partial sums land in fixed slots and are reduced in a fixed order (double): deterministic losses.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void rand2(uint64_t seed, uint64_t stream, uint64_t i, float &u, float &v)
+{
+    const uint64_t r = mix64(seed ^ mix64(stream * 0xD1342543DE82EF95ull + i));
+    u = (float)(uint32_t)(r & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    v = (float)(uint32_t)((r >> 32) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+
+// bilinear sample (grid_sample, zeros padding, align_corners=False) of a [H,W] plane at (u,v) in [0,1]
+template <typename T>
+__device__ __forceinline__ float sample_plane(const T *__restrict__ pl, int H, int W, float u, float v)
+{
+    const float gx = 2.f * u - 1.f, gy = 2.f * v - 1.f;
+    const float x = ((gx + 1.f) * W - 1.f) * 0.5f, y = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
+    const float fx = x - x0, fy = y - y0;
+    const bool xa = x0 >= 0 && x0 < W, xb = x1 >= 0 && x1 < W, ya = y0 >= 0 && y0 < H, yb = y1 >= 0 && y1 < H;
+    float acc = 0.f;
+    if (ya && xa) acc += (float)pl[(long)y0 * W + x0] * ((1.f - fx) * (1.f - fy));
+    if (ya && xb) acc += (float)pl[(long)y0 * W + x1] * (fx * (1.f - fy));
+    if (yb && xa) acc += (float)pl[(long)y1 * W + x0] * ((1.f - fx) * fy);
+    if (yb && xb) acc += (float)pl[(long)y1 * W + x1] * (fx * fy);
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------ KD targets
+// kd_video_maskformer_model.py:436-456: scores = softmax(logits)[:, :-1]; top-K; keep score >= thr.
+// Kept queries are emitted in ascending query order (the reference's topk(sorted=False) order is
+// implementation-defined; every downstream quantity is invariant to a permutation of the targets).
+__global__ void kd_select_kernel(const float *__restrict__ cls, int Q, int K, float thr, int Nmax, int *__restrict__ count,
+                                 int *__restrict__ kept)
+{
+    __shared__ float sc[128];
+    __shared__ int keep[128];
+    const int b = blockIdx.x, q = threadIdx.x;
+    if (q < Q) {
+        const float l0 = cls[((long)b * Q + q) * 2], l1 = cls[((long)b * Q + q) * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        sc[q] = e0 / (e0 + e1);
+    }
+    __syncthreads();
+    if (q < Q) {
+        int rank = 0;
+        for (int j = 0; j < Q; ++j) rank += (sc[j] > sc[q]) || (sc[j] == sc[q] && j < q);
+        keep[q] = (rank < K) && (sc[q] >= thr);
+    }
+    __syncthreads();
+    if (q == 0) {
+        int c = 0;
+        for (int j = 0; j < Q; ++j)
+            if (keep[j] && c < Nmax) kept[b * Nmax + c++] = j;
+        count[b] = c;
+    }
+}
+
+// masks = bilinear(teacher mask logits -> (H,W), align_corners=False) > 0   (:462-468), written as u8 planes
+__global__ __launch_bounds__(256) void kd_upsample_kernel(const float *__restrict__ ml, int ldq, int T, int hm, int wm, int H,
+                                                          int W, int Nmax, const int *__restrict__ count,
+                                                          const int *__restrict__ kept, uint8_t *__restrict__ tgt,
+                                                          int *__restrict__ nonempty)
+{
+    __shared__ int kq[128];
+    __shared__ unsigned int anyset[128];
+    const int bt = blockIdx.z, b = bt / T, t = bt % T;
+    const int Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    const int cnt = count[b];
+    if (threadIdx.x < 128) {
+        kq[threadIdx.x] = threadIdx.x < cnt ? kept[b * Nmax + threadIdx.x] : 0;
+        anyset[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    if (X < W) {
+        float sy = ((float)hm / H) * (Y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = ((float)wm / W) * (X + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hm - 1 ? 1 : 0), x1 = x0 + (x0 < wm - 1 ? 1 : 0);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *fr = ml + ((long)b * T + t) * hm * wm * ldq;
+        const float *r00 = fr + ((long)y0 * wm + x0) * ldq, *r01 = fr + ((long)y0 * wm + x1) * ldq;
+        const float *r10 = fr + ((long)y1 * wm + x0) * ldq, *r11 = fr + ((long)y1 * wm + x1) * ldq;
+        for (int k = 0; k < cnt; ++k) {
+            const int q = kq[k];
+            const float val = hy * (hx * r00[q] + lx * r01[q]) + ly * (hx * r10[q] + lx * r11[q]);
+            const uint8_t m = val > 0.f ? 1 : 0;
+            tgt[((((long)b * Nmax + k) * T + t) * H + Y) * W + X] = m;
+            if (m) anyset[k] = 1u;  // benign race: all writers store 1
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < cnt && anyset[threadIdx.x]) nonempty[((long)b * Nmax + threadIdx.x) * T + t] = 1;
+}
+
+// nonempty[b][n][t] = any(tgt[b][n][t])   (the DropLoss predicate, criterion.py:310-313)
+__global__ __launch_bounds__(256) void nonempty_kernel(const uint8_t *__restrict__ tgt, const int *__restrict__ count, int Nmax,
+                                                       int T, long HW, int *__restrict__ nonempty)
+{
+    const int plane = blockIdx.x;  // (b*Nmax + n)*T + t
+    const int n = (plane / T) % Nmax, b = plane / (T * Nmax);
+    if (n >= count[b]) { if (threadIdx.x == 0) nonempty[plane] = 0; return; }
+    const uint8_t *p = tgt + (long)plane * HW;
+    int any = 0;
+    const long n16 = HW / 16;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+    for (long i = threadIdx.x; i < n16; i += 256) {
+        const uint4 v = p4[i];
+        any |= (v.x | v.y | v.z | v.w) != 0u;
+    }
+    for (long i = n16 * 16 + threadIdx.x; i < HW; i += 256) any |= p[i] != 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) nonempty[plane] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ rows
+struct LossParams {
+    const float *ml;          // [NL][B][T*hm*wm][ldq] pixel-major mask logits
+    const uint8_t *tgt;       // [B][Nmax][T][H][W]
+    const int *tgt_count;     // [B]
+    const int *nonempty;      // [B][Nmax][T]
+    const int *idx_q, *idx_t; // [NL*B][maxm]
+    const int *n_match;       // [NL*B]
+    const float *coords_over; // [NL][Rmax_l][n_over][2] or null (Rmax_l = B*maxm*T; slot = rank among kept rows of the layer)
+    const float *coords_rand; // [NL][Rmax_l][n_rand][2] or null
+    uint64_t seed;
+    int NL, B, Q, ldq, T, hm, wm, H, W, Nmax, maxm, n_over, n_unc, n_rand, drop;
+    float world_size;
+    // workspace
+    int *active, *rank;       // [rows]
+    float *mq;                // [rows][hm*wm]
+    unsigned int *hist;       // [rows][2048]
+    unsigned int *prefix;     // [rows]  key prefix found so far
+    int *krem;                // [rows]  how many still to take inside the prefix
+    unsigned int *tie;        // [rows]
+    float *part;              // [rows][chunks][4]
+    int chunks;
+};
+
+// one block per layer: active flag + rank (= position among the kept rows of this layer, reference row order
+// (clip, slot, frame): criterion.py:298-322)
+__global__ void row_prep_kernel(LossParams p)
+{
+    const int layer = blockIdx.x;
+    const int rows_l = p.B * p.maxm * p.T;
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < rows_l; r0 += blockDim.x) {
+        const int r = r0 + threadIdx.x;
+        int act = 0;
+        if (r < rows_l) {
+            const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
+            const int prob = layer * p.B + b;
+            if (s < p.n_match[prob]) {
+                const int n = p.idx_t[(long)prob * p.maxm + s];
+                act = p.drop ? p.nonempty[((long)b * p.Nmax + n) * p.T + t] : 1;
+            }
+        }
+        // block-wide exclusive scan of `act` in thread order (blockDim.x == 256: 4 waves)
+        __shared__ int wsum[4];
+        const unsigned long long m = __ballot(act);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int inw = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (r < rows_l) {
+            const long rowid = (long)layer * rows_l + r;
+            p.active[rowid] = act;
+            p.rank[rowid] = off + inw;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+// gather matched query maps: mq[row][pix] = ml[layer][b][t][pix][q]; 64 pixels per block through LDS
+__global__ __launch_bounds__(256) void gather_rows_kernel(LossParams p)
+{
+    __shared__ float tile[64][129];
+    const int prob = blockIdx.z, t = blockIdx.y, pix0 = blockIdx.x * 64;
+    const int layer = prob / p.B, b = prob % p.B;
+    const int hw = p.hm * p.wm;
+    const int nm = p.n_match[prob];
+    const long row_base = (((long)layer * p.B + b) * p.maxm) * p.T;
+    bool any = false;
+    for (int s = 0; s < nm; ++s) any = any || p.active[row_base + (long)s * p.T + t];
+    if (!any) return;
+    const float *src = p.ml + (((long)prob * p.T + t) * hw + pix0) * p.ldq;
+    const int npix = min(64, hw - pix0);
+    for (int e = threadIdx.x; e < npix * p.ldq; e += 256) {
+        const int px = e / p.ldq, q = e % p.ldq;
+        if (q < 128) tile[px][q] = src[e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int s = wv; s < nm; s += 4) {
+        const long rowid = row_base + (long)s * p.T + t;
+        if (!p.active[rowid]) continue;
+        const int q = p.idx_q[(long)prob * p.maxm + s];
+        if (lane < npix) p.mq[rowid * hw + pix0 + lane] = tile[lane][q];
+    }
+}
+
+__device__ __forceinline__ void row_coord(const LossParams &p, long rowid, int layer, bool over, long i, float &u, float &v)
+{
+    const float *c = over ? p.coords_over : p.coords_rand;
+    if (c) {
+        const long rows_l = (long)p.B * p.maxm * p.T;
+        const long n = over ? p.n_over : p.n_rand;
+        const long slot = (long)layer * rows_l + p.rank[rowid];
+        u = c[(slot * n + i) * 2];
+        v = c[(slot * n + i) * 2 + 1];
+    } else {
+        rand2(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1), (uint64_t)i, u, v);
+    }
+}
+
+// level 0: bits 30..20, level 1: bits 19..10, level 2: bits 9..0 of |x|
+template <int LEVEL>
+__global__ __launch_bounds__(256) void hist_kernel(LossParams p)
+{
+    __shared__ unsigned int h[2048];
+    const long rowid = blockIdx.y;
+    if (!p.active[rowid]) return;
+    const int rows_l = p.B * p.maxm * p.T;
+    const int layer = (int)(rowid / rows_l);
+    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0u;
+    __syncthreads();
+    const float *map = p.mq + rowid * p.hm * p.wm;
+    const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
+    const long per = (p.n_over + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_over, i0 + per);
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        float u, v;
+        row_coord(p, rowid, layer, true, i, u, v);
+        const float x = sample_plane(map, p.hm, p.wm, u, v);
+        const unsigned int key = __float_as_uint(fabsf(x));
+        if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
+        else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
+        else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+    }
+    __syncthreads();
+    const int nb = LEVEL == 0 ? 2048 : 1024;
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
+}
+
+// find the bin holding the krem-th smallest key; one block per row
+template <int LEVEL>
+__global__ __launch_bounds__(256) void select_kernel(LossParams p)
+{
+    __shared__ unsigned int csum[256];
+    const long rowid = blockIdx.x;
+    if (!p.active[rowid]) return;
+    const int nb = LEVEL == 0 ? 2048 : 1024, per = nb / 256;
+    const int k = LEVEL == 0 ? p.n_unc : p.krem[rowid];
+    unsigned int *h = p.hist + rowid * 2048;
+    unsigned int loc[8], s = 0;
+    for (int j = 0; j < per; ++j) { loc[j] = h[threadIdx.x * per + j]; s += loc[j]; }
+    csum[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int i = 0; i < 256; ++i) { const unsigned int c = csum[i]; csum[i] = run; run += c; }
+    }
+    __syncthreads();
+    unsigned int before = csum[threadIdx.x];
+    for (int j = 0; j < per; ++j) {
+        if (before < (unsigned)k && before + loc[j] >= (unsigned)k) {
+            const unsigned int bin = threadIdx.x * per + j;
+            const unsigned int pre = LEVEL == 0 ? 0u : p.prefix[rowid];
+            p.prefix[rowid] = LEVEL == 0 ? (bin << 20) : LEVEL == 1 ? (pre | (bin << 10)) : (pre | bin);
+            p.krem[rowid] = k - (int)before;
+        }
+        before += loc[j];
+    }
+    __syncthreads();
+    for (int j = 0; j < per; ++j) h[threadIdx.x * per + j] = 0u;  // ready for the next level
+}
+
+__device__ __forceinline__ void acc_point(float x, float t, float &bce, float &sgt, float &sg, float &ts)
+{
+    const float e = expf(-fabsf(x));
+    const float inv = 1.f / (1.f + e);
+    const float s = x >= 0.f ? inv : e * inv;
+    bce += fmaxf(x, 0.f) - x * t + log1pf(e);   // F.binary_cross_entropy_with_logits (criterion.py:74)
+    sgt += s * t; sg += s; ts += t;             // dice terms (criterion.py:37-41)
+}
+
+__global__ __launch_bounds__(256) void accumulate_kernel(LossParams p)
+{
+    const long rowid = blockIdx.y;
+    if (!p.active[rowid]) return;
+    const int rows_l = p.B * p.maxm * p.T;
+    const int layer = (int)(rowid / rows_l);
+    const int r = (int)(rowid % rows_l);
+    const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
+    const int prob = layer * p.B + b;
+    const int n = p.idx_t[(long)prob * p.maxm + s];
+    const float *map = p.mq + rowid * p.hm * p.wm;
+    const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * p.H * p.W;
+    const unsigned int thr = p.prefix[rowid];
+    const unsigned int take = (unsigned int)p.krem[rowid];
+    float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
+    {
+        const long per = (p.n_over + gridDim.x - 1) / gridDim.x;
+        const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_over, i0 + per);
+        for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+            float u, v;
+            row_coord(p, rowid, layer, true, i, u, v);
+            const float x = sample_plane(map, p.hm, p.wm, u, v);
+            const unsigned int key = __float_as_uint(fabsf(x));
+            bool sel = key < thr;
+            if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+            if (sel) acc_point(x, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+        }
+    }
+    {
+        const long per = (p.n_rand + gridDim.x - 1) / gridDim.x;
+        const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_rand, i0 + per);
+        for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+            float u, v;
+            row_coord(p, rowid, layer, false, i, u, v);
+            acc_point(sample_plane(map, p.hm, p.wm, u, v), sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+        }
+    }
+    __shared__ float red[4][4];
+    bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x;
+        p.part[(rowid * p.chunks + blockIdx.x) * 4 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+}
+
+// losses[layer][0] = loss_mask, [1] = loss_dice  (criterion.py:349-352; normaliser = num_masks :404-409)
+__global__ void loss_finalize_kernel(LossParams p, float *__restrict__ losses)
+{
+    const int layer = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int rows_l = p.B * p.maxm * p.T;
+    double num = 0.;
+    for (int b = 0; b < p.B; ++b) num += (double)min(p.tgt_count[b], p.Nmax);
+    num = fmax(num / (double)p.world_size, 1.0);
+    const double P = (double)(p.n_unc + p.n_rand);
+    double lm = 0., ld = 0.;
+    for (int r = 0; r < rows_l; ++r) {
+        const long rowid = (long)layer * rows_l + r;
+        if (!p.active[rowid]) continue;
+        double bce = 0., sgt = 0., sg = 0., ts = 0.;
+        for (int c = 0; c < p.chunks; ++c) {
+            const float *q = p.part + (rowid * p.chunks + c) * 4;
+            bce += q[0]; sgt += q[1]; sg += q[2]; ts += q[3];
+        }
+        lm += bce / P;
+        ld += 1.0 - (2.0 * sgt + 1.0) / (sg + ts + 1.0);
+    }
+    losses[layer * 2 + 0] = (float)(lm / num);
+    losses[layer * 2 + 1] = (float)(ld / num);
+}
+
+// loss_labels (criterion.py:227-251): weighted CE, matched queries -> class 0, others -> class 1 (= no object)
+__global__ void class_loss_kernel(const float *__restrict__ cls, const int *__restrict__ idx_q, const int *__restrict__ n_match,
+                                  int B, int Q, int maxm, float eos, float *__restrict__ out)
+{
+    __shared__ unsigned char matched[128];
+    __shared__ double snum, sden;
+    if (threadIdx.x == 0) { snum = 0.; sden = 0.; }
+    double num = 0., den = 0.;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        if (threadIdx.x < 128) matched[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x < n_match[b]) matched[idx_q[(long)b * maxm + threadIdx.x]] = 1;
+        __syncthreads();
+        const int q = threadIdx.x;
+        if (q < Q) {
+            const float l0 = cls[((long)b * Q + q) * 2], l1 = cls[((long)b * Q + q) * 2 + 1];
+            const float mx = fmaxf(l0, l1);
+            const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+            const bool m = matched[q];
+            const float w = m ? 1.f : eos;
+            num += (double)(w * (lse - (m ? l0 : l1)));
+            den += (double)w;
+        }
+    }
+    num = wave_sum_d(num); den = wave_sum_d(den);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&snum, num); atomicAdd(&sden, den); }
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(snum / sden);
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, float score_thr, int topk, int B, int Q,
+                      int ldq, int T, int hm, int wm, int H, int W, int Nmax, uint8_t *tgt, int *count, int *kept_q,
+                      int *nonempty, hipStream_t stream)
+{
+    if (Q > 128 || Nmax > 128) return S2D_ERR_ARG;
+    if (B == 0) return S2D_OK;
+    if (hipMemsetAsync(nonempty, 0, sizeof(int) * (size_t)B * Nmax * T, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(kd_select_kernel, dim3(B), dim3(128), 0, stream, t_class_logits, Q, topk < Q ? topk : Q, score_thr,
+                       Nmax, count, kept_q);
+    hipLaunchKernelGGL(kd_upsample_kernel, dim3(cdiv(W, 256), H, B * T), dim3(256), 0, stream, t_mask_logits, ldq, T, hm, wm,
+                       H, W, Nmax, count, kept_q, tgt, nonempty);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, int T, int H, int W, int *nonempty,
+                        hipStream_t stream)
+{
+    if (B * Nmax * T == 0) return S2D_OK;
+    if (((long)H * W) % 16) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(nonempty_kernel, dim3(B * Nmax * T), dim3(256), 0, stream, tgt, count, Nmax, T, (long)H * W, nonempty);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+static const int LOSS_CHUNKS = 8;
+
+long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm)
+{
+    const long maxm = Q < Nmax ? Q : Nmax;
+    const long rows = (long)NL * B * maxm * T;
+    return rows * (2 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 256;
+}
+
+int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                       const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
+                       const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                       int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
+                       float world_size, void *workspace, float *losses, hipStream_t stream)
+{
+    if (Q > 128 || Nmax > 128 || ldq > 128 || ldq < Q) return S2D_ERR_ARG;
+    LossParams p;
+    p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count; p.nonempty = nonempty;
+    p.idx_q = idx_q; p.idx_t = idx_t; p.n_match = n_match; p.coords_over = coords_over; p.coords_rand = coords_rand;
+    p.seed = seed; p.NL = NL; p.B = B; p.Q = Q; p.ldq = ldq; p.T = T; p.hm = hm; p.wm = wm; p.H = H; p.W = W; p.Nmax = Nmax;
+    p.maxm = Q < Nmax ? Q : Nmax;
+    p.n_over = (int)(num_points * oversample_ratio);                 // point_features.py:89
+    p.n_unc = (int)(importance_ratio * num_points);                  // :99
+    p.n_rand = num_points - p.n_unc;                                 // :100
+    p.drop = drop_empty; p.world_size = world_size; p.chunks = LOSS_CHUNKS;
+    const long rows = (long)NL * B * p.maxm * T;
+    if (rows == 0) return S2D_OK;
+    char *w = (char *)workspace;
+    p.active = (int *)w; w += rows * 4;
+    p.rank = (int *)w; w += rows * 4;
+    p.prefix = (unsigned int *)w; w += rows * 4;
+    p.krem = (int *)w; w += rows * 4;
+    p.tie = (unsigned int *)w; w += rows * 4;
+    w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    p.hist = (unsigned int *)w; w += rows * 2048 * 4;
+    p.part = (float *)w; w += rows * LOSS_CHUNKS * 16;
+    p.mq = (float *)w;
+    if (hipMemsetAsync(p.hist, 0, (size_t)rows * 2048 * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipMemsetAsync(p.tie, 0, (size_t)rows * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
+    const dim3 g(LOSS_CHUNKS, (unsigned)rows);
+    hipLaunchKernelGGL(hist_kernel<0>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(select_kernel<0>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hist_kernel<1>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hist_kernel<2>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(accumulate_kernel, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_class_loss_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,
+                       float eos_coef, float *loss_ce, hipStream_t stream)
+{
+    if (Q > 128) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(class_loss_kernel, dim3(1), dim3(128), 0, stream, class_logits, idx_q, n_match, B, Q, maxm, eos_coef,
+                       loss_ce);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

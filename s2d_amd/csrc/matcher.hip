@@ -1,0 +1,384 @@
+// VideoHungarianMatcher on the device: fused point-sampling + cost contractions, and the rectangular LSAP.
+//
+// Replaces model_training/mask2former_video/modeling/matcher.py:225-294 for ALL prediction layers and clips
+// of one criterion pass in two launches + one LSAP launch, with no device->host copy (the reference does
+// C.cpu() + scipy per layer per clip, matcher.py:287-289).
+//
+// Cost algebra (exact rewrites of matcher.py:15-30, 38-62; x = sampled logit, t = sampled target in [0,1]):
+//   cost_mask[q,n] = ( sum_p softplus(-x)*t + softplus(x)*(1-t) ) / TP = ( sum_p softplus(x_qp) - sum_p x_qp*t_np ) / TP
+//   cost_dice[q,n] = 1 - (2*sum_p sigmoid(x_qp)*t_np + 1) / (sum_p sigmoid(x_qp) + sum_p t_np + 1)
+// so one pass over the T*P sample points accumulates two [Q x N] contractions (x.t^T and sigmoid(x).t^T, on the
+// fp32 MFMA) and three vectors.  Partials per sample chunk are written to a workspace and reduced in a fixed
+// order in double, so the cost matrix -- and therefore the assignment -- is run-to-run deterministic.
+//
+// Mask logits are read PIXEL-MAJOR ([T*hm*wm][ldq], the row-major output of the mask-logit GEMM): the four
+// bilinear corners of a sample point are four contiguous Q-float rows, one coalesced 128-B segment per wave.
+#include "common.h"
+
+namespace {
+
+constexpr int SB = 32;   // samples per batch (the MFMA K extent)
+constexpr int QP = 128;  // padded queries
+constexpr int NP = 128;  // padded targets
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// two uniforms in [0,1) with 24 random bits each (torch.rand's float construction), keyed by (seed, stream, i)
+__device__ __forceinline__ void rand2(uint64_t seed, uint64_t stream, uint64_t i, float &u, float &v)
+{
+    const uint64_t r = mix64(seed ^ mix64(stream * 0xD1342543DE82EF95ull + i));
+    u = (float)(uint32_t)(r & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    v = (float)(uint32_t)((r >> 32) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+
+struct Bil {
+    int i00, i01, i10, i11;   // pixel indices (y*W+x), -1 = outside (zero padding)
+    float w00, w01, w10, w11;
+};
+// F.grid_sample(bilinear, zeros, align_corners=False) at normalised (u,v) in [0,1]  (point_features.py:19-42)
+__device__ __forceinline__ Bil bil_setup(float u, float v, int H, int W)
+{
+    const float gx = 2.f * u - 1.f, gy = 2.f * v - 1.f;
+    const float x = ((gx + 1.f) * W - 1.f) * 0.5f, y = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
+    const float fx = x - x0, fy = y - y0;
+    Bil b;
+    const bool xa = x0 >= 0 && x0 < W, xb = x1 >= 0 && x1 < W, ya = y0 >= 0 && y0 < H, yb = y1 >= 0 && y1 < H;
+    b.i00 = (ya && xa) ? y0 * W + x0 : -1;
+    b.i01 = (ya && xb) ? y0 * W + x1 : -1;
+    b.i10 = (yb && xa) ? y1 * W + x0 : -1;
+    b.i11 = (yb && xb) ? y1 * W + x1 : -1;
+    b.w00 = (1.f - fx) * (1.f - fy); b.w01 = fx * (1.f - fy); b.w10 = (1.f - fx) * fy; b.w11 = fx * fy;
+    return b;
+}
+
+struct CostParams {
+    const float *ml;         // [NL][B][T*hm*wm][ldq]
+    const uint8_t *tgt;      // [B][Nmax][T][H][W]
+    const int *tgt_count;    // [B]
+    const float *coords;     // [NL][B][P][2] or null
+    uint64_t seed;
+    int NL, B, Q, ldq, T, hm, wm, H, W, Nmax, P, chunks;
+    float *wsA, *wsD;        // [prob][chunk][QP][NP]
+    float *wsV;              // [prob][chunk][3][128] : softplus sums[q], sigmoid sums[q], target sums[n]
+};
+
+__global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
+{
+    __shared__ float Ts[SB][NP];
+    __shared__ float coordS[SB][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int prob = blockIdx.y, chunk = blockIdx.x;
+    const int b = prob % p.B;
+    const int N = min(p.tgt_count[b], p.Nmax);
+    const int NT = (N + 31) / 32;
+    const long TP = (long)p.T * p.P;
+    const long per = ((TP + p.chunks - 1) / p.chunks + SB - 1) / SB * SB;
+    const long i0 = (long)chunk * per, i1 = min(TP, i0 + per);
+    const int q = wv * 32 + l32;
+    const bool qok = q < p.Q;
+    const float *ml = p.ml + (long)prob * p.T * p.hm * p.wm * p.ldq;
+    const uint8_t *tg = p.tgt + (long)b * p.Nmax * p.T * p.H * p.W;
+    const float *cr = p.coords ? p.coords + (long)prob * p.P * 2 : nullptr;
+
+    f32x16 aA[4], aD[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aA[k][r] = 0.f; aD[k][r] = 0.f; }
+    float spsum = 0.f, sgsum = 0.f, tsum = 0.f;
+    const int tn = tid & 127, tgrp = tid >> 7;
+
+    for (long base = i0; base < i1; base += SB) {
+        __syncthreads();  // previous batch's Ts/coordS fully consumed
+        if (tid < SB) {
+            const long i = base + tid;
+            float u = 0.f, v = 0.f;
+            if (i < i1) {
+                const long pi = i % p.P;
+                if (cr) { u = cr[2 * pi]; v = cr[2 * pi + 1]; }
+                else rand2(p.seed, (uint64_t)prob, (uint64_t)pi, u, v);
+            }
+            coordS[tid][0] = u; coordS[tid][1] = v;
+        }
+        __syncthreads();
+        // target tile: thread (tn, tgrp) samples target tn at 16 of the 32 points
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int k = tgrp * 16 + s;
+            const long i = base + k;
+            float val = 0.f;
+            if (tn < N && i < i1) {
+                const int t = (int)(i / p.P);
+                const Bil bl = bil_setup(coordS[k][0], coordS[k][1], p.H, p.W);
+                const uint8_t *pl = tg + ((long)tn * p.T + t) * p.H * p.W;
+                if (bl.i00 >= 0) val += (float)pl[bl.i00] * bl.w00;
+                if (bl.i01 >= 0) val += (float)pl[bl.i01] * bl.w01;
+                if (bl.i10 >= 0) val += (float)pl[bl.i10] * bl.w10;
+                if (bl.i11 >= 0) val += (float)pl[bl.i11] * bl.w11;
+            }
+            Ts[k][tn] = val;
+            tsum += val;
+        }
+        // query side: lane (q, h) samples its query at points 2s+h
+        float xs[16], sg[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 2 * s + h;
+            const long i = base + k;
+            float x = 0.f, sgm = 0.f;
+            if (qok && i < i1) {
+                const int t = (int)(i / p.P);
+                const Bil bl = bil_setup(coordS[k][0], coordS[k][1], p.hm, p.wm);
+                const float *fr = ml + (long)t * p.hm * p.wm * p.ldq + q;
+                if (bl.i00 >= 0) x += fr[(long)bl.i00 * p.ldq] * bl.w00;
+                if (bl.i01 >= 0) x += fr[(long)bl.i01 * p.ldq] * bl.w01;
+                if (bl.i10 >= 0) x += fr[(long)bl.i10 * p.ldq] * bl.w10;
+                if (bl.i11 >= 0) x += fr[(long)bl.i11 * p.ldq] * bl.w11;
+                const float e = expf(-fabsf(x));
+                const float inv = 1.f / (1.f + e);
+                sgm = x >= 0.f ? inv : e * inv;            // sigmoid(x)
+                spsum += fmaxf(x, 0.f) + log1pf(e);        // softplus(x) = BCE-with-logits vs 0  (matcher.py:54-56)
+                sgsum += sgm;
+            }
+            xs[s] = x; sg[s] = sgm;
+        }
+        __syncthreads();  // Ts complete
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NT) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float tb = Ts[2 * s + h][nt * 32 + l32];
+                    aA[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[s], tb, aA[nt], 0, 0, 0);
+                    aD[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[s], tb, aD[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partials: acc[nt][r] = M[q = wv*32 + (r&3)+8(r>>2)+4h][n = nt*32 + l32]
+    const long pc = (long)prob * p.chunks + chunk;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (nt < NT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                p.wsA[(pc * QP + qq) * NP + nt * 32 + l32] = aA[nt][r];
+                p.wsD[(pc * QP + qq) * NP + nt * 32 + l32] = aD[nt][r];
+            }
+        }
+    }
+    spsum += __shfl_xor(spsum, 32, 64);
+    sgsum += __shfl_xor(sgsum, 32, 64);
+    if (h == 0) {
+        p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
+        p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
+    }
+    __syncthreads();
+    Ts[0][tid & 127] = 0.f;  // reuse as scratch for the two target-sum halves
+    __syncthreads();
+    atomicAdd(&Ts[0][tn], tsum);  // exactly two adds per slot: order-independent in fp32
+    __syncthreads();
+    if (tid < 128) p.wsV[(pc * 3 + 2) * 128 + tid] = Ts[0][tid];
+}
+
+// C[prob][q][n] = w_mask*cost_mask + w_class*(-softmax(logits)[q][0]) + w_dice*cost_dice   (matcher.py:280-287)
+__global__ void matcher_finalize_kernel(CostParams p, const float *__restrict__ cls, float wc, float wm_, float wd,
+                                        float *__restrict__ C)
+{
+    const int prob = blockIdx.y;
+    const int b = prob % p.B;
+    const int N = min(p.tgt_count[b], p.Nmax);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.Q * p.Nmax) return;
+    const int q = i / p.Nmax, n = i % p.Nmax;
+    float out = 0.f;
+    if (n < N) {
+        double A = 0., D = 0., SP = 0., SG = 0., ST = 0.;
+        for (int c = 0; c < p.chunks; ++c) {
+            const long pc = (long)prob * p.chunks + c;
+            A += (double)p.wsA[(pc * QP + q) * NP + n];
+            D += (double)p.wsD[(pc * QP + q) * NP + n];
+            SP += (double)p.wsV[(pc * 3 + 0) * 128 + q];
+            SG += (double)p.wsV[(pc * 3 + 1) * 128 + q];
+            ST += (double)p.wsV[(pc * 3 + 2) * 128 + n];
+        }
+        const double TP = (double)p.T * p.P;
+        const double cost_mask = (SP - A) / TP;
+        const double cost_dice = 1.0 - (2.0 * D + 1.0) / (SG + ST + 1.0);
+        const float l0 = cls[((long)prob * p.Q + q) * 2], l1 = cls[((long)prob * p.Q + q) * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const double prob0 = (double)(e0 / (e0 + e1));
+        out = (float)((double)wm_ * cost_mask + (double)wc * (-prob0) + (double)wd * cost_dice);
+    }
+    C[((long)prob * p.Q + q) * p.Nmax + n] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rectangular linear sum assignment, one wavefront per problem.  Same algorithm and scan order as
+// scipy.optimize.linear_sum_assignment (Crouse 2016 shortest augmenting paths; called at matcher.py:289), so
+// ties resolve identically: rows <= cols (the [Q,N] cost is used transposed when N < Q), the column scan runs
+// over the `remaining` list (filled in reverse, swap-removed), and among equal minima the LAST unassigned
+// column in scan order wins, else the FIRST column.  All arithmetic in double on the fp32 costs, like scipy.
+constexpr int LMAX = 128;
+constexpr int COSTMAX = 12800;  // floats of LDS for the cost matrix: min(Q,N) * max(Q,N) <= 100 * 128
+__global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ Call, const int *__restrict__ tgt_count, int B,
+                                                  int Q, int Nmax, int maxm, int *__restrict__ idx_q,
+                                                  int *__restrict__ idx_t, int *__restrict__ n_match)
+{
+    __shared__ float cost[COSTMAX];   // [nr][nc]
+    __shared__ double u[LMAX], v[LMAX], spc[LMAX];
+    __shared__ int path[LMAX], row4col[LMAX], col4row[LMAX], remaining[LMAX];
+    __shared__ unsigned char SR[LMAX], SC[LMAX];
+    __shared__ int s_i, s_sink, s_nrem;
+    __shared__ double s_min;
+    const int prob = blockIdx.x, lane = threadIdx.x;
+    const int b = prob % B;
+    const int N = min(tgt_count[b], Nmax);
+    const float *C = Call + (long)prob * Q * Nmax;
+    const bool transpose = N < Q;
+    const int nr = transpose ? N : Q, nc = transpose ? Q : N;
+    if (nr == 0) { if (lane == 0) n_match[prob] = 0; return; }
+    for (int e = lane; e < nr * nc; e += 64) {
+        const int r = e / nc, c = e % nc;
+        cost[e] = transpose ? C[(long)c * Nmax + r] : C[(long)r * Nmax + c];
+    }
+    for (int e = lane; e < LMAX; e += 64) { u[e] = 0.; v[e] = 0.; col4row[e] = -1; row4col[e] = -1; path[e] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int e = lane; e < nc; e += 64) { remaining[e] = nc - e - 1; spc[e] = INFINITY; SC[e] = 0; }
+        for (int e = lane; e < nr; e += 64) SR[e] = 0;
+        if (lane == 0) { s_i = cur; s_sink = -1; s_nrem = nc; s_min = 0.; }
+        __syncthreads();
+        while (true) {
+            const int i = s_i, nrem = s_nrem;
+            const double minVal = s_min;
+            if (lane == 0) SR[i] = 1;
+            // candidate of this lane over its strided share of `remaining`, in ascending `it`
+            double best = INFINITY; int best_it_first = 0x7fffffff, best_it_unas = -1;
+            const double ui = u[i];
+            for (int it = lane; it < nrem; it += 64) {
+                const int j = remaining[it];
+                const double r = minVal + (double)cost[i * nc + j] - ui - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                const double sj = spc[j];
+                if (sj < best) { best = sj; best_it_first = it; best_it_unas = (row4col[j] == -1) ? it : -1; }
+                else if (sj == best) { if (row4col[j] == -1) best_it_unas = it; }
+            }
+            // wave reduction: global min; among lanes at the min: max unassigned `it`, else min `it`
+            double gmin = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, o, 64));
+            int fi = (best == gmin) ? best_it_first : 0x7fffffff;
+            int ua = (best == gmin) ? best_it_unas : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { fi = min(fi, __shfl_xor(fi, o, 64)); ua = max(ua, __shfl_xor(ua, o, 64)); }
+            __syncthreads();
+            if (gmin == INFINITY) { if (lane == 0) n_match[prob] = -1; return; }  // infeasible (cannot happen: finite costs)
+            const int index = ua >= 0 ? ua : fi;
+            if (lane == 0) {
+                const int j = remaining[index];
+                s_min = gmin;
+                if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
+                SC[j] = 1;
+                remaining[index] = remaining[nrem - 1];
+                s_nrem = nrem - 1;
+            }
+            __syncthreads();
+            if (s_sink != -1) break;
+        }
+        const double minVal = s_min;
+        // dual updates
+        for (int r = lane; r < nr; r += 64) {
+            if (r == cur) u[r] += minVal;
+            else if (SR[r]) u[r] += minVal - spc[col4row[r]];
+        }
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        __syncthreads();
+        if (lane == 0) {
+            int j = s_sink;
+            while (true) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int t = col4row[r];
+                col4row[r] = j;
+                j = t;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    // emit in scipy's order (first index ascending)
+    int *oq = idx_q + (long)prob * maxm, *ot = idx_t + (long)prob * maxm;
+    if (!transpose) {
+        for (int r = lane; r < nr; r += 64) { oq[r] = r; ot[r] = col4row[r]; }
+    } else {
+        int basec = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const bool has = j < nc && row4col[j] != -1;
+            const unsigned long long m = __ballot(has);
+            if (has) {
+                const int pos = basec + __popcll(m & ((1ull << lane) - 1ull));
+                oq[pos] = j; ot[pos] = row4col[j];
+            }
+            basec += __popcll(m);
+        }
+    }
+    if (lane == 0) n_match[prob] = nr;
+}
+
+}  // namespace
+
+extern "C" {
+
+
+
+long s2d_matcher_workspace_floats(int NL, int B)
+{
+    const long nprob = (long)NL * B, ch = 64;
+    return nprob * ch * (2L * QP * NP + 3 * 128);
+}
+
+int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
+                         const float *coords, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                         int W, int Nmax, int P, float w_class, float w_mask, float w_dice, float *workspace, float *C,
+                         hipStream_t stream)
+{
+    if (Q > QP || Nmax > NP || Q <= 0 || Nmax <= 0 || ldq < Q) return S2D_ERR_ARG;
+    const int nprob = NL * B;
+    if (nprob == 0) return S2D_OK;
+    CostParams p;
+    p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count; p.coords = coords; p.seed = seed;
+    p.NL = NL; p.B = B; p.Q = Q; p.ldq = ldq; p.T = T; p.hm = hm; p.wm = wm; p.H = H; p.W = W; p.Nmax = Nmax; p.P = P;
+    p.chunks = 64;
+    p.wsA = workspace;
+    p.wsD = p.wsA + (long)nprob * p.chunks * QP * NP;
+    p.wsV = p.wsD + (long)nprob * p.chunks * QP * NP;
+    hipLaunchKernelGGL(matcher_cost_kernel, dim3(p.chunks, nprob), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
+                       class_logits, w_class, w_mask, w_dice, C);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_lsap_f32(const float *C, const int *tgt_count, int nprob, int B, int Q, int Nmax, int *idx_q, int *idx_t,
+                 int *n_match, hipStream_t stream)
+{
+    if (Q > LMAX || Nmax > LMAX || (long)Q * Nmax > COSTMAX) return S2D_ERR_ARG;
+    if (nprob == 0) return S2D_OK;
+    const int maxm = Q < Nmax ? Q : Nmax;
+    hipLaunchKernelGGL(lsap_kernel, dim3(nprob), dim3(64), 0, stream, C, tgt_count, B, Q, Nmax, maxm, idx_q, idx_t, n_match);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

@@ -176,3 +176,82 @@ def masked_attn(q, k, v, bits=None, unmasked=None, H=8):
     out = torch.empty_like(q)
     lib().call("s2d_masked_attn_f32", q, k, v, bits, unmasked, B, Q, K, C, H, ws, out, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- matcher / criterion
+def matcher_cost(mask_logits, class_logits, tgt, tgt_count, dims, P, weights, coords=None, seed=0):
+    """mask_logits [NL,B,T*hm*wm,ldq] pixel-major, class_logits [NL,B,Q,2], tgt u8 [B,Nmax,T,H,W], tgt_count i32 [B].
+    dims = (Q, T, hm, wm).  -> C [NL*B, Q, Nmax]"""
+    _chk(mask_logits); _chk(class_logits); _chk(tgt, torch.uint8); _chk(tgt_count, torch.int32); _chk(coords)
+    NL, B = mask_logits.shape[:2]
+    Q, T, hm, wm = dims
+    Nmax, H, W = tgt.shape[1], tgt.shape[3], tgt.shape[4]
+    n = lib().call("s2d_matcher_workspace_floats", NL, B)
+    ws = torch.empty((n,), device=tgt.device, dtype=torch.float32)
+    C = torch.empty((NL * B, Q, Nmax), device=tgt.device, dtype=torch.float32)
+    wc, wm_, wd = weights
+    lib().call("s2d_matcher_cost_f32", mask_logits, class_logits, tgt, tgt_count, coords, int(seed), NL, B, Q,
+               mask_logits.shape[-1], T, hm, wm, H, W, Nmax, P, float(wc), float(wm_), float(wd), ws, C, _stream())
+    return C
+
+
+def lsap(C, tgt_count, B):
+    """C [nprob,Q,Nmax] -> idx_q, idx_t int32 [nprob, min(Q,Nmax)], n_match int32 [nprob]"""
+    _chk(C); _chk(tgt_count, torch.int32)
+    nprob, Q, Nmax = C.shape
+    maxm = min(Q, Nmax)
+    iq = torch.zeros((nprob, maxm), device=C.device, dtype=torch.int32)
+    it = torch.zeros((nprob, maxm), device=C.device, dtype=torch.int32)
+    nm = torch.zeros((nprob,), device=C.device, dtype=torch.int32)
+    lib().call("s2d_lsap_f32", C, tgt_count, nprob, B, Q, Nmax, iq, it, nm, _stream())
+    return iq, it, nm
+
+
+def kd_targets(t_class_logits, t_mask_logits, dims, H, W, Nmax, thr=0.75, topk=100):
+    """teacher class logits [B,Q,2], mask logits pixel-major [B,T*hm*wm,ldq]; dims=(Q,T,hm,wm)."""
+    _chk(t_class_logits); _chk(t_mask_logits)
+    B = t_class_logits.shape[0]
+    Q, T, hm, wm = dims
+    dev = t_class_logits.device
+    tgt = torch.empty((B, Nmax, T, H, W), device=dev, dtype=torch.uint8)
+    count = torch.zeros((B,), device=dev, dtype=torch.int32)
+    kept = torch.zeros((B, Nmax), device=dev, dtype=torch.int32)
+    nonempty = torch.empty((B, Nmax, T), device=dev, dtype=torch.int32)
+    lib().call("s2d_kd_targets_u8", t_class_logits, t_mask_logits, float(thr), int(topk), B, Q, t_mask_logits.shape[-1], T, hm,
+               wm, H, W, Nmax, tgt, count, kept, nonempty, _stream())
+    return tgt, count, kept, nonempty
+
+
+def target_nonempty(tgt, count):
+    _chk(tgt, torch.uint8); _chk(count, torch.int32)
+    B, Nmax, T, H, W = tgt.shape
+    out = torch.empty((B, Nmax, T), device=tgt.device, dtype=torch.int32)
+    lib().call("s2d_target_nonempty", tgt, count, B, Nmax, T, H, W, out, _stream())
+    return out
+
+
+def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dims, P, oversample=3.0, importance=0.75,
+               coords_over=None, coords_rand=None, seed=0, drop_empty=True, world_size=1.0):
+    """-> losses [NL,2] (loss_mask, loss_dice)"""
+    _chk(mask_logits); _chk(tgt, torch.uint8); _chk(coords_over); _chk(coords_rand)
+    for t in (tgt_count, nonempty, idx_q, idx_t, n_match):
+        _chk(t, torch.int32)
+    NL, B = mask_logits.shape[:2]
+    Q, T, hm, wm = dims
+    Nmax, H, W = tgt.shape[1], tgt.shape[3], tgt.shape[4]
+    nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm)
+    ws = torch.empty((nbytes,), device=tgt.device, dtype=torch.uint8)
+    losses = torch.zeros((NL, 2), device=tgt.device, dtype=torch.float32)
+    lib().call("s2d_point_loss_f32", mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand,
+               int(seed), NL, B, Q, mask_logits.shape[-1], T, hm, wm, H, W, Nmax, int(P), float(oversample), float(importance),
+               int(drop_empty), float(world_size), ws, losses, _stream())
+    return losses
+
+
+def class_loss(class_logits, idx_q, n_match, eos_coef=0.1):
+    """class_logits [B,Q,2], idx_q [B,maxm], n_match [B] -> 0-dim loss_ce"""
+    _chk(class_logits); _chk(idx_q, torch.int32); _chk(n_match, torch.int32)
+    B, Q, _ = class_logits.shape
+    out = torch.zeros((1,), device=class_logits.device, dtype=torch.float32)
+    lib().call("s2d_class_loss_f32", class_logits, idx_q, n_match, B, Q, idx_q.shape[-1], float(eos_coef), out, _stream())
+    return out[0]
