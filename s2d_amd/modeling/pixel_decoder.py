@@ -1,0 +1,224 @@
+"""MSDeformAttn pixel decoder, host side.  Mirrors
+model_training/mask2former/modeling/pixel_decoder/msdeformattn.py (MSDeformAttnPixelDecoder :164-358,
+MSDeformAttnTransformerEncoderOnly :22-89, encoder layer :92-131) and ops/modules/ms_deform_attn.py:34-125, with the
+reference's parameter names and shapes so its checkpoints load unchanged.
+
+Activations stay NHWC == the reference's [N, S, C] token layout, so flatten/transpose/split are views.  Per encoder
+layer: one GEMM produces sampling offsets + attention logits together (weights concatenated at pack time), one GEMM
+the value projection, the fused MSDA kernel does softmax + location arithmetic + bilinear gather, the output
+projection GEMM adds the residual in its epilogue, LayerNorm follows; FFN likewise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class MSDeformAttn(nn.Module):
+    """Parameter container + drop-in forward of ops/modules/ms_deform_attn.py:34-125."""
+
+    def __init__(self, d_model=256, n_levels=3, n_heads=8, n_points=4):
+        super().__init__()
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+        self._packed = None
+
+    def _reset_parameters(self):  # ms_deform_attn.py:66-80
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.)
+        nn.init.constant_(self.attention_weights.bias.data, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.)
+
+    def packed(self):
+        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight, self.attention_weights.bias)
+        key = tuple(p._version for p in ps) + (ps[0].device,)
+        if self._packed is None or self._packed[0] != key:
+            w = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
+            b = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
+            self._packed = (key, w, b)
+        return self._packed[1:]
+
+    def forward_fused(self, query, src, shapes, res):
+        """self-attention over the flattened pyramid (query positions == value positions).  Returns
+        output_proj(msda(...)) + res."""
+        N, S, C = src.shape
+        w_oa, b_oa = self.packed()
+        oa = ops.gemm_nt(query.view(-1, C), w_oa, bias=b_oa).view(N, S, -1)
+        value = ops.gemm_nt(src.view(-1, C), self.value_proj.weight, bias=self.value_proj.bias).view(N, S, C)
+        samp = ops.msda_fused_forward(value, shapes, oa, self.n_heads, self.n_points)
+        out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C))
+        return out.view(N, S, C)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """The reference's general signature (ms_deform_attn.py:82-125), built from the drop-in MSDA op."""
+        N, Lq, C = query.shape
+        S = input_flatten.shape[1]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = ops.gemm_nt(input_flatten.reshape(-1, C).contiguous(), self.value_proj.weight, bias=self.value_proj.bias)
+        if input_padding_mask is not None:
+            value = value.view(N, S, C).masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, S, M, C // M)
+        q2 = query.reshape(-1, C).contiguous()
+        off = ops.gemm_nt(q2, self.sampling_offsets.weight, bias=self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
+        aw = ops.gemm_nt(q2, self.attention_weights.weight, bias=self.attention_weights.bias).view(N, Lq, M, L * P)
+        aw = torch.softmax(aw, -1).view(N, Lq, M, L, P)
+        shp = torch.as_tensor(input_spatial_shapes, device=query.device)
+        norm = torch.stack([shp[..., 1], shp[..., 0]], -1).to(query.dtype)
+        loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        out = ops.msda_forward(value.contiguous(), input_spatial_shapes, input_level_start_index, loc.contiguous(), aw.contiguous())
+        return ops.gemm_nt(out.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias).view(N, Lq, C)
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, n_levels=3, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout_p = dropout
+
+    def forward(self, src, pos, shapes):
+        """msdeformattn.py:122-131 (post-norm).  src [N,S,C], pos [S,C]."""
+        if self.dropout_p:
+            raise NotImplementedError("dropout > 0 (training noise) is not on the measured fwd+loss parity path; "
+                                      "set MODEL.MASK_FORMER.DROPOUT 0.0 (SURVEY.md Appendix C)")
+        N, S, C = src.shape
+        q = ops.add_bcast(src, pos)
+        x = self.self_attn.forward_fused(q, src, shapes, res=src)
+        src = ops.layernorm(x, self.norm1.weight, self.norm1.bias)
+        h = ops.gemm_nt(src.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
+        x = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=src.view(-1, C)).view(N, S, C)
+        return ops.layernorm(x, self.norm2.weight, self.norm2.bias)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.0,
+                 num_feature_levels=3, enc_n_points=4):
+        super().__init__()
+        self.encoder = _Encoder([MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, num_feature_levels,
+                                                                      nhead, enc_n_points) for _ in range(num_encoder_layers)])
+        self.level_embed = nn.Parameter(torch.empty(num_feature_levels, d_model))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.level_embed)
+
+
+class _ConvGN(nn.Module):
+    """detectron2 Conv2d(bias=False, norm=GroupNorm(32)) parameter container: `weight` + `norm.{weight,bias}`."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=1)  # fvcore c2_xavier_fill
+        self.norm = nn.GroupNorm(32, cout)
+        self._packed = None
+
+    def packed(self):
+        key = (self.weight._version, self.weight.device)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, self.weight.detach().permute(0, 2, 3, 1).contiguous())
+        return self._packed[1]
+
+
+class MSDeformAttnPixelDecoder(nn.Module):
+    """forward_features(features: dict res2..res5 NHWC) ->
+    (mask_features [BT,h2,w2,C] NHWC, multi_scale [(tokens [BT,h*w,C], (h,w)) x3: res5,res4,res3 scale])"""
+
+    def __init__(self, conv_dim=256, mask_dim=256, transformer_dropout=0.0, transformer_nheads=8,
+                 transformer_dim_feedforward=1024, transformer_enc_layers=6, in_channels=(2048, 1024, 512),
+                 res2_channels=256):
+        super().__init__()
+        self.conv_dim = conv_dim
+        self.input_proj = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in in_channels])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(conv_dim, transformer_nheads, transformer_enc_layers,
+                                                              transformer_dim_feedforward, transformer_dropout, 3)
+        self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=1)
+        nn.init.kaiming_uniform_(self.mask_features.weight, a=1)
+        nn.init.constant_(self.mask_features.bias, 0)
+        self.adapter_1 = _ConvGN(res2_channels, conv_dim, 1)
+        self.layer_1 = _ConvGN(conv_dim, conv_dim, 3)
+        self._pos_cache = {}
+
+    @classmethod
+    def from_config(cls, cfg, input_shape=None):  # msdeformattn.py:294-312
+        return cls(conv_dim=cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM, mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
+                   transformer_dropout=cfg.MODEL.MASK_FORMER.DROPOUT, transformer_nheads=cfg.MODEL.MASK_FORMER.NHEADS,
+                   transformer_dim_feedforward=1024,
+                   transformer_enc_layers=cfg.MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS)
+
+    def _pos(self, shapes, device):
+        le = self.transformer.level_embed
+        key = (tuple(shapes), le._version, device)
+        if self._pos_cache.get("key") != key:
+            pos = [ops.pe_sine(0, h, w, self.conv_dim // 2, add_c=le[i].detach().contiguous(), device=device)
+                   for i, (h, w) in enumerate(shapes)]
+            self._pos_cache = {"key": key, "pos": torch.cat(pos, 0).contiguous()}
+        return self._pos_cache["pos"]
+
+    @torch.no_grad()
+    def forward_features(self, features):
+        C = self.conv_dim
+        srcs, shapes = [], []
+        for idx, f in enumerate(("res5", "res4", "res3")):   # msdeformattn.py:319-322
+            x = features[f]
+            N, h, w, cin = x.shape
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            y = ops.gemm_nt(x.view(-1, cin), conv.weight.view(C, cin), bias=conv.bias).view(N, h, w, C)
+            y = ops.groupnorm_nhwc(y, 32, gn.weight, gn.bias, eps=gn.eps)
+            srcs.append(y.view(N, h * w, C))
+            shapes.append((h, w))
+        src = torch.cat(srcs, 1).contiguous()
+        pos = self._pos(shapes, src.device)
+        shp = torch.tensor(shapes, dtype=torch.int64)
+        for layer in self.transformer.encoder.layers:
+            src = layer(src, pos, shp)
+        N = src.shape[0]
+        outs, o = [], 0
+        for (h, w) in shapes:
+            outs.append(src[:, o:o + h * w].contiguous())
+            o += h * w
+        # extra FPN level on res2 (msdeformattn.py:343-351)
+        x = features["res2"]
+        _, h2, w2, c2 = x.shape
+        cur = ops.gemm_nt(x.view(-1, c2), self.adapter_1.weight.view(C, c2)).view(N, h2, w2, C)
+        h3, w3 = shapes[-1]
+        y = ops.groupnorm_nhwc(cur, 32, self.adapter_1.norm.weight, self.adapter_1.norm.bias, up=outs[-1].view(N, h3, w3, C),
+                               eps=self.adapter_1.norm.eps)
+        y = ops.conv2d_nhwc(y, self.layer_1.packed(), 1, 1)
+        y = ops.groupnorm_nhwc(y, 32, self.layer_1.norm.weight, self.layer_1.norm.bias, relu=True, eps=self.layer_1.norm.eps)
+        mf = ops.gemm_nt(y.view(-1, C), self.mask_features.weight.view(-1, C), bias=self.mask_features.bias).view(N, h2, w2, -1)
+        return mf, [(outs[i], shapes[i]) for i in range(3)]

@@ -1,0 +1,205 @@
+"""Video masked-attention transformer decoder, host side.  Mirrors
+model_training/mask2former_video/modeling/transformer_decoder/video_mask2former_transformer_decoder.py
+(VideoMultiScaleMaskedTransformerDecoder :208-480, layers :18-179, MLP :193-205) with the reference's parameter
+names/shapes (nn.MultiheadAttention in_proj_weight/in_proj_bias/out_proj.*).
+
+MI355X-first differences (results identical within fp32 rounding):
+* keys stay in the pixel decoder's NHWC token layout [B, T*h*w, C] (t-major, == :394-397) -- no permutes;
+* mask logits are produced PIXEL-major [NL, B, T*hm*wm, Q] straight from the GEMM (rows = pixels) and kept for all
+  10 prediction heads in one buffer: the attention-mask builder, the matcher and the loss read that layout coalesced;
+  the reference's [B,Q,T,h,w] view is produced on demand (`MaskOutputs.pred_masks`);
+* the [B*8,Q,K] bool mask is never built: a bit matrix + the streamed attention kernel replace it.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class MaskOutputs:
+    """All prediction heads of one forward.  class_logits [NL,B,Q,K+1]; mask_logits pixel-major [NL,B,T*hm*wm,ldq]."""
+
+    def __init__(self, class_logits, mask_logits, Q, T, hm, wm):
+        self.class_logits, self.mask_logits = class_logits, mask_logits
+        self.Q, self.T, self.hm, self.wm = Q, T, hm, wm
+
+    @property
+    def dims(self):
+        return (self.Q, self.T, self.hm, self.wm)
+
+    def pred_masks(self, layer=-1):
+        """reference layout [B,Q,T,hm,wm] (video_...decoder.py:455)"""
+        ml = self.mask_logits[layer][..., :self.Q]
+        B = ml.shape[0]
+        return ml.view(B, self.T, self.hm, self.wm, self.Q).permute(0, 4, 1, 2, 3)
+
+    def as_reference_dict(self):
+        """{'pred_logits','pred_masks','aux_outputs'} as the reference returns (:439-446)"""
+        NL = self.class_logits.shape[0]
+        return {"pred_logits": self.class_logits[-1], "pred_masks": self.pred_masks(-1),
+                "aux_outputs": [{"pred_logits": self.class_logits[i], "pred_masks": self.pred_masks(i)} for i in range(NL - 1)]}
+
+
+class _MHAParams(nn.Module):
+    """nn.MultiheadAttention parameter layout."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.self_attn = _MHAParams(d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+
+    def forward(self, tgt, query_pos):  # forward_post :41-51;  tgt [B,Q,C], query_pos [Q,C]
+        B, Q, C = tgt.shape
+        W, bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        qk_in = ops.add_bcast(tgt, query_pos)
+        qk = ops.gemm_nt(qk_in.view(-1, C), W[:2 * C], bias=bi[:2 * C]).view(B, Q, 2 * C)
+        v = ops.gemm_nt(tgt.view(-1, C), W[2 * C:], bias=bi[2 * C:]).view(B, Q, C)
+        a = ops.masked_attn(qk[..., :C].contiguous(), qk[..., C:].contiguous(), v, H=self.nhead)
+        x = ops.gemm_nt(a.view(-1, C), self.self_attn.out_proj.weight, bias=self.self_attn.out_proj.bias, res=tgt.view(-1, C))
+        return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.multihead_attn = _MHAParams(d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+
+    def forward(self, tgt, k_in, v_in, bits, unmasked, query_pos):  # forward_post :99-111
+        B, Q, C = tgt.shape
+        K = k_in.shape[1]
+        W, bi = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
+        q = ops.gemm_nt(ops.add_bcast(tgt, query_pos).view(-1, C), W[:C], bias=bi[:C]).view(B, Q, C)
+        k = ops.gemm_nt(k_in.view(-1, C), W[C:2 * C], bias=bi[C:2 * C]).view(B, K, C)
+        v = ops.gemm_nt(v_in.view(-1, C), W[2 * C:], bias=bi[2 * C:]).view(B, K, C)
+        a = ops.masked_attn(q, k, v, bits, unmasked, H=self.nhead)
+        x = ops.gemm_nt(a.view(-1, C), self.multihead_attn.out_proj.weight, bias=self.multihead_attn.out_proj.bias,
+                        res=tgt.view(-1, C))
+        return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):  # forward_post :164-168
+        B, Q, C = tgt.shape
+        h = ops.gemm_nt(tgt.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
+        x = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=tgt.view(-1, C))
+        return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, l in enumerate(self.layers):
+            x = ops.gemm_nt(x, l.weight, bias=l.bias, relu=i < len(self.layers) - 1)
+        return x
+
+
+class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
+    def __init__(self, in_channels=256, mask_classification=True, *, num_classes=1, hidden_dim=256, num_queries=100,
+                 nheads=8, dim_feedforward=2048, dec_layers=9, pre_norm=False, mask_dim=256, enforce_input_project=False,
+                 num_frames=2, detach_cls=False):
+        super().__init__()
+        assert mask_classification and not pre_norm and in_channels == hidden_dim and not enforce_input_project, \
+            "only the shipped S2D configuration (post-norm, identity input_proj) is on the hot path"
+        self.num_frames, self.num_heads, self.num_layers, self.num_queries = num_frames, nheads, dec_layers, num_queries
+        self.hidden_dim = hidden_dim
+        self.transformer_self_attention_layers = nn.ModuleList(SelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(CrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_ffn_layers = nn.ModuleList(FFNLayer(hidden_dim, dim_feedforward) for _ in range(dec_layers))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.level_embed = nn.Embedding(3, hidden_dim)
+        self.input_proj = nn.ModuleList(nn.Sequential() for _ in range(3))
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
+        self._pos_cache = {}
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification=True):  # :344-372
+        mf = cfg.MODEL.MASK_FORMER
+        return cls(in_channels, mask_classification, num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES, hidden_dim=mf.HIDDEN_DIM,
+                   num_queries=mf.NUM_OBJECT_QUERIES, nheads=mf.NHEADS, dim_feedforward=mf.DIM_FEEDFORWARD,
+                   dec_layers=mf.DEC_LAYERS - 1, pre_norm=mf.PRE_NORM, mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
+                   enforce_input_project=mf.ENFORCE_INPUT_PROJ, num_frames=cfg.INPUT.SAMPLING_FRAME_NUM)
+
+    def _pos(self, T, sizes, device):
+        """per level: pos3d + level_embed (for keys) and level_embed alone (for values), token-major [T*h*w, C]"""
+        le = self.level_embed.weight
+        key = (T, tuple(sizes), le._version, device)
+        if self._pos_cache.get("key") != key:
+            self._pos_cache = {"key": key, "posl": [
+                ops.pe_sine(T, h, w, self.hidden_dim // 2, add_c=le[i].detach().contiguous(), device=device)
+                for i, (h, w) in enumerate(sizes)]}
+        return self._pos_cache["posl"]
+
+    def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm):
+        """forward_prediction_heads :448-467 for all clips; writes slot `layer_slot` of the output buffers and
+        returns the attention-mask bits for the next layer."""
+        Q, C = self.num_queries, self.hidden_dim
+        d = ops.layernorm(output, self.decoder_norm.weight, self.decoder_norm.bias).view(-1, C)
+        ops.gemm_nt(d, self.class_embed.weight, bias=self.class_embed.bias, out=out_cls[layer_slot].view(B * Q, -1))
+        e = self.mask_embed(d).view(B, Q, -1)
+        # einsum "bqc,btchw->bqthw" as a pixel-major GEMM: [T*hm*wm, C] x [Q, C]^T per clip
+        ops.gemm_nt(mf, e, out=out_ml[layer_slot])
+        if target_hw is None:
+            return None, None
+        return ops.attn_mask_bits(out_ml[layer_slot], B, Q, T, hm, wm, target_hw[0], target_hw[1])
+
+    @torch.no_grad()
+    def forward(self, multi_scale, mask_features, training=True):
+        """multi_scale: 3 x (tokens [BT,h*w,C], (h,w)) from the pixel decoder (res5, res4, res3 scale);
+        mask_features [BT,hm,wm,C] NHWC.  Returns MaskOutputs."""
+        BT, hm, wm, C = mask_features.shape
+        B = BT // self.num_frames if training else 1   # :376
+        T = BT // B
+        Q, NL = self.num_queries, self.num_layers + 1
+        dev = mask_features.device
+        sizes = [s for _, s in multi_scale]
+        posl = self._pos(T, sizes, dev)
+        k_in, v_in = [], []
+        for i, (tok, (h, w)) in enumerate(multi_scale):
+            x = tok.view(B, T * h * w, C)
+            k_in.append(ops.add_bcast(x, posl[i]))                                         # src + level_embed + pos
+            v_in.append(ops.add_bcast(x, self.level_embed.weight[i].detach().contiguous()))  # src + level_embed
+        mf = mask_features.view(B, T * hm * wm, C)
+        ldq = (Q + 3) // 4 * 4
+        out_cls = torch.empty((NL, B, Q, self.class_embed.out_features), device=dev, dtype=torch.float32)
+        out_ml = torch.empty((NL, B, T * hm * wm, ldq), device=dev, dtype=torch.float32)
+        if ldq != Q:
+            out_ml.zero_()
+        qe = self.query_embed.weight.detach()
+        output = self.query_feat.weight.detach().unsqueeze(0).repeat(B, 1, 1).contiguous()
+        bits, unm = self._heads(0, output, mf, out_cls, out_ml, sizes[0], B, T, hm, wm)
+        for i in range(self.num_layers):
+            lvl = i % 3
+            output = self.transformer_cross_attention_layers[i](output, k_in[lvl], v_in[lvl], bits, unm, qe)
+            output = self.transformer_self_attention_layers[i](output, qe)
+            output = self.transformer_ffn_layers[i](output)
+            nxt = sizes[(i + 1) % 3] if i + 1 < self.num_layers else None
+            bits, unm = self._heads(i + 1, output, mf, out_cls, out_ml, nxt, B, T, hm, wm)
+        return MaskOutputs(out_cls, out_ml, Q, T, hm, wm)

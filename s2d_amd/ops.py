@@ -28,10 +28,12 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
     assert B.shape[-1] == K
     if out is None:
         out = torch.empty((bs, M, N) if batched else (M, N), device=A.device, dtype=torch.float32)
+    ldc = out.shape[-1]          # out may be wider than N (padded row stride)
+    assert ldc >= N and out.shape[-2] == M
     sA = M * K if batched else 0
     sB = N * K if B.dim() == 3 else 0
-    sC = M * N
-    lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, N, bs, sA, sB, sC, scale, bias, res, N,
+    sC = M * ldc
+    lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, N,
                M * N if res is not None and res.dim() == 3 else 0, int(relu), _stream())
     return out
 
