@@ -538,6 +538,8 @@ def loss_masks(masks, targets, indices, num_masks, coords_over=None, coords_rand
     if callable(coords_over):                                          # lazily drawn, like the reference
         coords_over = coords_over()
         coords_rand = coords_rand()
+    if coords_over is not None and coords_over.shape[0] > R:         # padded injection buffers: first R slots
+        coords_over, coords_rand = coords_over[:R], coords_rand[:R]
     if coords_over is None:
         coords_over = rng.random((R, 3 * P, 2), dtype=np.float32)
         coords_rand = rng.random((R, P - int(0.75 * P), 2), dtype=np.float32)

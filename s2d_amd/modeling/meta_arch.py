@@ -1,0 +1,241 @@
+"""Meta-architectures, host side: KDVideoMaskFormer (model_training/mask2former_video/kd_video_maskformer_model.py:29-610)
+and VideoMaskFormer (video_maskformer_model.py:24-378), plus MaskFormerHead (mask2former/modeling/meta_arch/
+mask_former_head.py:18-132).  Same registry names, same `forward(batched_inputs) -> dict[str, 0-dim tensor]` contract
+in training (keys of kd_video_maskformer_model.py:314-326), same attributes the trainer touches (.student, .teacher =
+nn.Sequential(backbone, head) so checkpoint keys are student.0.* / student.1.*; .criterion.weight_dict; .accum_iter;
+.device).  The forward is the measured hot path: normalise/pad -> student -> teacher -> GT criterion -> KD targets ->
+KD criterion -> rename/weight, all enqueued on the current stream without a host synchronisation.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .backbone import ResNet50
+from .criterion import TargetSet, VideoHungarianMatcher, VideoSetCriterion
+from .pixel_decoder import MSDeformAttnPixelDecoder
+from .video_decoder import VideoMultiScaleMaskedTransformerDecoder
+
+try:  # plug into detectron2's registries when it is installed (the drop-in boundary)
+    from detectron2.modeling import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY  # type: ignore
+except Exception:  # detectron2 absent (as in this image): local registries with the same interface
+    class _Registry(dict):
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self.register(o)
+            self[obj.__name__] = obj
+            return obj
+
+        def get(self, name):
+            return self[name]
+
+    META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY = _Registry(), _Registry()
+
+SEM_SEG_HEADS_REGISTRY.register(MSDeformAttnPixelDecoder)
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MaskFormerHead(nn.Module):
+    def __init__(self, pixel_decoder, transformer_predictor, num_classes=1):
+        super().__init__()
+        self.pixel_decoder, self.predictor, self.num_classes = pixel_decoder, transformer_predictor, num_classes
+
+    @classmethod
+    def from_config(cls, cfg, input_shape=None):  # mask_former_head.py:87-113
+        return cls(MSDeformAttnPixelDecoder.from_config(cfg), VideoMultiScaleMaskedTransformerDecoder.from_config(
+            cfg, cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM, True), cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES)
+
+    def forward(self, features, training=True):  # layers(), mask_former_head.py:118-132 ("multi_scale_pixel_decoder")
+        mask_features, multi_scale = self.pixel_decoder.forward_features(features)
+        return self.predictor(multi_scale, mask_features, training)
+
+
+class _Net(nn.Sequential):
+    """nn.Sequential(backbone, head): keeps the reference's state_dict keys (kd_video_maskformer_model.py:94-95)."""
+
+    def forward(self, x, training=True):
+        return self[1](self[0](x), training)
+
+
+def _frames_to_device(batched_inputs, device):
+    frames = [f for video in batched_inputs for f in video["image"]]
+    x = torch.stack([f if isinstance(f, torch.Tensor) else torch.as_tensor(f) for f in frames])
+    return x.to(device=device, dtype=torch.uint8, non_blocking=True).contiguous()
+
+
+def _gt_target_list(batched_inputs, num_frames, Hp, Wp, device):
+    """prepare_targets (kd_video_maskformer_model.py:358-386): paste per-frame BitMasks into [N,T,Hp,Wp], drop
+    instances whose ids are -1 in every frame.  Accepts detectron2 Instances (gt_masks.tensor / gt_ids) or plain
+    dicts {'gt_masks': [N,h,w], 'gt_ids': [N]}."""
+    out = []
+    for video in batched_inputs:
+        inst = video["instances"]
+        get = (lambda o, k: o[k]) if isinstance(inst[0], dict) else (lambda o, k: getattr(o, k))
+        n = len(get(inst[0], "gt_ids"))
+        masks = torch.zeros((n, num_frames, Hp, Wp), dtype=torch.uint8, device=device)
+        ids = []
+        for t, fr in enumerate(inst):
+            m = get(fr, "gt_masks")
+            m = m.tensor if hasattr(m, "tensor") else torch.as_tensor(m)
+            h, w = m.shape[-2:]
+            masks[:, t, :h, :w] = (m != 0).to(device=device, dtype=torch.uint8)
+            ids.append(torch.as_tensor(get(fr, "gt_ids"))[:, None])
+        valid = (torch.cat(ids, 1) != -1).any(-1)
+        out.append(masks[valid.to(device)])
+    return out
+
+
+@META_ARCH_REGISTRY.register()
+class KDVideoMaskFormer(nn.Module):
+    def __init__(self, *, student_backbone, student_sem_seg_head, teacher_backbone, teacher_sem_seg_head, criterion,
+                 num_queries, num_frames, size_divisibility=32, pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD,
+                 num_predictions_distillation=100, score_threshold_distillation=0.75, accum_iter=1, eval_student=False):
+        super().__init__()
+        self.student = _Net(student_backbone, student_sem_seg_head)
+        self.teacher = _Net(teacher_backbone, teacher_sem_seg_head)
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+        self.criterion = criterion
+        self.num_queries, self.num_frames, self.size_divisibility = num_queries, num_frames, size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        self.num_predictions_distillation = num_predictions_distillation
+        self.score_threshold_distillation = score_threshold_distillation
+        self.accum_iter, self.eval_student = accum_iter, eval_student
+
+    @classmethod
+    def from_config(cls, cfg):  # kd_video_maskformer_model.py:130-231
+        mf = cfg.MODEL.MASK_FORMER
+        sb, tb = ResNet50(), ResNet50()
+        sh, th = MaskFormerHead.from_config(cfg), MaskFormerHead.from_config(cfg)
+        cw, dw, mw = mf.CLASS_WEIGHT, mf.DICE_WEIGHT, mf.MASK_WEIGHT
+        kc, km, kd = mf.KD_CLASS_WEIGHT, mf.KD_MASK_WEIGHT, mf.KD_DICE_WEIGHT
+        if any([cw > 0, mw > 0, dw > 0]):
+            matcher = VideoHungarianMatcher(cw, mw, dw, mf.TRAIN_NUM_POINTS)
+        else:
+            matcher = VideoHungarianMatcher(kc, km, kd, mf.TRAIN_NUM_POINTS)
+        wd = {"loss_ce": cw, "loss_mask": mw, "loss_dice": dw, "kd_loss_ce": kc, "kd_loss_mask": km, "kd_loss_dice": kd}
+        if mf.DEEP_SUPERVISION:
+            aux = {}
+            for i in range(mf.DEC_LAYERS - 1):
+                aux.update({k + f"_{i}": v for k, v in wd.items()})
+            wd.update(aux)
+        crit = VideoSetCriterion(sh.num_classes, matcher=matcher, weight_dict=wd, eos_coef=mf.NO_OBJECT_WEIGHT,
+                                 losses=["labels", "masks"], num_points=mf.TRAIN_NUM_POINTS,
+                                 oversample_ratio=mf.OVERSAMPLE_RATIO, importance_sample_ratio=mf.IMPORTANCE_SAMPLE_RATIO,
+                                 loss_strategy=mf.LOSS_STRATEGY, distillation_loss_strategy=mf.DISTILLATION_LOSS_STRATEGY)
+        return cls(student_backbone=sb, student_sem_seg_head=sh, teacher_backbone=tb, teacher_sem_seg_head=th,
+                   criterion=crit, num_queries=mf.NUM_OBJECT_QUERIES, num_frames=cfg.INPUT.SAMPLING_FRAME_NUM,
+                   size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
+                   num_predictions_distillation=mf.NUM_PREDICTIONS_DISTILLATION,
+                   score_threshold_distillation=mf.SCORE_THRESHOLD_DISTILLATION, accum_iter=cfg.SOLVER.ACCUM_ITER)
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess(self, batched_inputs):
+        frames = _frames_to_device(batched_inputs, self.device)
+        return ops.normalize_pad(frames, self.size_divisibility, self.pixel_mean.flatten().cpu().numpy(),
+                                 self.pixel_std.flatten().cpu().numpy())
+
+    @torch.no_grad()
+    def forward_losses(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None):
+        """the device-side hot path from normalised frames to the weighted loss dict (no host sync)"""
+        student = self.student(images, True)
+        teacher = self.teacher(images, True)
+        losses = self.criterion(student, gt_targets, False, coords_gt)
+        Hp, Wp = images.shape[1:3]
+        kd_nmax = kd_nmax or min(self.num_predictions_distillation, self.num_queries)
+        tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                            self.score_threshold_distillation, self.num_predictions_distillation)
+        kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd)
+        for k, v in kd.items():
+            losses[k.replace("loss_", "kd_loss_")] = v
+        wd = self.criterion.weight_dict                                   # :319-325
+        out = {k: v * wd[k] for k, v in losses.items() if k in wd}
+        self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
+        return out
+
+    def forward(self, batched_inputs):
+        images = self.preprocess(batched_inputs)
+        if not self.training:
+            return self.inference(images, batched_inputs)
+        Hp, Wp = images.shape[1:3]
+        gt = TargetSet.from_list(_gt_target_list(batched_inputs, self.num_frames, Hp, Wp, self.device), device=self.device)
+        return self.forward_losses(images, gt)
+
+    @torch.no_grad()
+    def inference(self, images, batched_inputs):
+        """eval branch (kd_video_maskformer_model.py:327-356): whole video as one clip; returns the teacher's (or
+        student's) class logits and mask logits upsampled to the padded frame size.  The python mask-NMS /
+        top-k post-processing (inference_video, :530-610) is a 'next' row of SURVEY.md 8f, not on the metric path."""
+        net = self.student if self.eval_student else self.teacher
+        out = net(images, False)
+        masks = out.pred_masks(-1)[0]
+        masks = torch.nn.functional.interpolate(masks, size=images.shape[1:3], mode="bilinear", align_corners=False)
+        return {"pred_logits": out.class_logits[-1][0], "pred_masks": masks}
+
+
+@META_ARCH_REGISTRY.register()
+class VideoMaskFormer(nn.Module):
+    """Non-KD variant (video_maskformer_model.py:189-265): one network, one criterion pass."""
+
+    def __init__(self, *, backbone, sem_seg_head, criterion, num_queries, num_frames, size_divisibility=32,
+                 pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD):
+        super().__init__()
+        self.backbone, self.sem_seg_head, self.criterion = backbone, sem_seg_head, criterion
+        self.num_queries, self.num_frames, self.size_divisibility = num_queries, num_frames, size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    @torch.no_grad()
+    def forward_losses(self, images, gt_targets, coords=None):
+        out = self.sem_seg_head(self.backbone(images), True)
+        losses = self.criterion(out, gt_targets, False, coords)
+        wd = self.criterion.weight_dict
+        self.last = dict(outputs=out)
+        return {k: v * wd[k] for k, v in losses.items() if k in wd}
+
+    def forward(self, batched_inputs):
+        frames = _frames_to_device(batched_inputs, self.device)
+        images = ops.normalize_pad(frames, self.size_divisibility, self.pixel_mean.flatten().cpu().numpy(),
+                                   self.pixel_std.flatten().cpu().numpy())
+        Hp, Wp = images.shape[1:3]
+        gt = TargetSet.from_list(_gt_target_list(batched_inputs, self.num_frames, Hp, Wp, self.device), device=self.device)
+        return self.forward_losses(images, gt)
+
+
+def build_kd_model(num_queries=100, num_frames=8, num_points=160000, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0),
+                   dec_layers=10, seed=0, teacher_bias=None):
+    """Construct KDVideoMaskFormer with the shipped hyper-parameters
+    (configs/imagenet_video/ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml) without a yacs config."""
+    torch.manual_seed(seed)
+
+    def head():
+        return MaskFormerHead(MSDeformAttnPixelDecoder(),
+                              VideoMultiScaleMaskedTransformerDecoder(num_queries=num_queries, num_frames=num_frames,
+                                                                      dec_layers=dec_layers - 1))
+    sb, sh = ResNet50(), head()
+    tb, th = ResNet50(), head()
+    cw, mw, dw = weights
+    matcher = VideoHungarianMatcher(cw, mw, dw, num_points) if any(w > 0 for w in weights) else VideoHungarianMatcher(*kd_weights, num_points)
+    wd = {"loss_ce": cw, "loss_mask": mw, "loss_dice": dw, "kd_loss_ce": kd_weights[0], "kd_loss_mask": kd_weights[1],
+          "kd_loss_dice": kd_weights[2]}
+    aux = {}
+    for i in range(dec_layers - 1):
+        aux.update({k + f"_{i}": v for k, v in wd.items()})
+    wd.update(aux)
+    crit = VideoSetCriterion(1, matcher=matcher, weight_dict=wd, eos_coef=0.1, losses=["labels", "masks"], num_points=num_points,
+                             oversample_ratio=3.0, importance_sample_ratio=0.75, loss_strategy="masks-only",
+                             distillation_loss_strategy="masks-only")
+    model = KDVideoMaskFormer(student_backbone=sb, student_sem_seg_head=sh, teacher_backbone=tb, teacher_sem_seg_head=th,
+                              criterion=crit, num_queries=num_queries, num_frames=num_frames)
+    model.teacher.load_state_dict(model.student.state_dict())   # teacher starts as a copy of the student (EMA init)
+    if teacher_bias is not None:
+        with torch.no_grad():
+            model.teacher[1].predictor.class_embed.bias.copy_(torch.tensor(teacher_bias))
+    return model

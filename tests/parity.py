@@ -1,0 +1,101 @@
+"""Shared end-to-end parity harness: run the HIP KD forward+loss and the CPU oracle on identical seeded inputs with
+identical injected point coordinates.  Used by tests/ and __graft_entry__.smoke() only (it imports oracle/)."""
+import numpy as np
+import torch
+
+from s2d_amd.modeling import TargetSet, build_kd_model
+from s2d_amd.utils import synth
+from s2d_amd.utils.seeded import seeded_state
+from s2d_amd import ops
+
+
+def seeded_load(module, seed):
+    sd = module.state_dict()
+    new = seeded_state([(k, tuple(v.shape)) for k, v in sd.items()], seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=True)
+    return new
+
+
+def make_case(seed, B, T, H0, W0, Q, P, ns):
+    frames = np.stack([synth.smooth_frames_u8(seed, 10 + b, T, H0, W0) for b in range(B)]).reshape(B * T, 3, H0, W0)
+    tg = [synth.ellipse_targets(seed, 100 + b, n, T, H0, W0) for b, n in enumerate(ns)]
+    return frames, tg
+
+
+def make_coords(seed, NL, B, Q, Nmax, T, P):
+    rng = np.random.default_rng(seed)
+    maxm = min(Q, Nmax)
+    R = B * maxm * T
+    n_over, n_unc = int(P * 3.0), int(0.75 * P)
+    return dict(matcher=rng.random((NL, B, P, 2), dtype=np.float32), over=rng.random((NL, R, n_over, 2), dtype=np.float32),
+                rand=rng.random((NL, R, P - n_unc, 2), dtype=np.float32))
+
+
+def run_oracle(oracle, params_s, params_t, frames, tg, T, Q, P, coords_gt, coords_kd, weight_dict, mw=(0.0, 5.0, 5.0), NL=10):
+    B = len(tg)
+    x = oracle.normalize_pad(frames)
+    Hp, Wp = x.shape[-2:]
+
+    def net(p):
+        feats = oracle.resnet50(p, x, "0.")
+        mf, ms = oracle.pixel_decoder(p, feats, "1.pixel_decoder.")
+        return oracle.video_decoder(p, ms, mf, T, "1.predictor.", n_layers=NL - 1)
+
+    s_logits, s_masks = net(params_s)
+    t_logits, t_masks = net(params_t)
+    gts = [oracle.prepare_targets(m, ids, Hp, Wp)[0] for m, ids in tg]
+    kd = [oracle.kd_targets(t_logits[-1, b], t_masks[-1, b], Hp, Wp)[0] for b in range(B)]
+
+    # simple explicit driver instead of a clever iterator: replicate oracle.criterion's order here
+    def crit(targets, c):
+        num_masks = max(float(sum(t.shape[0] for t in targets)), 1.0)
+        losses, idxs = {}, []
+        for layer in [NL - 1] + list(range(NL - 1)):
+            coords = [c["matcher"][layer, b][None] for b in range(B)]
+            idx = oracle.matcher(s_logits[layer], s_masks[layer], targets, coords, *mw)
+            idxs.append(idx)
+            if layer == NL - 1:
+                losses["loss_ce"] = oracle.loss_labels(s_logits[layer], idx)
+            lm, ld = oracle.loss_masks(s_masks[layer], targets, idx, num_masks, c["over"][layer], c["rand"][layer], P=P)
+            suf = "" if layer == NL - 1 else f"_{layer}"
+            losses["loss_mask" + suf], losses["loss_dice" + suf] = lm, ld
+        return losses, idxs
+
+    losses, idx_gt = crit(gts, coords_gt)
+    dl, idx_kd = crit(kd, coords_kd)
+    for k, v in dl.items():
+        losses[k.replace("loss_", "kd_loss_")] = v
+    out = {k: np.float32(v * weight_dict[k]) for k, v in losses.items() if k in weight_dict}
+    return dict(losses=out, idx_gt=idx_gt, idx_kd=idx_kd, s_logits=s_logits, s_masks=s_masks, t_logits=t_logits,
+                kd_counts=[k.shape[0] for k in kd])
+
+
+def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), NL=10, weights=(2.0, 5.0, 5.0)):
+    """returns (hip result dict, oracle result dict or None)"""
+    dev = torch.device("cuda:0")
+    model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=weights, dec_layers=NL)
+    ps = seeded_load(model.student, seed)
+    pt = seeded_load(model.teacher, seed + 1)
+    model = model.to(dev)
+    frames, tg = make_case(seed, B, T, H0, W0, Q, P, ns)
+    images = ops.normalize_pad(torch.from_numpy(frames).to(dev))
+    Hp, Wp = images.shape[1:3]
+    gts = []
+    for m, ids in tg:
+        pad = np.zeros((m.shape[0], T, Hp, Wp), np.uint8)
+        pad[:, :, :H0, :W0] = m
+        gts.append(torch.from_numpy(pad[(ids != -1).any(-1)]))
+    Ngt = max(max(g.shape[0] for g in gts), 1)
+    cg = make_coords(seed + 10, NL, B, Q, Ngt, T, P)
+    ck = make_coords(seed + 11, NL, B, Q, Q, T, P)
+    to = lambda c: {k: torch.from_numpy(v).to(dev) for k, v in c.items()}
+    losses = model.forward_losses(images, TargetSet.from_list(gts, device=dev), to(cg), to(ck), kd_nmax=Q)
+    torch.cuda.synchronize()
+    st = model.last["student"]
+    hip = dict(losses={k: float(v) for k, v in losses.items()}, kd_counts=model.last["kd_count"].cpu().tolist(),
+               s_logits=st.class_logits.cpu().numpy(), s_masks=torch.stack([st.pred_masks(i) for i in range(NL)]).cpu().numpy(),
+               model=model)
+    ref = None
+    if oracle is not None:
+        ref = run_oracle(oracle, ps, pt, frames, tg, T, Q, P, cg, ck, model.criterion.weight_dict, weights, NL)
+    return hip, ref
