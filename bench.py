@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- clip-frames/s of the S2D hot path on MI355X: KDVideoMaskFormer forward + distillation loss
+(student fwd + teacher fwd + GT criterion + KD targets + KD criterion), R50 M2F-Video, T=8, 720p (736x1280 padded),
+Q=100, P=160000, 2 clips per GPU (BASELINE.json configs[3] shapes; forward+loss as BASELINE.json:metric says).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch (2 clips x 8 frames per GPU) of synthetic input that is already
+resident in HBM.  Clips are independent units: ranks shard clips, forward+loss needs no collective (scaling: weak).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (B clips/GPU, T, H0, W0, Q, P, N gt instances/clip)
+    "c4": (2, 8, 720, 1280, 100, 160000, 10),   # the metric's config: T=8 720p Q=100
+    "c2": (1, 2, 480, 854, 100, 12544, 10),      # BASELINE configs[1]
+    "tiny": (1, 2, 64, 96, 16, 256, 3),
+}
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def synth_batch(rank, B, T, H0, W0, N, device):
+    """seeded synthetic clips: smooth-noise frames + sparse moving ellipses, generated on the device"""
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    coarse = torch.rand((B * T, 3, H0 // 8 + 2, W0 // 8 + 2), generator=g, device=device)
+    frames = torch.nn.functional.interpolate(coarse, size=(H0, W0), mode="bilinear", align_corners=False)
+    frames = (frames * 255).clamp(0, 255).to(torch.uint8).contiguous()
+    Hp, Wp = (H0 + 31) // 32 * 32, (W0 + 31) // 32 * 32
+    yy = torch.arange(Hp, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(Wp, device=device, dtype=torch.float32)[None, :]
+    rng = np.random.default_rng(1234 + rank)
+    masks = []
+    for b in range(B):
+        m = torch.zeros((N, T, Hp, Wp), dtype=torch.uint8, device=device)
+        for i in range(N):
+            cy, cx = rng.uniform(0.2 * H0, 0.8 * H0), rng.uniform(0.2 * W0, 0.8 * W0)
+            ry, rx = rng.uniform(24, 160) * H0 / 720, rng.uniform(24, 160) * H0 / 720
+            present = rng.random(T) >= 0.5                      # sparse: ~50 % of frames annotated (DropLoss)
+            present[rng.integers(T)] = True
+            for t in range(T):
+                cy += rng.uniform(-8, 8); cx += rng.uniform(-8, 8)
+                if present[t]:
+                    e = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+                    e[H0:, :] = False; e[:, W0:] = False
+                    m[i, t] = e
+        masks.append(m)
+    return frames, masks
+
+
+def calibrate_teacher(model, images, want=10):
+    """random-init teachers score ~half the queries above 0.75; shift the class bias so ~`want` queries per clip pass
+    the distillation threshold ('teacher class logits biased so ~10 queries pass')."""
+    out = model.teacher(images, True)
+    d = (out.class_logits[-1][..., 0] - out.class_logits[-1][..., 1]).flatten().sort(descending=True).values
+    B = out.class_logits.shape[1]
+    thr = float(d[min(want * B, d.numel() - 1)])
+    need = float(np.log(0.75 / 0.25))
+    with torch.no_grad():
+        bias = model.teacher[1].predictor.class_embed.bias
+        bias[0] += (need - thr) / 2
+        bias[1] -= (need - thr) / 2
+
+
+def cpu_baseline(cfg_name):
+    """the CPU oracle timed on a bounded sample of the same workload (rank 0, N=1 only)"""
+    from oracle import oracle_np as O
+    from s2d_amd.utils import synth
+    from s2d_amd.utils.seeded import seeded_state
+    from tests.test_oracle import pixel_decoder_shapes, video_decoder_shapes
+    B, T, H0, W0, Q, P, N = CONFIGS[cfg_name]
+    Ts = 1                                      # sample: ONE frame of one clip, student forward + GT criterion (10 layers)
+    p = seeded_state([("0." + k, s) for k, s in O.r50_param_shapes()] +
+                     [("1.pixel_decoder." + k, s) for k, s in pixel_decoder_shapes()] +
+                     [("1.predictor." + k, s) for k, s in video_decoder_shapes(Q)], 0)
+    fr = synth.smooth_frames_u8(0, 1, Ts, H0, W0)
+    m, ids = synth.ellipse_targets(0, 2, N, Ts, H0, W0, sparse=0.0)
+    t0 = time.perf_counter()
+    x = O.normalize_pad(fr)
+    feats = O.resnet50(p, x, "0.")
+    mf, ms = O.pixel_decoder(p, feats, "1.pixel_decoder.")
+    logits, masks = O.video_decoder(p, ms, mf, Ts, "1.predictor.")
+    tg = [O.prepare_targets(m, ids, x.shape[2], x.shape[3])[0]]
+    rng = np.random.default_rng(0)
+    NL = logits.shape[0]
+    num_masks = float(max(tg[0].shape[0], 1))
+    for layer in range(NL):
+        coords = [rng.random((1, P, 2), dtype=np.float32)]
+        idx = O.matcher(logits[layer], masks[layer], tg, coords, 0.0, 5.0, 5.0)
+        O.loss_masks(masks[layer], tg, idx, num_masks, P=P, rng=rng)
+    dt = time.perf_counter() - t0
+    # the KD step also runs the teacher forward and the KD criterion: ~2x this sample's work per frame
+    return {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 frame {H0}x{W0} (T=1, Q={Q}, P={P}, N={N}): oracle student fwd + 10-layer GT criterion took {dt:.1f}s; "
+                      f"KD step = 2x (teacher fwd + KD criterion) -> frames/s = 1/(2*{dt:.1f})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from s2d_amd import ops
+    from s2d_amd.modeling import TargetSet, build_kd_model
+    B, T, H0, W0, Q, P, N = CONFIGS[args.config]
+    model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
+    model.train()
+    frames, masks = synth_batch(rank, B, T, H0, W0, N, dev)
+    gt = TargetSet.from_list(masks, device=dev)
+    calibrate_teacher(model, ops.normalize_pad(frames))
+    mean, std = model.pixel_mean.flatten().cpu().numpy(), model.pixel_std.flatten().cpu().numpy()
+
+    def step():
+        images = ops.normalize_pad(frames, 32, mean, std)
+        losses = model.forward_losses(images, gt)
+        return sum(losses.values())
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_kernel_events:
+        ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    assert bool(torch.isfinite(total)), "non-finite loss"
+
+    if rank == 0:
+        frames_per_step = world * B * T
+        res = {"metric": "clip-frames/sec fwd+loss, R50 M2F-Video T=8 720p Q=100", "value": round(frames_per_step * args.steps / dt, 3),
+               "unit": "clip-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
+                                      f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
+                          "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
+                          "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
+        if prof:
+            ms = sum(s.elapsed_time(e) for s, e, _ in prof)
+            fl = sum(f for _, _, f in prof)
+            n = len(prof)
+            ach = fl / (ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32-MFMA NT GEMM / implicit-GEMM conv)",
+                               "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": n // args.steps, "avg_launch_us": round(1000 * ms / n, 2),
+                               "kernel_ms_per_step": round(ms / args.steps, 2),
+                               "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

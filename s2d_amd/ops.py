@@ -5,8 +5,29 @@ import torch
 from ._lib import lib
 
 
+PROFILE = None   # bench.py sets this to a list: (start_event, end_event, algorithmic flops) per dense launch
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+class _Timed:
+    """HIP-event bracket around one dense-contraction launch on the current stream (bench.py roofline)."""
+
+    def __init__(self, flops):
+        self.flops = flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.append((self.s, self.e, self.flops))
 
 
 def _chk(t, dtype=torch.float32):
@@ -33,8 +54,9 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
     sA = M * K if batched else 0
     sB = N * K if B.dim() == 3 else 0
     sC = M * ldc
-    lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, N,
-               M * N if res is not None and res.dim() == 3 else 0, int(relu), _stream())
+    with _Timed(2.0 * bs * M * N * K):
+        lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, N,
+                   M * N if res is not None and res.dim() == 3 else 0, int(relu), _stream())
     return out
 
 
@@ -47,8 +69,9 @@ def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=Fal
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu),
-               _stream())
+    with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * (3 if Cin == 4 else Cin)):   # stem: algorithmic Cin is 3
+        lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu),
+                   _stream())
     return y
 
 
