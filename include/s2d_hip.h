@@ -130,7 +130,7 @@ int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const ui
  * (tgt_count[B]) so that distillation targets, whose number depends on teacher scores, need no host sync.
  * mask_logits are pixel-major [NL][B][T*hm*wm][ldq]; class_logits [NL][B][Q][2]. */
 
-long s2d_matcher_workspace_floats(int NL, int B);
+long s2d_matcher_workspace_floats(int NL, int B, int T, int P);
 
 /* C[problem][Q][Nmax] (columns >= tgt_count[clip] are zero) = w_mask*cost_mask + w_class*cost_class +
  * w_dice*cost_dice at P shared random points per problem: matcher.py:236-287 (batch_sigmoid_ce_loss :38-62,

@@ -23,11 +23,22 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ void rand2(uint64_t seed, uint64_t stream, uint64_t i, float &u, float &v)
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
 {
-    const uint64_t r = mix64(seed ^ mix64(stream * 0xD1342543DE82EF95ull + i));
-    u = (float)(uint32_t)(r & 0xFFFFFFu) * (1.0f / 16777216.0f);
-    v = (float)(uint32_t)((r >> 32) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// per-(seed, stream) key, computed once per work item (wave-uniform)
+__device__ __forceinline__ uint32_t rand_key(uint64_t seed, uint64_t stream)
+{
+    return (uint32_t)mix64(seed ^ mix64(stream * 0xD1342543DE82EF95ull));
+}
+// two uniforms in [0,1) with 24 random bits each (torch.rand's float construction) for counter i
+__device__ __forceinline__ void rand2(uint32_t key, uint32_t i, float &u, float &v)
+{
+    const uint32_t a = hash32(key + 2u * i), b = hash32(key + 2u * i + 1u);
+    u = (float)(a >> 8) * (1.0f / 16777216.0f);
+    v = (float)(b >> 8) * (1.0f / 16777216.0f);
 }
 
 // bilinear sample (grid_sample, zeros padding, align_corners=False) of a [H,W] plane at (u,v) in [0,1]
@@ -149,6 +160,8 @@ struct LossParams {
     float world_size;
     // workspace
     int *active, *rank;       // [rows]
+    int *list;                // [rows] compact list of active row ids (deterministic order: layer, clip, slot, frame)
+    int *lcount;              // [NL + 1]: kept rows per layer; [NL] = total
     float *mq;                // [rows][hm*wm]
     unsigned int *hist;       // [rows][2048]
     unsigned int *prefix;     // [rows]  key prefix found so far
@@ -196,6 +209,20 @@ __global__ void row_prep_kernel(LossParams p)
         if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
+    if (threadIdx.x == 0) p.lcount[layer] = base;
+}
+
+__global__ void row_list_kernel(LossParams p)
+{
+    const int layer = blockIdx.x;
+    const int rows_l = p.B * p.maxm * p.T;
+    int base = 0;
+    for (int l = 0; l < layer; ++l) base += p.lcount[l];
+    for (int r = threadIdx.x; r < rows_l; r += blockDim.x) {
+        const long rowid = (long)layer * rows_l + r;
+        if (p.active[rowid]) p.list[base + p.rank[rowid]] = (int)rowid;
+    }
+    if (layer == p.NL - 1 && threadIdx.x == 0) p.lcount[p.NL] = base + p.lcount[layer];
 }
 
 // gather matched query maps: mq[row][pix] = ml[layer][b][t][pix][q]; 64 pixels per block through LDS
@@ -226,48 +253,72 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(LossParams p)
     }
 }
 
-__device__ __forceinline__ void row_coord(const LossParams &p, long rowid, int layer, bool over, long i, float &u, float &v)
+// c = injected coordinate rows of this work item (or null), key = RNG key of (row, over/rand)
+__device__ __forceinline__ void row_coord(const float *__restrict__ c, uint32_t key, int i, float &u, float &v)
+{
+    if (c) { u = c[2 * i]; v = c[2 * i + 1]; }
+    else rand2(key, (uint32_t)i, u, v);
+}
+__device__ __forceinline__ const float *coord_rows(const LossParams &p, long rowid, bool over)
 {
     const float *c = over ? p.coords_over : p.coords_rand;
-    if (c) {
-        const long rows_l = (long)p.B * p.maxm * p.T;
-        const long n = over ? p.n_over : p.n_rand;
-        const long slot = (long)layer * rows_l + p.rank[rowid];
-        u = c[(slot * n + i) * 2];
-        v = c[(slot * n + i) * 2 + 1];
-    } else {
-        rand2(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1), (uint64_t)i, u, v);
-    }
+    if (!c) return nullptr;
+    const long rows_l = (long)p.B * p.maxm * p.T;
+    const long n = over ? p.n_over : p.n_rand;
+    return c + ((rowid / rows_l) * rows_l + p.rank[rowid]) * n * 2;
 }
+
+// Persistent work distribution for the per-row sampling passes.  Work item = (active row, chunk).  All CH chunks of
+// a row run on ONE XCD (blocks with equal blockIdx % 8 share an XCD under round-robin dispatch: speed only), and an
+// XCD works on 8 rows at a time, so the 235 KB logit maps it samples (4 random 4-B taps per point) stay in its 4 MB
+// L2 instead of thrashing all eight L2s.  Every block reaches its exit: the item index grows until it passes n_active.
+constexpr int CH = 32;            // chunks per row
+constexpr int PGRID = 2048;       // persistent blocks: 8 XCD labels x 256
+struct WorkIter {
+    int xcd, w, n_active;
+    __device__ WorkIter(const LossParams &p) : xcd(blockIdx.x & 7), w(blockIdx.x >> 3), n_active(p.lcount[p.NL]) {}
+    __device__ bool next(const LossParams &p, long &rowid, int &chunk)
+    {
+        const int li = (w / CH) * 8 + xcd;
+        if (li >= n_active) return false;
+        chunk = w % CH;
+        rowid = p.list[li];
+        w += PGRID / 8;
+        return true;
+    }
+};
 
 // level 0: bits 30..20, level 1: bits 19..10, level 2: bits 9..0 of |x|
 template <int LEVEL>
 __global__ __launch_bounds__(256) void hist_kernel(LossParams p)
 {
     __shared__ unsigned int h[2048];
-    const long rowid = blockIdx.y;
-    if (!p.active[rowid]) return;
-    const int rows_l = p.B * p.maxm * p.T;
-    const int layer = (int)(rowid / rows_l);
-    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0u;
-    __syncthreads();
-    const float *map = p.mq + rowid * p.hm * p.wm;
-    const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
-    const long per = (p.n_over + gridDim.x - 1) / gridDim.x;
-    const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_over, i0 + per);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-        float u, v;
-        row_coord(p, rowid, layer, true, i, u, v);
-        const float x = sample_plane(map, p.hm, p.wm, u, v);
-        const unsigned int key = __float_as_uint(fabsf(x));
-        if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
-        else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
-        else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+    constexpr int nb = LEVEL == 0 ? 2048 : 1024;
+    WorkIter it(p);
+    long rowid; int chunk;
+    while (it.next(p, rowid, chunk)) {
+        for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0u;
+        __syncthreads();
+        const float *map = p.mq + rowid * p.hm * p.wm;
+        const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
+        const float *cr = coord_rows(p, rowid, true);
+        const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
+        const int per = (p.n_over + CH - 1) / CH;
+        const int i0 = chunk * per, i1 = min(p.n_over, i0 + per);
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+            float u, v;
+            row_coord(cr, key0, i, u, v);
+            const float x = sample_plane(map, p.hm, p.wm, u, v);
+            const unsigned int key = __float_as_uint(fabsf(x));
+            if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
+            else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
+            else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256)
+            if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
+        __syncthreads();
     }
-    __syncthreads();
-    const int nb = LEVEL == 0 ? 2048 : 1024;
-    for (int i = threadIdx.x; i < nb; i += 256)
-        if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
 }
 
 // find the bin holding the krem-th smallest key; one block per row
@@ -275,8 +326,8 @@ template <int LEVEL>
 __global__ __launch_bounds__(256) void select_kernel(LossParams p)
 {
     __shared__ unsigned int csum[256];
-    const long rowid = blockIdx.x;
-    if (!p.active[rowid]) return;
+    if ((int)blockIdx.x >= p.lcount[p.NL]) return;
+    const long rowid = p.list[blockIdx.x];
     const int nb = LEVEL == 0 ? 2048 : 1024, per = nb / 256;
     const int k = LEVEL == 0 ? p.n_unc : p.krem[rowid];
     unsigned int *h = p.hist + rowid * 2048;
@@ -305,58 +356,65 @@ __global__ __launch_bounds__(256) void select_kernel(LossParams p)
 
 __device__ __forceinline__ void acc_point(float x, float t, float &bce, float &sgt, float &sg, float &ts)
 {
-    const float e = expf(-fabsf(x));
-    const float inv = 1.f / (1.f + e);
+    const float e = __expf(-fabsf(x));
+    const float inv = __frcp_rn(1.f + e);
     const float s = x >= 0.f ? inv : e * inv;
-    bce += fmaxf(x, 0.f) - x * t + log1pf(e);   // F.binary_cross_entropy_with_logits (criterion.py:74)
+    bce += fmaxf(x, 0.f) - x * t + __logf(1.f + e);   // F.binary_cross_entropy_with_logits (criterion.py:74)
     sgt += s * t; sg += s; ts += t;             // dice terms (criterion.py:37-41)
 }
 
 __global__ __launch_bounds__(256) void accumulate_kernel(LossParams p)
 {
-    const long rowid = blockIdx.y;
-    if (!p.active[rowid]) return;
-    const int rows_l = p.B * p.maxm * p.T;
-    const int layer = (int)(rowid / rows_l);
-    const int r = (int)(rowid % rows_l);
-    const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
-    const int prob = layer * p.B + b;
-    const int n = p.idx_t[(long)prob * p.maxm + s];
-    const float *map = p.mq + rowid * p.hm * p.wm;
-    const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * p.H * p.W;
-    const unsigned int thr = p.prefix[rowid];
-    const unsigned int take = (unsigned int)p.krem[rowid];
-    float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
-    {
-        const long per = (p.n_over + gridDim.x - 1) / gridDim.x;
-        const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_over, i0 + per);
-        for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-            float u, v;
-            row_coord(p, rowid, layer, true, i, u, v);
-            const float x = sample_plane(map, p.hm, p.wm, u, v);
-            const unsigned int key = __float_as_uint(fabsf(x));
-            bool sel = key < thr;
-            if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
-            if (sel) acc_point(x, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
-        }
-    }
-    {
-        const long per = (p.n_rand + gridDim.x - 1) / gridDim.x;
-        const long i0 = (long)blockIdx.x * per, i1 = min((long)p.n_rand, i0 + per);
-        for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-            float u, v;
-            row_coord(p, rowid, layer, false, i, u, v);
-            acc_point(sample_plane(map, p.hm, p.wm, u, v), sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
-        }
-    }
     __shared__ float red[4][4];
-    bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int j = threadIdx.x;
-        p.part[(rowid * p.chunks + blockIdx.x) * 4 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    const int rows_l = p.B * p.maxm * p.T;
+    WorkIter it(p);
+    long rowid; int chunk;
+    while (it.next(p, rowid, chunk)) {
+        const int layer = (int)(rowid / rows_l);
+        const int r = (int)(rowid % rows_l);
+        const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
+        const int prob = layer * p.B + b;
+        const int n = p.idx_t[(long)prob * p.maxm + s];
+        const float *map = p.mq + rowid * p.hm * p.wm;
+        const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * p.H * p.W;
+        const unsigned int thr = p.prefix[rowid];
+        const unsigned int take = (unsigned int)p.krem[rowid];
+        float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
+        {
+            const float *cr = coord_rows(p, rowid, true);
+            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
+            const int per = (p.n_over + CH - 1) / CH;
+            const int i0 = chunk * per, i1 = min(p.n_over, i0 + per);
+            for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+                float u, v;
+                row_coord(cr, key0, i, u, v);
+                const float x = sample_plane(map, p.hm, p.wm, u, v);
+                const unsigned int key = __float_as_uint(fabsf(x));
+                bool sel = key < thr;
+                if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+                if (sel) acc_point(x, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+            }
+        }
+        {
+            const float *cr = coord_rows(p, rowid, false);
+            const uint32_t key1 = rand_key(p.seed, (uint64_t)rowid * 2 + 1);
+            const int per = (p.n_rand + CH - 1) / CH;
+            const int i0 = chunk * per, i1 = min(p.n_rand, i0 + per);
+            for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+                float u, v;
+                row_coord(cr, key1, i, u, v);
+                acc_point(sample_plane(map, p.hm, p.wm, u, v), sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+            }
+        }
+        bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int j = threadIdx.x;
+            p.part[(rowid * p.chunks + chunk) * 4 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        }
     }
 }
 
@@ -446,13 +504,13 @@ int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, i
     return S2D_OK;
 }
 
-static const int LOSS_CHUNKS = 8;
+static const int LOSS_CHUNKS = CH;
 
 long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm)
 {
     const long maxm = Q < Nmax ? Q : Nmax;
     const long rows = (long)NL * B * maxm * T;
-    return rows * (2 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 256;
+    return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 4L * (NL + 1) + 512;
 }
 
 int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
@@ -479,6 +537,8 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     p.prefix = (unsigned int *)w; w += rows * 4;
     p.krem = (int *)w; w += rows * 4;
     p.tie = (unsigned int *)w; w += rows * 4;
+    p.list = (int *)w; w += rows * 4;
+    p.lcount = (int *)w; w += 4L * (NL + 1);
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.hist = (unsigned int *)w; w += rows * 2048 * 4;
     p.part = (float *)w; w += rows * LOSS_CHUNKS * 16;
@@ -486,8 +546,9 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     if (hipMemsetAsync(p.hist, 0, (size_t)rows * 2048 * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
     if (hipMemsetAsync(p.tie, 0, (size_t)rows * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
-    const dim3 g(LOSS_CHUNKS, (unsigned)rows);
+    const dim3 g(PGRID);
     hipLaunchKernelGGL(hist_kernel<0>, g, dim3(256), 0, stream, p);
     hipLaunchKernelGGL(select_kernel<0>, dim3((unsigned)rows), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(hist_kernel<1>, g, dim3(256), 0, stream, p);

@@ -61,97 +61,163 @@ struct CostParams {
     const float *ml;         // [NL][B][T*hm*wm][ldq]
     const uint8_t *tgt;      // [B][Nmax][T][H][W]
     const int *tgt_count;    // [B]
-    const float *coords;     // [NL][B][P][2] or null
-    uint64_t seed;
-    int NL, B, Q, ldq, T, hm, wm, H, W, Nmax, P, chunks;
+    const float *coords;     // [NL][B][P][2]  (band-sorted copy made by sort_points)
+    int NL, B, Q, ldq, T, hm, wm, H, W, Nmax, P, chunks;   // chunks = T * CHM
     float *wsA, *wsD;        // [prob][chunk][QP][NP]
     float *wsV;              // [prob][chunk][3][128] : softplus sums[q], sigmoid sums[q], target sums[n]
 };
 
+constexpr int CHM = 16;      // sample chunks per frame
+constexpr int BANDS = 32;    // y-bands of the band sort
+
+// ---- points: generation (RNG mode) and a stable counting sort by y-band --------------------------------
+// The P points of a problem are i.i.d. uniform; every cost term is a SUM over points, so the order is free.
+// Sorting them by image band makes each block's bilinear gathers hit a few MB of logits / target rows that
+// stay in its XCD's L2 instead of striding over the 188 MB per-problem logit tensor.
+__global__ void gen_points_kernel(float *__restrict__ out, uint64_t seed, int P)
+{
+    const int prob = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float u, v;
+    rand2(seed, (uint64_t)prob, (uint64_t)i, u, v);
+    out[((long)prob * P + i) * 2] = u;
+    out[((long)prob * P + i) * 2 + 1] = v;
+}
+
+__device__ __forceinline__ int band_of(float v) { return min(BANDS - 1, max(0, (int)(v * BANDS))); }
+
+__global__ __launch_bounds__(256) void band_count_kernel(const float *__restrict__ in, int P, int *__restrict__ counts)
+{
+    const int band = blockIdx.x, prob = blockIdx.y;
+    const float *c = in + (long)prob * P * 2;
+    int n = 0;
+    for (int i = threadIdx.x; i < P; i += 256) n += band_of(c[2 * i + 1]) == band;
+    __shared__ int red[4];
+    int w = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[prob * BANDS + band] = red[0] + red[1] + red[2] + red[3];
+}
+
+// stable: members of a band keep their original relative order (ordered ballot compaction)
+__global__ __launch_bounds__(256) void band_fill_kernel(const float *__restrict__ in, int P, const int *__restrict__ counts,
+                                                        float *__restrict__ out)
+{
+    const int band = blockIdx.x, prob = blockIdx.y;
+    const float *c = in + (long)prob * P * 2;
+    float *o = out + (long)prob * P * 2;
+    int base = 0;
+    for (int k = 0; k < band; ++k) base += counts[prob * BANDS + k];
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < P; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        float u = 0.f, v = 0.f;
+        bool mine = false;
+        if (i < P) { u = c[2 * i]; v = c[2 * i + 1]; mine = band_of(v) == band; }
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wcnt[w];
+        if (mine) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            o[2 * pos] = u; o[2 * pos + 1] = v;
+        }
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+}
+
+template <int NT>
 __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
 {
-    __shared__ float Ts[SB][NP];
-    __shared__ float coordS[SB][2];
+    constexpr int TN = 32 * NT, SLOTS = 256 / TN, SPT = SB / SLOTS;
+    __shared__ float Ts[SB][TN];
+    __shared__ int bqi[4][SB], bti[4][SB];
+    __shared__ float bqw[4][SB], btw[4][SB];
+    __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
-    const int prob = blockIdx.y, chunk = blockIdx.x;
+    const int prob = blockIdx.z, t = blockIdx.y, c = blockIdx.x;
     const int b = prob % p.B;
     const int N = min(p.tgt_count[b], p.Nmax);
-    const int NT = (N + 31) / 32;
-    const long TP = (long)p.T * p.P;
-    const long per = ((TP + p.chunks - 1) / p.chunks + SB - 1) / SB * SB;
-    const long i0 = (long)chunk * per, i1 = min(TP, i0 + per);
+    if (N == 0 || (NT == 1 ? N > 32 : N <= 32)) return;      // the other instantiation owns this problem
+    const int ntl = (N + 31) / 32;
+    const int per = ((p.P + CHM - 1) / CHM + SB - 1) / SB * SB;
+    const int p0 = c * per, p1 = min(p.P, p0 + per);
     const int q = wv * 32 + l32;
     const bool qok = q < p.Q;
-    const float *ml = p.ml + (long)prob * p.T * p.hm * p.wm * p.ldq;
-    const uint8_t *tg = p.tgt + (long)b * p.Nmax * p.T * p.H * p.W;
-    const float *cr = p.coords ? p.coords + (long)prob * p.P * 2 : nullptr;
+    const float *ml = p.ml + ((long)prob * p.T + t) * p.hm * p.wm * p.ldq + (qok ? q : 0);
+    const uint8_t *tg = p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W;
+    const long tplane = (long)p.T * p.H * p.W;
+    const float *cr = p.coords + (long)prob * p.P * 2;
+    const int tn = tid % TN, slot = tid / TN;
 
-    f32x16 aA[4], aD[4];
+    f32x16 aA[NT], aD[NT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NT; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { aA[k][r] = 0.f; aD[k][r] = 0.f; }
     float spsum = 0.f, sgsum = 0.f, tsum = 0.f;
-    const int tn = tid & 127, tgrp = tid >> 7;
 
-    for (long base = i0; base < i1; base += SB) {
-        __syncthreads();  // previous batch's Ts/coordS fully consumed
+    for (int base = p0; base < p1; base += SB) {
+        const int nvalid = min(SB, p1 - base);
+        __syncthreads();  // previous batch fully consumed
         if (tid < SB) {
-            const long i = base + tid;
             float u = 0.f, v = 0.f;
-            if (i < i1) {
-                const long pi = i % p.P;
-                if (cr) { u = cr[2 * pi]; v = cr[2 * pi + 1]; }
-                else rand2(p.seed, (uint64_t)prob, (uint64_t)pi, u, v);
-            }
-            coordS[tid][0] = u; coordS[tid][1] = v;
+            if (tid < nvalid) { u = cr[2 * (base + tid)]; v = cr[2 * (base + tid) + 1]; }
+            const Bil a = bil_setup(u, v, p.hm, p.wm), d = bil_setup(u, v, p.H, p.W);
+            bqi[0][tid] = a.i00; bqi[1][tid] = a.i01; bqi[2][tid] = a.i10; bqi[3][tid] = a.i11;
+            bqw[0][tid] = a.w00; bqw[1][tid] = a.w01; bqw[2][tid] = a.w10; bqw[3][tid] = a.w11;
+            bti[0][tid] = d.i00; bti[1][tid] = d.i01; bti[2][tid] = d.i10; bti[3][tid] = d.i11;
+            btw[0][tid] = d.w00; btw[1][tid] = d.w01; btw[2][tid] = d.w10; btw[3][tid] = d.w11;
         }
         __syncthreads();
-        // target tile: thread (tn, tgrp) samples target tn at 16 of the 32 points
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int k = tgrp * 16 + s;
-            const long i = base + k;
-            float val = 0.f;
-            if (tn < N && i < i1) {
-                const int t = (int)(i / p.P);
-                const Bil bl = bil_setup(coordS[k][0], coordS[k][1], p.H, p.W);
-                const uint8_t *pl = tg + ((long)tn * p.T + t) * p.H * p.W;
-                if (bl.i00 >= 0) val += (float)pl[bl.i00] * bl.w00;
-                if (bl.i01 >= 0) val += (float)pl[bl.i01] * bl.w01;
-                if (bl.i10 >= 0) val += (float)pl[bl.i10] * bl.w10;
-                if (bl.i11 >= 0) val += (float)pl[bl.i11] * bl.w11;
+        // target tile Ts[k][n]: thread (tn, slot) samples target tn at points slot, slot+SLOTS, ...
+        {
+            const uint8_t *pl = tg + (long)tn * tplane;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int k = slot + SLOTS * j;
+                float val = 0.f;
+                if (tn < N && k < nvalid) {
+#pragma unroll
+                    for (int cnr = 0; cnr < 4; ++cnr) {
+                        const int ix = bti[cnr][k];
+                        if (ix >= 0) val += (float)pl[ix] * btw[cnr][k];
+                    }
+                }
+                Ts[k][tn] = val;
+                tsum += val;
             }
-            Ts[k][tn] = val;
-            tsum += val;
         }
         // query side: lane (q, h) samples its query at points 2s+h
         float xs[16], sg[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = 2 * s + h;
-            const long i = base + k;
             float x = 0.f, sgm = 0.f;
-            if (qok && i < i1) {
-                const int t = (int)(i / p.P);
-                const Bil bl = bil_setup(coordS[k][0], coordS[k][1], p.hm, p.wm);
-                const float *fr = ml + (long)t * p.hm * p.wm * p.ldq + q;
-                if (bl.i00 >= 0) x += fr[(long)bl.i00 * p.ldq] * bl.w00;
-                if (bl.i01 >= 0) x += fr[(long)bl.i01 * p.ldq] * bl.w01;
-                if (bl.i10 >= 0) x += fr[(long)bl.i10 * p.ldq] * bl.w10;
-                if (bl.i11 >= 0) x += fr[(long)bl.i11 * p.ldq] * bl.w11;
-                const float e = expf(-fabsf(x));
-                const float inv = 1.f / (1.f + e);
-                sgm = x >= 0.f ? inv : e * inv;            // sigmoid(x)
-                spsum += fmaxf(x, 0.f) + log1pf(e);        // softplus(x) = BCE-with-logits vs 0  (matcher.py:54-56)
+            if (qok && k < nvalid) {
+#pragma unroll
+                for (int cnr = 0; cnr < 4; ++cnr) {
+                    const int ix = bqi[cnr][k];
+                    if (ix >= 0) x += ml[(long)ix * p.ldq] * bqw[cnr][k];
+                }
+                const float e = __expf(-fabsf(x));
+                const float inv = __frcp_rn(1.f + e);
+                sgm = x >= 0.f ? inv : e * inv;                 // sigmoid(x)
+                spsum += fmaxf(x, 0.f) + __logf(1.f + e);       // softplus(x) = BCE-with-logits vs 0 (matcher.py:54-56)
                 sgsum += sgm;
             }
             xs[s] = x; sg[s] = sgm;
         }
         __syncthreads();  // Ts complete
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt < NT) {
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt < ntl) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float tb = Ts[2 * s + h][nt * 32 + l32];
@@ -162,10 +228,10 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
         }
     }
     // partials: acc[nt][r] = M[q = wv*32 + (r&3)+8(r>>2)+4h][n = nt*32 + l32]
-    const long pc = (long)prob * p.chunks + chunk;
+    const long pc = (long)prob * p.chunks + (long)t * CHM + c;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        if (nt < NT) {
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt < ntl) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -180,12 +246,14 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
         p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
         p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
     }
+    tpart[slot][tn] = tsum;
     __syncthreads();
-    Ts[0][tid & 127] = 0.f;  // reuse as scratch for the two target-sum halves
-    __syncthreads();
-    atomicAdd(&Ts[0][tn], tsum);  // exactly two adds per slot: order-independent in fp32
-    __syncthreads();
-    if (tid < 128) p.wsV[(pc * 3 + 2) * 128 + tid] = Ts[0][tid];
+    if (tid < TN) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) s += tpart[k][tid];   // fixed order: deterministic
+        p.wsV[(pc * 3 + 2) * 128 + tid] = s;
+    }
 }
 
 // C[prob][q][n] = w_mask*cost_mask + w_class*(-softmax(logits)[q][0]) + w_dice*cost_dice   (matcher.py:280-287)
@@ -342,10 +410,10 @@ extern "C" {
 
 
 
-long s2d_matcher_workspace_floats(int NL, int B)
+long s2d_matcher_workspace_floats(int NL, int B, int T, int P)
 {
-    const long nprob = (long)NL * B, ch = 64;
-    return nprob * ch * (2L * QP * NP + 3 * 128);
+    const long nprob = (long)NL * B, ch = (long)T * CHM;
+    return nprob * ch * (2L * QP * NP + 3 * 128) + 4L * nprob * P + nprob * BANDS + 64;
 }
 
 int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
@@ -357,13 +425,24 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     const int nprob = NL * B;
     if (nprob == 0) return S2D_OK;
     CostParams p;
-    p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count; p.coords = coords; p.seed = seed;
+    p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count;
     p.NL = NL; p.B = B; p.Q = Q; p.ldq = ldq; p.T = T; p.hm = hm; p.wm = wm; p.H = H; p.W = W; p.Nmax = Nmax; p.P = P;
-    p.chunks = 64;
+    p.chunks = T * CHM;
     p.wsA = workspace;
     p.wsD = p.wsA + (long)nprob * p.chunks * QP * NP;
     p.wsV = p.wsD + (long)nprob * p.chunks * QP * NP;
-    hipLaunchKernelGGL(matcher_cost_kernel, dim3(p.chunks, nprob), dim3(256), 0, stream, p);
+    float *raw = p.wsV + (long)nprob * p.chunks * 3 * 128;
+    float *sorted = raw + 2L * nprob * P;
+    int *counts = (int *)(sorted + 2L * nprob * P);
+    if (!coords) {
+        hipLaunchKernelGGL(gen_points_kernel, dim3(cdiv(P, 256), nprob), dim3(256), 0, stream, raw, seed, P);
+        coords = raw;
+    }
+    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, counts);
+    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, counts, sorted);
+    p.coords = sorted;
+    hipLaunchKernelGGL(matcher_cost_kernel<1>, dim3(CHM, T, nprob), dim3(256), 0, stream, p);
+    if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(CHM, T, nprob), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
                        class_logits, w_class, w_mask, w_dice, C);
     S2D_CHECK_LAUNCH();
