@@ -179,6 +179,32 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
 int s2d_class_loss_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,
                        float eos_coef, float *loss_ce, hipStream_t stream);
 
+/* ---- keymask discovery (paths relative to /root/reference/keymask_ident) ------------------------------- */
+
+/* pred_tracks_to_binary_masks(return_mask=False), cotracker_matching.py:453-503: tracks [T][Np][2] (x,y px) ->
+ * masks u8 [T][H][W] (zeroed here); torch.round (half-to-even), keep 0<=x<W, 0<=y<H. */
+int s2d_tracks_to_masks_u8(const float *tracks, int T, int Np, int H, int W, uint8_t *masks, hipStream_t stream);
+
+/* extract_mask_matches inner loops (:665-719) for ALL frames and object ids at once: counts[t][id] =
+ * #(point pixels of frame t whose nearest-resized (:687-689) id-map value == id), total[t] = #point pixels.
+ * compute_point_mask_intersection (:640-662) is then counts[t][oid] / total[t] (0.0 if total == 0), formed on the
+ * host in double exactly as the reference's python float division.  idmap int64 [T][Hi][Wi] (:176-209). */
+int s2d_point_id_counts(const uint8_t *point_masks, const int64_t *idmap, int T, int H, int W, int Hi, int Wi, int max_id,
+                        int *counts, int *total, hipStream_t stream);
+
+/* presence[t][id] = id occurs in frame t (torch.unique at :680); u8 [T][max_id+1]. */
+int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_id, uint8_t *presence, hipStream_t stream);
+
+/* cotracker_occlusions.py:359: curve[t] = mean_n(visibility[t][n] != 0). */
+int s2d_visibility_curve_f32(const uint8_t *visibility, int T, int Np, float *curve, hipStream_t stream);
+
+/* K1 (co-tracker is not in the reference tree; self-defined restatement, parity unpinned): local 4-D correlation
+ * corr[t][n][i][j] = <bilinear(fmap[t], coords[t][n] + offset_i), support[n][j]> over C channels, offsets on the
+ * (2r+1)^2 integer grid, zero padding.  fmap NHWC [T][H][W][C], coords [T][Np][2] in pixels of this level,
+ * support [Np][(2r+1)^2][C], corr [T][Np][(2r+1)^2][(2r+1)^2]. */
+int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float *support, int T, int Np, int H, int W, int C,
+                       int r, float *corr, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -637,3 +637,30 @@ def extract_mask_matches(tracks, idmap, H, W, v_range, thr=0.5):
 def visibility_curve(vis):
     """cotracker_occlusions.py:359: mean over points of pred_visibility.float(). vis [T,Np] bool -> [T]."""
     return vis.astype(np.float32).mean(1)
+
+
+def local_correlation(fmap, coords, support, r=3):
+    """K1, SELF-DEFINED (co-tracker is a third-party dependency absent from /root/reference, requirements.txt:2;
+    parity unpinned): local 4-D correlation.  fmap [T,H,W,C], coords [T,Np,2] (x,y px), support [Np,S,C], S=(2r+1)^2.
+    corr[t,n,i,j] = <bilinear(fmap[t], coords[t,n] + offset_i), support[n,j]>, zero padding."""
+    T, H, W, C = fmap.shape
+    Np = coords.shape[1]
+    k = 2 * r + 1
+    dy, dx = np.meshgrid(np.arange(-r, r + 1), np.arange(-r, r + 1), indexing="ij")
+    out = np.zeros((T, Np, k * k, k * k), np.float32)
+    fp = np.pad(fmap.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for t in range(T):
+        x = coords[t, :, 0, None].astype(np.float32) + dx.reshape(1, -1).astype(np.float32)
+        y = coords[t, :, 1, None].astype(np.float32) + dy.reshape(1, -1).astype(np.float32)
+        x0, y0 = np.floor(x), np.floor(y)
+        fx, fy = (x - x0).astype(np.float64), (y - y0).astype(np.float64)
+        nb = np.zeros((Np, k * k, C))
+        for ky in (0, 1):
+            for kx in (0, 1):
+                xx, yy = x0.astype(int) + kx, y0.astype(int) + ky
+                ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+                w = (fx if kx else 1 - fx) * (fy if ky else 1 - fy)
+                v = fp[t, np.clip(yy, -1, H) + 1, np.clip(xx, -1, W) + 1]
+                nb += np.where(ok[..., None], v, 0.0) * w[..., None]
+        out[t] = np.einsum("nic,njc->nij", nb, support.astype(np.float64))
+    return out

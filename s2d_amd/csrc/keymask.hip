@@ -1,0 +1,189 @@
+// Keymask discovery, device side (bandwidth-bound; coalesced HBM, wavefront reductions, no MFMA).
+// Reference: /root/reference/keymask_ident/cotracker_matching.py and cotracker_occlusions.py.
+//
+//  K2 visibility curve      cotracker_occlusions.py:359       mean over points of pred_visibility
+//  K3 tracks -> point masks cotracker_matching.py:453-503     round-half-even, bounds filter, scatter 1
+//  K4 id == oid, nearest    :176-209, :687-689                never materialised: the id map is read through the
+//                                                             nearest-resize index map at the point pixels only
+//  K5 point/mask "IoU"      :640-662                          #(points & obj) / #points  -> integer counts per (frame, id)
+//  K6 match loop            :665-719                          one launch for all frames x all object ids of a tracked mask
+//  K1 local correlation     co-tracker (third party, not in the reference tree): self-defined restatement of its local
+//                           4-D correlation: per (frame, track point) the (2r+1)^2 bilinear-sampled neighbourhood
+//                           features dotted with the track's (2r+1)^2 support features.  PARITY UNPINNED.
+//
+// The reference runs K4+K5 as O(frames x objects) full-frame launches with two .item() syncs per pair; here the
+// point mask is visited once per frame and a per-frame histogram over object ids yields every pair's count at once.
+#include "common.h"
+
+namespace {
+
+__global__ void scatter_tracks_kernel(const float *__restrict__ tracks, int T, int Np, int H, int W, uint8_t *__restrict__ masks)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * Np) return;
+    const int t = (int)(i / Np);
+    const long x = (long)rintf(tracks[2 * i]);       // torch.round: half to even, then .long()
+    const long y = (long)rintf(tracks[2 * i + 1]);
+    if (x >= 0 && x < W && y >= 0 && y < H) masks[((long)t * H + y) * W + x] = 1;
+}
+
+// counts[t][id] = #{point pixels of frame t whose nearest-resized id-map value is id}; total[t] = #point pixels
+__global__ __launch_bounds__(256) void point_id_hist_kernel(const uint8_t *__restrict__ pm, const int64_t *__restrict__ ids,
+                                                            int H, int W, int Hi, int Wi, int max_id,
+                                                            int *__restrict__ counts, int *__restrict__ total)
+{
+    extern __shared__ int hist[];   // [max_id + 2]: ids 0..max_id, last = total
+    const int t = blockIdx.y;
+    for (int i = threadIdx.x; i < max_id + 2; i += 256) hist[i] = 0;
+    __syncthreads();
+    const float sh = (float)Hi / H, sw = (float)Wi / W;      // F.interpolate(mode="nearest"): src = floor(dst * in/out)
+    const long per = ((long)H * W + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = min((long)H * W, i0 + per);
+    const uint8_t *p = pm + (long)t * H * W;
+    const int64_t *idf = ids + (long)t * Hi * Wi;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (!p[i]) continue;
+        const int y = (int)(i / W), x = (int)(i % W);
+        int sy = (int)floorf(y * sh), sx = (int)floorf(x * sw);
+        sy = min(sy, Hi - 1); sx = min(sx, Wi - 1);
+        const int64_t id = idf[(long)sy * Wi + sx];
+        atomicAdd(&hist[max_id + 1], 1);
+        if (id >= 0 && id <= max_id) atomicAdd(&hist[(int)id], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_id; i += 256)
+        if (hist[i]) atomicAdd(&counts[(long)t * (max_id + 1) + i], hist[i]);
+    if (threadIdx.x == 0 && hist[max_id + 1]) atomicAdd(&total[t], hist[max_id + 1]);
+}
+
+// presence[t][id] = id occurs in frame t of the id map (torch.unique of :680)
+__global__ __launch_bounds__(256) void id_presence_kernel(const int64_t *__restrict__ ids, long HW, int max_id,
+                                                          uint8_t *__restrict__ presence)
+{
+    extern __shared__ int seen[];
+    const int t = blockIdx.y;
+    for (int i = threadIdx.x; i <= max_id; i += 256) seen[i] = 0;
+    __syncthreads();
+    const long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = min(HW, i0 + per);
+    const int64_t *p = ids + (long)t * HW;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int64_t id = p[i];
+        if (id >= 0 && id <= max_id && !seen[(int)id]) seen[(int)id] = 1;   // benign race: all writers store 1
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_id; i += 256)
+        if (seen[i]) presence[(long)t * (max_id + 1) + i] = 1;
+}
+
+// vis [T][Np] (bytes, nonzero = visible) -> curve[t] = mean  (wavefront reduction)
+__global__ __launch_bounds__(256) void visibility_kernel(const uint8_t *__restrict__ vis, int Np, float *__restrict__ curve)
+{
+    __shared__ int red[4];
+    const int t = blockIdx.x;
+    int c = 0;
+    for (int i = threadIdx.x; i < Np; i += 256) c += vis[(long)t * Np + i] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) curve[t] = (float)(red[0] + red[1] + red[2] + red[3]) / (float)Np;
+}
+
+// K1: corr[t][n][i][j] = sum_c nb[t][n][i][c] * support[n][j][c], nb = bilinear samples of fmap[t] (NHWC) on the
+// (2r+1)^2 integer-offset grid around coords[t][n] (zero padding outside).  One workgroup per (n, t).
+__global__ __launch_bounds__(256) void local_corr_kernel(const float *__restrict__ fmap, const float *__restrict__ coords,
+                                                         const float *__restrict__ support, int T, int Np, int H, int W,
+                                                         int C, int r, float *__restrict__ corr)
+{
+    extern __shared__ float sm[];
+    const int S = (2 * r + 1) * (2 * r + 1);
+    const int ldc = C + 1;                   // +1: conflict-free column walks
+    float *nb = sm, *sp = sm + S * ldc;
+    const int n = blockIdx.x, t = blockIdx.y;
+    const float cx = coords[((long)t * Np + n) * 2], cy = coords[((long)t * Np + n) * 2 + 1];
+    const float *fm = fmap + (long)t * H * W * C;
+    for (int e = threadIdx.x; e < S * C; e += 256) {
+        const int i = e / C, c = e % C;
+        const int dy = i / (2 * r + 1) - r, dx = i % (2 * r + 1) - r;
+        const float x = cx + dx, y = cy + dy;
+        const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+        const float fx = x - x0, fy = y - y0;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H)
+                v += fm[((long)yy * W + xx) * C + c] * ((k & 1 ? fx : 1.f - fx) * (k >> 1 ? fy : 1.f - fy));
+        }
+        nb[i * ldc + c] = v;
+        sp[i * ldc + c] = support[((long)n * S + i) * C + c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * S; e += 256) {
+        const int i = e / S, j = e % S;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += nb[i * ldc + c] * sp[j * ldc + c];
+        corr[(((long)t * Np + n) * S + i) * S + j] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_tracks_to_masks_u8(const float *tracks, int T, int Np, int H, int W, uint8_t *masks, hipStream_t stream)
+{
+    if (hipMemsetAsync(masks, 0, (size_t)T * H * W, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    const long n = (long)T * Np;
+    if (n == 0) return S2D_OK;
+    hipLaunchKernelGGL(scatter_tracks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, tracks, T, Np, H, W, masks);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_point_id_counts(const uint8_t *point_masks, const int64_t *idmap, int T, int H, int W, int Hi, int Wi, int max_id,
+                        int *counts, int *total, hipStream_t stream)
+{
+    if (max_id < 0 || max_id > 8190) return S2D_ERR_ARG;
+    if (T == 0) return S2D_OK;
+    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T * (max_id + 1), stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipMemsetAsync(total, 0, sizeof(int) * (size_t)T, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(point_id_hist_kernel, dim3(32, T), dim3(256), sizeof(int) * (max_id + 2), stream, point_masks, idmap, H, W,
+                       Hi, Wi, max_id, counts, total);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_id, uint8_t *presence, hipStream_t stream)
+{
+    if (max_id < 0 || max_id > 8190) return S2D_ERR_ARG;
+    if (T == 0) return S2D_OK;
+    if (hipMemsetAsync(presence, 0, (size_t)T * (max_id + 1), stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(id_presence_kernel, dim3(32, T), dim3(256), sizeof(int) * (max_id + 1), stream, idmap, (long)Hi * Wi, max_id,
+                       presence);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_visibility_curve_f32(const uint8_t *visibility, int T, int Np, float *curve, hipStream_t stream)
+{
+    if (T == 0 || Np <= 0) return S2D_OK;
+    hipLaunchKernelGGL(visibility_kernel, dim3(T), dim3(256), 0, stream, visibility, Np, curve);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float *support, int T, int Np, int H, int W, int C,
+                       int r, float *corr, hipStream_t stream)
+{
+    const int S = (2 * r + 1) * (2 * r + 1);
+    const size_t lds = sizeof(float) * 2 * S * (C + 1);
+    if (r < 0 || lds > 64 * 1024) return S2D_ERR_ARG;
+    if (T == 0 || Np == 0) return S2D_OK;
+    hipLaunchKernelGGL(local_corr_kernel, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""GPU parity of the keymask propagation kernels (K2-K6: bit-exact vs reference goldens; K1: vs the self-defined oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from s2d_amd.utils import synth
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(lst):
+    return np.array([[d["frame_id"], d["mask_id"], d["iou"]] for d in lst], np.float64).reshape(-1, 3)
+
+
+def test_keymask_golden():
+    from s2d_amd import keymask as km
+    g = golden("keymask")
+    tracks = torch.from_numpy(g["tracks"]).cuda()                       # [1,T,P,2]
+    idmap = km.IdMap(torch.from_numpy(g["idmap"].astype(np.int64)))
+    T, H, W = idmap.T, idmap.Hi, idmap.Wi
+    tm = km.pred_tracks_to_binary_masks(tracks, H, W)
+    np.testing.assert_array_equal(tm.cpu().numpy(), g["track_masks"])  # K3 bit-exact (half-to-even, OOB)
+    m, a = km.extract_mask_matches((H, W), tracks, idmap, (0, T - 1))
+    np.testing.assert_array_equal(_rows(a), g["allc_same"])             # python-float ratios: bit-exact
+    np.testing.assert_array_equal(_rows(m), g["matches_same"])
+    H2, W2 = (int(v) for v in g["resized_dims"])
+    tr2 = tracks * torch.tensor([W2 / W, H2 / H], device="cuda")
+    m, a = km.extract_mask_matches((H2, W2), tr2, idmap, (1, 4))        # nearest-resize path (:687-689)
+    np.testing.assert_array_equal(_rows(a), g["allc_resized"])
+    np.testing.assert_array_equal(_rows(m), g["matches_resized"])
+
+
+def test_keymask_config3_shapes_vs_oracle(oracle):
+    """BASELINE config 3: 32-frame 480p clip, 6 objects, 2500 tracked points"""
+    from s2d_amd import keymask as km
+    T, H, W, Np = 32, 480, 854, 2500
+    m, _ = synth.ellipse_targets(12, 1, 6, T, H, W, sparse=0.0, rmin=30, rmax=90)
+    idm = np.zeros((T, H, W), np.int64)
+    for o in range(6):
+        idm[m[o] > 0] = o + 1
+    rng = synth.rng_for(12, 2)
+    ys, xs = np.nonzero(m[0, 0])
+    sel = rng.integers(0, len(ys), Np)
+    tracks = np.stack([np.stack([xs[sel], ys[sel]], -1).astype(np.float32) + rng.normal(0, 1, (Np, 2)).astype(np.float32) + 0.6 * t
+                       for t in range(T)])[None]
+    vis = rng.random((1, T, Np)) > 0.3
+    idmap = km.IdMap(torch.from_numpy(idm))
+    mt, al = km.extract_mask_matches((H, W), torch.from_numpy(tracks).cuda(), idmap, (0, T - 1))
+    rm, ra = oracle.extract_mask_matches(tracks[0], idm, H, W, (0, T - 1))
+    np.testing.assert_array_equal(_rows(al), ra)
+    np.testing.assert_array_equal(_rows(mt), rm)
+    np.testing.assert_array_equal(km.visibility_curve(torch.from_numpy(vis)).cpu().numpy(), oracle.visibility_curve(vis[0]))
+    pm = torch.from_numpy(oracle.tracks_to_masks(tracks[0], H, W)[3])
+    assert km.compute_point_mask_intersection(pm, torch.from_numpy(idm[3] == 1)) == oracle.point_mask_iou(idm[3], 1, pm.numpy())
+
+
+def test_local_correlation_vs_oracle(oracle):
+    from s2d_amd import keymask as km
+    T, H, W, C, Np, r = 3, 30, 54, 128, 40, 3
+    fmap = synth.randn(13, 1, (T, H, W, C))
+    coords = (synth.rng_for(13, 2).random((T, Np, 2)) * np.array([W + 4, H + 4]) - 2).astype(np.float32)  # some near/over the border
+    sup = synth.randn(13, 3, (Np, 49, C))
+    ref = oracle.local_correlation(fmap, coords, sup, r)
+    out = km.local_correlation(torch.from_numpy(fmap).cuda(), torch.from_numpy(coords).cuda(), torch.from_numpy(sup).cuda(), r)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
