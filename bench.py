@@ -27,7 +27,11 @@ CONFIGS = {
     "c2": (1, 2, 480, 854, 100, 12544, 10),      # BASELINE configs[1]
     "tiny": (1, 2, 64, 96, 16, 256, 3),
 }
-F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters: dense MFMA peaks
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "bf16x3": 2500.0}
+DENSE_DESC = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
+              "f16x3": "split-fp16 x3 on v_mfma_f32_32x32x16_f16 (fp32-class accuracy: 3 MFMA flops per algorithmic flop)",
+              "bf16x3": "split-bf16 x3 on v_mfma_f32_32x32x16_bf16 (3 MFMA flops per algorithmic flop)"}
 
 
 def synth_batch(rank, B, T, H0, W0, N, device):
@@ -113,6 +117,8 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
+                    help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +134,7 @@ def main():
 
     from s2d_amd import ops
     from s2d_amd.modeling import TargetSet, build_kd_model
+    ops.set_dense_mode(args.dense)
     B, T, H0, W0, Q, P, N = CONFIGS[args.config]
     model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
     model.train()
@@ -170,7 +177,7 @@ def main():
         res = {"metric": "clip-frames/sec fwd+loss, R50 M2F-Video T=8 720p Q=100", "value": round(frames_per_step * args.steps / dt, 3),
                "unit": "clip-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32" if args.dense == "f32" else f"f32 ({args.dense} MFMA for dense contractions)", "data": "synthetic",
                "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
                                       f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
@@ -180,9 +187,13 @@ def main():
             fl = sum(f for _, _, f in prof)
             n = len(prof)
             ach = fl / (ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32-MFMA NT GEMM / implicit-GEMM conv)",
-                               "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            peak = MFMA_PEAK_TFLOPS[args.dense]
+            passes = 1 if args.dense == "f32" else 3
+            res["roofline"] = {"bound": "mfma", "kernel": "dense NT GEMM / implicit-GEMM conv: " + DENSE_DESC[args.dense],
+                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
+                               "mfma_flops_per_algorithmic_flop": passes, "mfma_pipe_frac": round(passes * ach / peak, 4),
+                               "achieved_vs_fp32_mfma_peak_157.3": round(ach / 157.3, 4),
                                "launches_per_step": n // args.steps, "avg_launch_us": round(1000 * ms / n, 2),
                                "kernel_ms_per_step": round(ms / args.steps, 2),
                                "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1)}

@@ -30,6 +30,11 @@ extern "C" {
 
 int s2d_abi_version(void);
 
+/* Arithmetic of the dense contractions below (process-wide): 1 (default) = split-bf16 x3 on the bf16 MFMA
+ * (A.B^T ~= Ah.Bh^T + Ah.Bl^T + Al.Bh^T with f32 accumulation: fp32-class accuracy, ~1e-5 relative);
+ * 0 = fp32-input MFMA (an exact f32 FMA chain, 1/16 of the bf16 rate). */
+int s2d_set_dense_mode(int mode);
+
 /* ---- dense contractions (fp32-input MFMA) ------------------------------------------------------ */
 
 /* C[b][M,N] = act((A[b][M,K] * B[b][N,K]^T) * scale[N] + bias[N] + res[b][M,N]); scale/bias/res may be NULL.

@@ -11,23 +11,11 @@
 // from one ds_read_b128: lane half h supplies k = 8g+4h+j for MFMA j of group g (A and B use the same
 // map, so every k is visited once).
 #include "common.h"
+#include "gemm_params.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_STRIDE = BK + 4;
-
-struct GemmParams {
-    const float *A, *B;
-    float *C;
-    int M, N, K;
-    long lda, ldb, ldc;
-    long sA, sB, sC;  // batch strides (elements)
-    const float *scale, *bias, *res;
-    long ldr, sR;
-    int relu;
-    // implicit-GEMM convolution (A = NHWC input)
-    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
-};
 
 template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p)
@@ -178,10 +166,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p)
     }
 }
 
+int g_dense_mode = 2;   // 0: fp32-input MFMA (exact f32 FMA chain); 1: split-bf16 x3; 2: split-fp16 x3 (gemm_bf16.hip)
+
 int launch(const GemmParams &p, bool conv, int batch, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return S2D_OK;
     if (p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return S2D_ERR_ARG;
+    if (g_dense_mode >= 1) return s2d_launch_gemm_bf16x3(p, conv, batch, st, g_dense_mode == 2);
     const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
     dim3 grid(nwg, batch);
     if (conv)
@@ -229,3 +220,10 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
 }  // extern "C"
 
 extern "C" int s2d_abi_version(void) { return 1; }
+
+extern "C" int s2d_set_dense_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return S2D_ERR_ARG;
+    g_dense_mode = mode;
+    return S2D_OK;
+}

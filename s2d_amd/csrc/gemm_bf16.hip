@@ -1,0 +1,443 @@
+// Dense contractions at fp32-class accuracy on the bf16 matrix cores ("split-bf16 x3").
+//
+// Every f32 operand x is split on the fly into hi = bf16(x) and lo = bf16(x - hi) while it is staged into LDS, and
+//     A.B^T  ~=  Ah.Bh^T + Ah.Bl^T + Al.Bh^T          (the dropped Al.Bl^T term is ~2^-16 relative)
+// is accumulated in f32 by three v_mfma_f32_32x32x16_bf16 per tile and k-step.  gfx950 has no TF32/xf32 path and its
+// fp32-input MFMA runs at 1/16 of the bf16 rate, so three bf16 MFMAs deliver fp32-class results (observed relative
+// error ~1e-6..1e-5, well inside the path's 1e-3 parity budget) at ~5x the fp32-MFMA throughput.
+//
+// Same NT-GEMM / implicit-GEMM-conv contract and epilogue as gemm.hip (C = act(A.B^T * scale + bias + res)).
+// Tile: (64*WM) x 128 x 32 per workgroup, WM*2 waves, each wave 64x64 = 2x2 MFMA tiles.  WM = 4 (256x128, 512
+// threads, 1 workgroup/CU = 2 waves/SIMD) for large M, WM = 2 (128x128) otherwise.  Staging: global f32 (16-B loads)
+// -> registers -> split (v_cvt_pk_bf16_f32, v_pk_add_f32) -> LDS rows of [16 words hi | 16 words lo | 4 pad]
+// (stride 36 words: conflict-free for ds_read_b128 fragment reads and the ds_write_b64 stores), double buffered.
+#include "common.h"
+#include "gemm_params.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BN = 128, BK = 32, ROWW = 36;  // LDS row = 36 words (144 B)
+
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo)
+{
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+    const unsigned int ua = __builtin_bit_cast(unsigned int, ha), ub = __builtin_bit_cast(unsigned int, hb);
+    const f32x2 fa = {__uint_as_float(ua << 16), __uint_as_float(ua & 0xFFFF0000u)};
+    const f32x2 fb = {__uint_as_float(ub << 16), __uint_as_float(ub & 0xFFFF0000u)};
+    const bf16x2 la = __builtin_convertvector(a - fa, bf16x2), lb = __builtin_convertvector(b - fb, bf16x2);
+    hi[0] = ua; hi[1] = ub;
+    lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
+}
+
+template <int WM, bool CONV>
+__global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
+{
+    constexpr int BM = 64 * WM, NT = 128 * WM, RPT = NT / 8;     // RPT: rows covered per staging pass
+    constexpr int A_IT = BM / RPT, B_IT = BN / RPT;              // float4 loads per thread per k-tile (4 / 4 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *As = lds;                         // [2][BM][ROWW]
+    unsigned int *Bs = lds + 2 * BM * ROWW;         // [2][BN][ROWW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: consecutive tile ids (sharing an A row panel) stay on one XCD (bijective remap)
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+    const float *A = p.A + (long)bz * p.sA;
+    const float *B = p.B + (long)bz * p.sB;
+    float *C = p.C + (long)bz * p.sC;
+
+    // Staging coordinates.  Loads are branch-free buffer loads: an out-of-range row / k / convolution tap gets an
+    // offset beyond the descriptor's size and the hardware returns zeros (no exec-mask branches, so the compiler
+    // can pipeline loads, splits and MFMAs in one basic block).  Rows of consecutive 8-lane groups are 4 apart
+    // (mod 8): their ds_write_b64 land 16 banks apart instead of overlapping (2-way conflict with adjacent rows).
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    constexpr unsigned int OOB = 0xFFFFFFF0u;      // any 16-B load at this offset is out of range -> returns zeros
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    unsigned int a_off[A_IT];      // dense: byte offset of the row; conv: byte offset of the image
+    int a_iy0[A_IT], a_ix0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + RPT * i;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.Wout, t = mm / p.Wout, oy = t % p.Hout, n = t / p.Hout;
+            a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);     // invalid row: every tap is out of the image
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
+        } else {
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : OOB;
+            a_iy0[i] = a_ix0[i] = 0;
+        }
+    }
+    unsigned int b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + r0 + RPT * i;
+        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : OOB;
+    }
+
+    f32x4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
+    auto load_tile = [&](int kt, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
+        const int k = kt * BK + c4 * 4;
+        const bool kok = k < p.K;
+        int kh = 0, kw = 0, ci = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool in = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                off = (in && kok) ? a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4) : OOB;
+            } else {
+                off = (kok && a_off[i] != OOB) ? a_off[i] + (unsigned int)(k * 4) : OOB;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsB, (int)((kok && b_off[i] != OOB) ? b_off[i] + (unsigned int)(k * 4) : OOB), 0, 0));
+    };
+    auto store_tile = [&](int buf, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            u32x2 hi, lo;
+            split4(ra[i], hi, lo);
+            unsigned int *row = &As[(buf * BM + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            u32x2 hi, lo;
+            split4(rb[i], hi, lo);
+            unsigned int *row = &Bs[(buf * BN + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int cur) {
+        // fragment of k-step s: 8 bf16 (16 B) at word 8*s + 4*h (hi) / 16 + 8*s + 4*h (lo) of the lane's row
+        const unsigned int *as = &As[(cur * BM + wm * 64 + l32) * ROWW + 4 * h];
+        const unsigned int *bs = &Bs[(cur * BN + wn * 64 + l32) * ROWW + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const bf16x8 *>(as + t * 32 * ROWW + 8 * s);
+                al[t] = *reinterpret_cast<const bf16x8 *>(as + t * 32 * ROWW + 16 + 8 * s);
+                bh[t] = *reinterpret_cast<const bf16x8 *>(bs + t * 32 * ROWW + 8 * s);
+                bl[t] = *reinterpret_cast<const bf16x8 *>(bs + t * 32 * ROWW + 16 + 8 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // small terms first, the dominant hi.hi last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0, ra0, rb0);
+    if (nk > 1) load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even phase: MFMAs on LDS buffer 0 (tile kt); set 0 is free -> fetch tile kt+2; then stage tile kt+1 (set 1)
+        if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < nk) store_tile(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd phase: MFMAs on buffer 1 (tile kt+1); fetch tile kt+3 into set 1; stage tile kt+2 (set 0)
+        if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
+        compute(1);
+        if (kt + 2 < nk) store_tile(0, ra0, rb0);
+        __syncthreads();
+    }
+
+    const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + l32;
+        if (col >= p.N) continue;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[tm][tn][r] * sc + bi;
+                if (res) v += res[(long)row * p.ldr + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                C[(long)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split-fp16 x3 with a scaled low part ("f16x3"): fp32-class accuracy (~3*2^-22) at the same MFMA count.
+//   x = h + l * 2^-11,   h = fp16_rtz(x),   l = fp16_rtz((x - h) * 2^11)          (22+ significant bits, l never
+//   A.B^T = [Ah.Bh^T] + 2^-11 * [Ah.Bl^T + Al.Bh^T]                                 underflows relative to h)
+// The two brackets are accumulated in separate f32 accumulators (main / cross) and combined in the epilogue.
+// Operands must satisfy |x| < 65504 (fp16 range); the S2D activations and weights are O(1e-3..1e3).
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
+{
+    const h16x2 ha = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), hb = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2 ra = (a - __builtin_convertvector(ha, f32x2)) * 2048.f, rb = (b - __builtin_convertvector(hb, f32x2)) * 2048.f;
+    const h16x2 la = __builtin_amdgcn_cvt_pkrtz(ra[0], ra[1]), lb = __builtin_amdgcn_cvt_pkrtz(rb[0], rb[1]);
+    hi[0] = __builtin_bit_cast(unsigned int, ha); hi[1] = __builtin_bit_cast(unsigned int, hb);
+    lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
+{
+    constexpr int BM = 128, RPT = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *As = lds;                         // [2][BM][ROWW]
+    unsigned int *Bs = lds + 2 * BM * ROWW;         // [2][BN][ROWW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+    const float *A = p.A + (long)bz * p.sA;
+    const float *B = p.B + (long)bz * p.sB;
+    float *C = p.C + (long)bz * p.sC;
+
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    constexpr unsigned int OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    unsigned int a_off[4], b_off[4];
+    int a_iy0[4], a_ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + RPT * i;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.Wout, t = mm / p.Wout, oy = t % p.Hout, n = t / p.Hout;
+            a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
+        } else {
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : OOB;
+            a_iy0[i] = a_ix0[i] = 0;
+        }
+        const int n = n0 + r0 + RPT * i;
+        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : OOB;
+    }
+    f32x4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + c4 * 4;
+        const bool kok = k < p.K;
+        int kh = 0, kw = 0, ci = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool in = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                off = (in && kok) ? a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4) : OOB;
+            } else {
+                off = (kok && a_off[i] != OOB) ? a_off[i] + (unsigned int)(k * 4) : OOB;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsB, (int)((kok && b_off[i] != OOB) ? b_off[i] + (unsigned int)(k * 4) : OOB), 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 hi, lo;
+            split4_f16(ra[i], hi, lo);
+            unsigned int *row = &As[(buf * BM + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+            split4_f16(rb[i], hi, lo);
+            row = &Bs[(buf * BN + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+    };
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned int *as = &As[(cur * BM + wm * 64 + l32) * ROWW + 4 * h];
+        const unsigned int *bs = &Bs[(cur * BN + wn * 64 + l32) * ROWW + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 8 * s);
+                bl[t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 16 + 8 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 8 * s);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 16 + 8 * s);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], accx[i][j], 0, 0, 0);
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], accm[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + l32;
+        if (col >= p.N) continue;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = (accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f)) * sc + bi;
+                if (res) v += res[(long)row * p.ldr + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                C[(long)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <bool CONV>
+int launch_f16(const GemmParams &p, int batch, hipStream_t st)
+{
+    const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV>), dim3(nwg, batch), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+template <int WM, bool CONV>
+int launch_t(const GemmParams &p, int batch, hipStream_t st)
+{
+    constexpr int BM = 64 * WM;
+    const size_t lds = sizeof(unsigned int) * 2 * (BM + BN) * ROWW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_kernel<WM, CONV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, CONV>), dim3(nwg, batch), dim3(128 * WM), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // namespace
+
+int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStream_t st, int f16)
+{
+    GemmParams p = pin;
+    const long bA = conv ? (long)(p.M / ((long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 4L : ((long)(p.M - 1) * p.lda + p.K) * 4L;
+    const long bB = ((long)(p.N - 1) * p.ldb + p.K) * 4L;
+    if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets
+    p.bytesA = (unsigned int)bA; p.bytesB = (unsigned int)bB;
+    // 256-row tiles only when they still fill the chip
+    if (f16) return conv ? launch_f16<true>(p, batch, st) : launch_f16<false>(p, batch, st);
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("S2D_GEMM_WM"); force = e ? atoi(e) : 0; }
+    bool big = (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= 256;
+    if (force == 2) big = false;
+    if (force == 4) big = true;
+    if (big) return conv ? launch_t<4, true>(p, batch, st) : launch_t<4, false>(p, batch, st);
+    return conv ? launch_t<2, true>(p, batch, st) : launch_t<2, false>(p, batch, st);
+}

@@ -1,0 +1,21 @@
+// Parameter block shared by the dense-contraction kernels (gemm.hip: fp32-input MFMA, gemm_bf16.hip: split-bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GemmParams {
+    const float *A, *B;
+    float *C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sA, sB, sC;  // batch strides (elements)
+    const float *scale, *bias, *res;
+    long ldr, sR;
+    int relu;
+    // implicit-GEMM convolution (A = NHWC input)
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+    // byte extents of one batch slice of A and B (buffer-descriptor bounds of the split-bf16 kernel)
+    unsigned int bytesA, bytesB;
+};
+
+
+int s2d_launch_gemm_bf16x3(const GemmParams &p, bool conv, int batch, hipStream_t st, int f16);

@@ -37,6 +37,12 @@ def _chk(t, dtype=torch.float32):
         raise RuntimeError(f"s2d op needs a contiguous {dtype} CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+def set_dense_mode(mode):
+    """"f16x3" (default: split-fp16 x3 on the f16 MFMA, ~3e-7 relative), "bf16x3" (split-bf16 x3, ~5e-6, no range
+    limit) or "f32" (fp32-input MFMA, exact f32 FMA chain)."""
+    lib().call("s2d_set_dense_mode", {"f32": 0, "bf16x3": 1, "f16x3": 2}[mode])
+
+
 def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
     """out[..., M, N] = act(A[..., M, K] @ B[(...), N, K]^T * scale + bias + res).
     A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch)."""

@@ -12,8 +12,16 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture(params=["f32", "bf16x3", "f16x3"], autouse=True)
+def dense_mode(request):
+    from s2d_amd import ops
+    ops.set_dense_mode(request.param)
+    yield request.param
+    ops.set_dense_mode("f16x3")
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (200, 256, 256, 1), (1000, 100, 256, 2), (77, 288, 1024, 1),
-                                          (4096, 2048, 512, 1), (5, 2, 256, 1)])
+                                          (4096, 2048, 512, 1), (5, 2, 256, 1), (40000, 256, 256, 1), (300, 256, 1024, 3)])
 def test_gemm_nt(oracle, M, N, K, batch):
     from s2d_amd import ops
     A = synth.randn(1, 1, (batch, M, K))
