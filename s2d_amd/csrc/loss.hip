@@ -49,12 +49,15 @@ __device__ __forceinline__ float sample_plane(const T *__restrict__ pl, int H, i
     const float x = ((gx + 1.f) * W - 1.f) * 0.5f, y = ((gy + 1.f) * H - 1.f) * 0.5f;
     const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
     const float fx = x - x0, fy = y - y0;
-    const bool xa = x0 >= 0 && x0 < W, xb = x1 >= 0 && x1 < W, ya = y0 >= 0 && y0 < H, yb = y1 >= 0 && y1 < H;
-    float acc = 0.f;
-    if (ya && xa) acc += (float)pl[(long)y0 * W + x0] * ((1.f - fx) * (1.f - fy));
-    if (ya && xb) acc += (float)pl[(long)y0 * W + x1] * (fx * (1.f - fy));
-    if (yb && xa) acc += (float)pl[(long)y1 * W + x0] * ((1.f - fx) * fy);
-    if (yb && xb) acc += (float)pl[(long)y1 * W + x1] * (fx * fy);
+    // zero padding without branches: clamp the tap into the plane and zero its weight (4 unconditional loads)
+    const float wxa = (x0 >= 0 && x0 < W) ? 1.f - fx : 0.f, wxb = (x1 >= 0 && x1 < W) ? fx : 0.f;
+    const float wya = (y0 >= 0 && y0 < H) ? 1.f - fy : 0.f, wyb = (y1 >= 0 && y1 < H) ? fy : 0.f;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1) * W, yb = min(max(y1, 0), H - 1) * W;
+    float acc = (float)pl[ya + xa] * (wxa * wya);
+    acc += (float)pl[ya + xb] * (wxb * wya);
+    acc += (float)pl[yb + xa] * (wxa * wyb);
+    acc += (float)pl[yb + xb] * (wxb * wyb);
     return acc;
 }
 
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void select_kernel(LossParams p)
 __device__ __forceinline__ void acc_point(float x, float t, float &bce, float &sgt, float &sg, float &ts)
 {
     const float e = __expf(-fabsf(x));
-    const float inv = __frcp_rn(1.f + e);
+    const float inv = __builtin_amdgcn_rcpf(1.f + e);
     const float s = x >= 0.f ? inv : e * inv;
     bce += fmaxf(x, 0.f) - x * t + __logf(1.f + e);   // F.binary_cross_entropy_with_logits (criterion.py:74)
     sgt += s * t; sg += s; ts += t;             // dice terms (criterion.py:37-41)

@@ -67,13 +67,16 @@ struct CostParams {
     float *wsV;              // [prob][chunk][3][128] : softplus sums[q], sigmoid sums[q], target sums[n]
 };
 
-constexpr int CHM = 16;      // sample chunks per frame
-constexpr int BANDS = 32;    // y-bands of the band sort
+constexpr int CHM = 16;      // blocks per (problem, frame) pair; they walk the sorted points together (interleaved batches)
+constexpr int BANDS = 16;    // buckets per radix pass of the row sort (2 passes: 256 >= hm rows)
 
-// ---- points: generation (RNG mode) and a stable counting sort by y-band --------------------------------
+// ---- points: generation (RNG mode) and a stable sort by logit-map row ---------------------------------------
 // The P points of a problem are i.i.d. uniform; every cost term is a SUM over points, so the order is free.
-// Sorting them by image band makes each block's bilinear gathers hit a few MB of logits / target rows that
-// stay in its XCD's L2 instead of striding over the 188 MB per-problem logit tensor.
+// They are sorted by the row of the mask-logit map they fall on (stable 2-pass LSD radix sort, 4 bits per pass,
+// each pass a count + an ordered-ballot fill: deterministic).  The CHM blocks of one (problem, frame) pair run on
+// one XCD and walk this list together, so the ~3 logit rows (128 KB each) and target rows they are sampling at
+// any moment are fetched from HBM once and shared through that XCD's L2, instead of every bilinear corner being
+// an L2 miss on the 188 MB per-problem logit tensor (measured before: 12 % L2 hit rate, 47 GB fetched per launch).
 __global__ void gen_points_kernel(float *__restrict__ out, uint64_t seed, int P)
 {
     const int prob = blockIdx.y;
@@ -85,14 +88,19 @@ __global__ void gen_points_kernel(float *__restrict__ out, uint64_t seed, int P)
     out[((long)prob * P + i) * 2 + 1] = v;
 }
 
-__device__ __forceinline__ int band_of(float v) { return min(BANDS - 1, max(0, (int)(v * BANDS))); }
+__device__ __forceinline__ int band_of(float v, int rows, int shift)
+{
+    const int r = min(rows - 1, max(0, (int)(v * rows)));
+    return (r >> shift) & (BANDS - 1);
+}
 
-__global__ __launch_bounds__(256) void band_count_kernel(const float *__restrict__ in, int P, int *__restrict__ counts)
+__global__ __launch_bounds__(256) void band_count_kernel(const float *__restrict__ in, int P, int rows, int shift,
+                                                         int *__restrict__ counts)
 {
     const int band = blockIdx.x, prob = blockIdx.y;
     const float *c = in + (long)prob * P * 2;
     int n = 0;
-    for (int i = threadIdx.x; i < P; i += 256) n += band_of(c[2 * i + 1]) == band;
+    for (int i = threadIdx.x; i < P; i += 256) n += band_of(c[2 * i + 1], rows, shift) == band;
     __shared__ int red[4];
     int w = n;
 #pragma unroll
@@ -103,8 +111,8 @@ __global__ __launch_bounds__(256) void band_count_kernel(const float *__restrict
 }
 
 // stable: members of a band keep their original relative order (ordered ballot compaction)
-__global__ __launch_bounds__(256) void band_fill_kernel(const float *__restrict__ in, int P, const int *__restrict__ counts,
-                                                        float *__restrict__ out)
+__global__ __launch_bounds__(256) void band_fill_kernel(const float *__restrict__ in, int P, int rows, int shift,
+                                                        const int *__restrict__ counts, float *__restrict__ out)
 {
     const int band = blockIdx.x, prob = blockIdx.y;
     const float *c = in + (long)prob * P * 2;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void band_fill_kernel(const float *__restrict_
         const int i = i0 + threadIdx.x;
         float u = 0.f, v = 0.f;
         bool mine = false;
-        if (i < P) { u = c[2 * i]; v = c[2 * i + 1]; mine = band_of(v) == band; }
+        if (i < P) { u = c[2 * i]; v = c[2 * i + 1]; mine = band_of(v, rows, shift) == band; }
         const unsigned long long m = __ballot(mine);
         if (lane == 0) wcnt[wv] = __popcll(m);
         __syncthreads();
@@ -141,13 +149,16 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
     __shared__ float bqw[4][SB], btw[4][SB];
     __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
-    const int prob = blockIdx.z, t = blockIdx.y, c = blockIdx.x;
+    // XCD-affine decode: blocks with equal blockIdx % 8 share an XCD (speed only).  The CHM blocks of a
+    // (problem, frame) pair get consecutive slots on ONE XCD, i.e. they are dispatched together and share its L2.
+    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int pair = (bslot / CHM) * 8 + xcd, c = bslot % CHM;
+    if (pair >= p.NL * p.B * p.T) return;
+    const int prob = pair / p.T, t = pair % p.T;
     const int b = prob % p.B;
     const int N = min(p.tgt_count[b], p.Nmax);
     if (N == 0 || (NT == 1 ? N > 32 : N <= 32)) return;      // the other instantiation owns this problem
     const int ntl = (N + 31) / 32;
-    const int per = ((p.P + CHM - 1) / CHM + SB - 1) / SB * SB;
-    const int p0 = c * per, p1 = min(p.P, p0 + per);
     const int q = wv * 32 + l32;
     const bool qok = q < p.Q;
     const float *ml = p.ml + ((long)prob * p.T + t) * p.hm * p.wm * p.ldq + (qok ? q : 0);
@@ -163,33 +174,36 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
         for (int r = 0; r < 16; ++r) { aA[k][r] = 0.f; aD[k][r] = 0.f; }
     float spsum = 0.f, sgsum = 0.f, tsum = 0.f;
 
-    for (int base = p0; base < p1; base += SB) {
-        const int nvalid = min(SB, p1 - base);
+    for (int base = c * SB; base < p.P; base += CHM * SB) {     // batches c, c+CHM, ... of the row-sorted points
+        const int nvalid = min(SB, p.P - base);
         __syncthreads();  // previous batch fully consumed
         if (tid < SB) {
             float u = 0.f, v = 0.f;
             if (tid < nvalid) { u = cr[2 * (base + tid)]; v = cr[2 * (base + tid) + 1]; }
             const Bil a = bil_setup(u, v, p.hm, p.wm), d = bil_setup(u, v, p.H, p.W);
-            bqi[0][tid] = a.i00; bqi[1][tid] = a.i01; bqi[2][tid] = a.i10; bqi[3][tid] = a.i11;
-            bqw[0][tid] = a.w00; bqw[1][tid] = a.w01; bqw[2][tid] = a.w10; bqw[3][tid] = a.w11;
-            bti[0][tid] = d.i00; bti[1][tid] = d.i01; bti[2][tid] = d.i10; bti[3][tid] = d.i11;
-            btw[0][tid] = d.w00; btw[1][tid] = d.w01; btw[2][tid] = d.w10; btw[3][tid] = d.w11;
+            // out-of-image corners (zero padding): clamp the offset to a valid element and zero the weight, so the
+            // gathers below are unconditional (no exec-mask branches around 80 loads per batch)
+            const bool tail = tid >= nvalid;
+            bqi[0][tid] = a.i00 < 0 ? 0 : a.i00 * p.ldq; bqi[1][tid] = a.i01 < 0 ? 0 : a.i01 * p.ldq;
+            bqi[2][tid] = a.i10 < 0 ? 0 : a.i10 * p.ldq; bqi[3][tid] = a.i11 < 0 ? 0 : a.i11 * p.ldq;
+            bqw[0][tid] = (a.i00 < 0 || tail) ? 0.f : a.w00; bqw[1][tid] = (a.i01 < 0 || tail) ? 0.f : a.w01;
+            bqw[2][tid] = (a.i10 < 0 || tail) ? 0.f : a.w10; bqw[3][tid] = (a.i11 < 0 || tail) ? 0.f : a.w11;
+            bti[0][tid] = max(d.i00, 0); bti[1][tid] = max(d.i01, 0); bti[2][tid] = max(d.i10, 0); bti[3][tid] = max(d.i11, 0);
+            btw[0][tid] = (d.i00 < 0 || tail) ? 0.f : d.w00; btw[1][tid] = (d.i01 < 0 || tail) ? 0.f : d.w01;
+            btw[2][tid] = (d.i10 < 0 || tail) ? 0.f : d.w10; btw[3][tid] = (d.i11 < 0 || tail) ? 0.f : d.w11;
         }
         __syncthreads();
         // target tile Ts[k][n]: thread (tn, slot) samples target tn at points slot, slot+SLOTS, ...
         {
-            const uint8_t *pl = tg + (long)tn * tplane;
+            const uint8_t *pl = tg + (long)(tn < N ? tn : 0) * tplane;
+            const float live = tn < N ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int k = slot + SLOTS * j;
                 float val = 0.f;
-                if (tn < N && k < nvalid) {
 #pragma unroll
-                    for (int cnr = 0; cnr < 4; ++cnr) {
-                        const int ix = bti[cnr][k];
-                        if (ix >= 0) val += (float)pl[ix] * btw[cnr][k];
-                    }
-                }
+                for (int cnr = 0; cnr < 4; ++cnr) val += (float)pl[bti[cnr][k]] * btw[cnr][k];
+                val *= live;
                 Ts[k][tn] = val;
                 tsum += val;
             }
@@ -199,20 +213,16 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = 2 * s + h;
-            float x = 0.f, sgm = 0.f;
-            if (qok && k < nvalid) {
+            float x = 0.f;
 #pragma unroll
-                for (int cnr = 0; cnr < 4; ++cnr) {
-                    const int ix = bqi[cnr][k];
-                    if (ix >= 0) x += ml[(long)ix * p.ldq] * bqw[cnr][k];
-                }
-                const float e = __expf(-fabsf(x));
-                const float inv = __frcp_rn(1.f + e);
-                sgm = x >= 0.f ? inv : e * inv;                 // sigmoid(x)
-                spsum += fmaxf(x, 0.f) + __logf(1.f + e);       // softplus(x) = BCE-with-logits vs 0 (matcher.py:54-56)
-                sgsum += sgm;
-            }
-            xs[s] = x; sg[s] = sgm;
+            for (int cnr = 0; cnr < 4; ++cnr) x += ml[bqi[cnr][k]] * bqw[cnr][k];
+            const float liveq = (qok && k < nvalid) ? 1.f : 0.f;
+            const float e = __expf(-fabsf(x));
+            const float inv = __builtin_amdgcn_rcpf(1.f + e);
+            const float sgm = (x >= 0.f ? inv : e * inv) * liveq;          // sigmoid(x)
+            spsum += (fmaxf(x, 0.f) + __logf(1.f + e)) * liveq;            // softplus(x) = BCE-with-logits vs 0 (matcher.py:54-56)
+            sgsum += sgm;
+            xs[s] = x * liveq; sg[s] = sgm;
         }
         __syncthreads();  // Ts complete
 #pragma unroll
@@ -413,7 +423,7 @@ extern "C" {
 long s2d_matcher_workspace_floats(int NL, int B, int T, int P)
 {
     const long nprob = (long)NL * B, ch = (long)T * CHM;
-    return nprob * ch * (2L * QP * NP + 3 * 128) + 4L * nprob * P + nprob * BANDS + 64;
+    return nprob * ch * (2L * QP * NP + 3 * 128) + 6L * nprob * P + nprob * BANDS + 64;
 }
 
 int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
@@ -433,16 +443,23 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     p.wsV = p.wsD + (long)nprob * p.chunks * QP * NP;
     float *raw = p.wsV + (long)nprob * p.chunks * 3 * 128;
     float *sorted = raw + 2L * nprob * P;
-    int *counts = (int *)(sorted + 2L * nprob * P);
+    float *raw2 = sorted + 2L * nprob * P;
+    int *counts = (int *)(raw2 + 2L * nprob * P);
     if (!coords) {
         hipLaunchKernelGGL(gen_points_kernel, dim3(cdiv(P, 256), nprob), dim3(256), 0, stream, raw, seed, P);
         coords = raw;
     }
-    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, counts);
-    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, counts, sorted);
-    p.coords = sorted;
-    hipLaunchKernelGGL(matcher_cost_kernel<1>, dim3(CHM, T, nprob), dim3(256), 0, stream, p);
-    if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(CHM, T, nprob), dim3(256), 0, stream, p);
+    if (hm > 256) return S2D_ERR_ARG;
+    // stable LSD radix sort on the row index: low nibble (coords -> sorted), then high nibble (sorted -> raw)
+    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, hm, 0, counts);
+    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, hm, 0, counts, sorted);
+    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, sorted, P, hm, 4, counts);
+    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, sorted, P, hm, 4, counts, raw2);
+    p.coords = raw2;
+    const int npairs = nprob * T;
+    const int grid = ((npairs + 7) / 8) * 8 * CHM;
+    hipLaunchKernelGGL(matcher_cost_kernel<1>, dim3(grid), dim3(256), 0, stream, p);
+    if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
                        class_logits, w_class, w_mask, w_dice, C);
     S2D_CHECK_LAUNCH();
