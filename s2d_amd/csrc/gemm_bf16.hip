@@ -72,7 +72,7 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
     constexpr unsigned int OOB = 0xFFFFFFF0u;      // any 16-B load at this offset is out of range -> returns zeros
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
-    unsigned int a_off[A_IT];      // dense: byte offset of the row; conv: byte offset of the image
+    unsigned int a_off[A_IT], a_bad[A_IT];      // dense: byte offset of the row; conv: byte offset of the image; a_bad = OOB bits for rows >= M
     int a_iy0[A_IT], a_ix0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -85,21 +85,23 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
             a_ix0[i] = ox * p.stride - p.pad;
             a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
         } else {
-            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : OOB;
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : 0u;
             a_iy0[i] = a_ix0[i] = 0;
         }
+        a_bad[i] = ok ? 0u : OOB;
     }
-    unsigned int b_off[B_IT];
+    unsigned int b_off[B_IT], b_bad[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int n = n0 + r0 + RPT * i;
-        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : OOB;
+        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : 0u;
+        b_bad[i] = n < p.N ? 0u : OOB;
     }
 
     f32x4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
     auto load_tile = [&](int kt, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
         const int k = kt * BK + c4 * 4;
-        const bool kok = k < p.K;
+        const unsigned int kmask = (unsigned int)((p.K - 1 - k) >> 31) & OOB;   // all-OOB bits when k >= K (no select: keeps loads unconditional)
         int kh = 0, kw = 0, ci = 0;
         if (CONV) {
             const int tap = k / p.Cin;
@@ -112,17 +114,17 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
             unsigned int off;
             if (CONV) {
                 const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-                const bool in = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = (in && kok) ? a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4) : OOB;
+                const unsigned int tmask = (unsigned int)(((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) >> 31)) & OOB;   // tap outside the image
+                off = (a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4)) | tmask | kmask;
             } else {
-                off = (kok && a_off[i] != OOB) ? a_off[i] + (unsigned int)(k * 4) : OOB;
+                off = (a_off[i] + (unsigned int)(k * 4)) | a_bad[i] | kmask;
             }
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsB, (int)((kok && b_off[i] != OOB) ? b_off[i] + (unsigned int)(k * 4) : OOB), 0, 0));
+                rsB, (int)((b_off[i] + (unsigned int)(k * 4)) | b_bad[i] | kmask), 0, 0));
     };
     auto store_tile = [&](int buf, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
 #pragma unroll
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
     constexpr unsigned int OOB = 0xFFFFFFF0u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
-    unsigned int a_off[4], b_off[4];
+    unsigned int a_off[4], b_off[4], a_bad[4], b_bad[4];
     int a_iy0[4], a_ix0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -279,16 +281,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             a_ix0[i] = ox * p.stride - p.pad;
             a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
         } else {
-            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : OOB;
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : 0u;
             a_iy0[i] = a_ix0[i] = 0;
         }
         const int n = n0 + r0 + RPT * i;
-        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : OOB;
+        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : 0u;
+        a_bad[i] = ok ? 0u : OOB;
+        b_bad[i] = n < p.N ? 0u : OOB;
     }
     f32x4 ra[4], rb[4];
     auto load_tile = [&](int kt) {
         const int k = kt * BK + c4 * 4;
-        const bool kok = k < p.K;
+        const unsigned int kmask = (unsigned int)((p.K - 1 - k) >> 31) & OOB;   // all-OOB bits when k >= K (no select: keeps loads unconditional)
         int kh = 0, kw = 0, ci = 0;
         if (CONV) {
             const int tap = k / p.Cin;
@@ -301,14 +305,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             unsigned int off;
             if (CONV) {
                 const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-                const bool in = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = (in && kok) ? a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4) : OOB;
+                const unsigned int tmask = (unsigned int)(((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) >> 31)) & OOB;   // tap outside the image
+                off = (a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4)) | tmask | kmask;
             } else {
-                off = (kok && a_off[i] != OOB) ? a_off[i] + (unsigned int)(k * 4) : OOB;
+                off = (a_off[i] + (unsigned int)(k * 4)) | a_bad[i] | kmask;
             }
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsB, (int)((kok && b_off[i] != OOB) ? b_off[i] + (unsigned int)(k * 4) : OOB), 0, 0));
+                rsB, (int)((b_off[i] + (unsigned int)(k * 4)) | b_bad[i] | kmask), 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
