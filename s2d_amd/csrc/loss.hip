@@ -256,12 +256,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(LossParams p)
     }
 }
 
-// c = injected coordinate rows of this work item (or null), key = RNG key of (row, over/rand)
-__device__ __forceinline__ void row_coord(const float *__restrict__ c, uint32_t key, int i, float &u, float &v)
-{
-    if (c) { u = c[2 * i]; v = c[2 * i + 1]; }
-    else rand2(key, (uint32_t)i, u, v);
-}
 __device__ __forceinline__ const float *coord_rows(const LossParams &p, long rowid, bool over)
 {
     const float *c = over ? p.coords_over : p.coords_rand;
@@ -271,56 +265,105 @@ __device__ __forceinline__ const float *coord_rows(const LossParams &p, long row
     return c + ((rowid / rows_l) * rows_l + p.rank[rowid]) * n * 2;
 }
 
-// Persistent work distribution for the per-row sampling passes.  Work item = (active row, chunk).  All CH chunks of
-// a row run on ONE XCD (blocks with equal blockIdx % 8 share an XCD under round-robin dispatch: speed only), and an
-// XCD works on 8 rows at a time, so the 235 KB logit maps it samples (4 random 4-B taps per point) stay in its 4 MB
-// L2 instead of thrashing all eight L2s.  Every block reaches its exit: the item index grows until it passes n_active.
-constexpr int CH = 32;            // chunks per row
-constexpr int PGRID = 2048;       // persistent blocks: 8 XCD labels x 256
-struct WorkIter {
-    int xcd, w, n_active;
-    __device__ WorkIter(const LossParams &p) : xcd(blockIdx.x & 7), w(blockIdx.x >> 3), n_active(p.lcount[p.NL]) {}
-    __device__ bool next(const LossParams &p, long &rowid, int &chunk)
+// ---- LDS-staged sampling --------------------------------------------------------------------------------------
+// The radix-select passes evaluate 3P = 480 000 bilinear samples per matched row on a 235 KB logit map.  Read from
+// L2 every 4-byte tap moves a 64-B sector (measured: ~12 ms per pass, fabric-bound).  Instead a work item = (row,
+// part): the workgroup copies one horizontal part of the map (<= 120 KB, + 1 overlap row) into LDS once, regenerates
+// the row's points from the counter RNG and handles those whose upper tap row falls in its part; all four taps
+// are then LDS reads.  v (the y coordinate) is drawn first so foreign points are dropped after one hash.
+constexpr int PART_BYTES = 120 * 1024;
+constexpr int LTHREADS = 512;
+struct PartGeom {
+    int rows_per_part, nparts;
+};
+__host__ __device__ inline PartGeom part_geom(int hm, int wm)
+{
+    PartGeom g;
+    g.rows_per_part = PART_BYTES / (wm * 4) - 1;
+    if (g.rows_per_part > hm) g.rows_per_part = hm;
+    g.nparts = (hm + g.rows_per_part - 1) / g.rows_per_part;
+    return g;
+}
+
+// persistent item loop: item = (active row index li, part)
+struct PartIter {
+    int w, n_items, nparts;
+    __device__ PartIter(const LossParams &p, int nparts_) : w(blockIdx.x), n_items(p.lcount[p.NL] * nparts_), nparts(nparts_) {}
+    __device__ bool next(const LossParams &p, long &rowid, int &part)
     {
-        const int li = (w / CH) * 8 + xcd;
-        if (li >= n_active) return false;
-        chunk = w % CH;
-        rowid = p.list[li];
-        w += PGRID / 8;
+        if (w >= n_items) return false;
+        rowid = p.list[w / nparts];
+        part = w % nparts;
+        w += gridDim.x;
         return true;
     }
 };
 
+// copy rows [r0, r0+nr) of the row's map into LDS (16-B loads)
+__device__ __forceinline__ void stage_part(const float *__restrict__ map, int wm, int r0, int nr, float *__restrict__ sm)
+{
+    const int n4 = nr * wm / 4;   // wm % 4 == 0 is checked on the host
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(map + (long)r0 * wm);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(sm);
+    for (int i = threadIdx.x; i < n4; i += LTHREADS) dst[i] = src[i];
+}
+
+// bilinear sample from the staged part; (y0 - r0, y0 + 1 - r0) are guaranteed inside the part for owned points
+__device__ __forceinline__ float sample_part(const float *__restrict__ sm, int hm, int wm, int r0, float x, float y, int x0, int y0)
+{
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float fx = x - x0, fy = y - y0;
+    const float wxa = (x0 >= 0) ? 1.f - fx : 0.f, wxb = (x1 < wm) ? fx : 0.f;
+    const float wya = (y0 >= 0) ? 1.f - fy : 0.f, wyb = (y1 < hm) ? fy : 0.f;
+    const int xa = max(x0, 0), xb = min(x1, wm - 1);
+    const int ya = (max(y0, 0) - r0) * wm, yb = (min(y1, hm - 1) - r0) * wm;
+    float acc = sm[ya + xa] * (wxa * wya);
+    acc += sm[ya + xb] * (wxb * wya);
+    acc += sm[yb + xa] * (wxa * wyb);
+    acc += sm[yb + xb] * (wxb * wyb);
+    return acc;
+}
+
 // level 0: bits 30..20, level 1: bits 19..10, level 2: bits 9..0 of |x|
 template <int LEVEL>
-__global__ __launch_bounds__(256) void hist_kernel(LossParams p)
+__global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
 {
-    __shared__ unsigned int h[2048];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int nb = LEVEL == 0 ? 2048 : 1024;
-    WorkIter it(p);
-    long rowid; int chunk;
-    while (it.next(p, rowid, chunk)) {
-        for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0u;
+    const PartGeom g = part_geom(p.hm, p.wm);
+    unsigned int *h = reinterpret_cast<unsigned int *>(smem);
+    float *sm = smem + 2048;
+    PartIter it(p, g.nparts);
+    long rowid; int part;
+    while (it.next(p, rowid, part)) {
         __syncthreads();
-        const float *map = p.mq + rowid * p.hm * p.wm;
+        for (int i = threadIdx.x; i < nb; i += LTHREADS) h[i] = 0u;
+        const int r0 = part * g.rows_per_part;
+        const int nr = min(g.rows_per_part + 1, p.hm - r0);
+        stage_part(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
+        __syncthreads();
         const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
         const float *cr = coord_rows(p, rowid, true);
         const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
-        const int per = (p.n_over + CH - 1) / CH;
-        const int i0 = chunk * per, i1 = min(p.n_over, i0 + per);
-        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
+        const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
+        for (int i = threadIdx.x; i < p.n_over; i += LTHREADS) {
             float u, v;
-            row_coord(cr, key0, i, u, v);
-            const float x = sample_plane(map, p.hm, p.wm, u, v);
-            const unsigned int key = __float_as_uint(fabsf(x));
+            if (cr) { v = cr[2 * i + 1]; } else { v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f); }
+            const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+            const int y0 = (int)floorf(y);
+            if (y0 < ylo || y0 >= yhi) continue;
+            if (cr) { u = cr[2 * i]; } else { u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f); }
+            const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+            const float xv = sample_part(sm, p.hm, p.wm, r0, x, y, (int)floorf(x), y0);
+            const unsigned int key = __float_as_uint(fabsf(xv));
             if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
             else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
             else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += 256)
+        for (int i = threadIdx.x; i < nb; i += LTHREADS)
             if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
-        __syncthreads();
     }
 }
 
@@ -366,57 +409,65 @@ __device__ __forceinline__ void acc_point(float x, float t, float &bce, float &s
     sgt += s * t; sg += s; ts += t;             // dice terms (criterion.py:37-41)
 }
 
-__global__ __launch_bounds__(256) void accumulate_kernel(LossParams p)
+__global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
 {
-    __shared__ float red[4][4];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[LTHREADS / 64][4];
+    const PartGeom g = part_geom(p.hm, p.wm);
+    float *sm = smem;
     const int rows_l = p.B * p.maxm * p.T;
-    WorkIter it(p);
-    long rowid; int chunk;
-    while (it.next(p, rowid, chunk)) {
+    PartIter it(p, g.nparts);
+    long rowid; int part;
+    while (it.next(p, rowid, part)) {
+        __syncthreads();
+        const int r0 = part * g.rows_per_part;
+        const int nr = min(g.rows_per_part + 1, p.hm - r0);
+        stage_part(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
+        __syncthreads();
         const int layer = (int)(rowid / rows_l);
         const int r = (int)(rowid % rows_l);
         const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
         const int prob = layer * p.B + b;
         const int n = p.idx_t[(long)prob * p.maxm + s];
-        const float *map = p.mq + rowid * p.hm * p.wm;
         const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * p.H * p.W;
         const unsigned int thr = p.prefix[rowid];
         const unsigned int take = (unsigned int)p.krem[rowid];
+        const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
         float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
-        {
-            const float *cr = coord_rows(p, rowid, true);
-            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
-            const int per = (p.n_over + CH - 1) / CH;
-            const int i0 = chunk * per, i1 = min(p.n_over, i0 + per);
-            for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {          // pass 0: the 3P oversampled points, pass 1: the extra uniform points
+            const bool over = pass == 0;
+            const float *cr = coord_rows(p, rowid, over);
+            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
+            const int cnt = over ? p.n_over : p.n_rand;
+            for (int i = threadIdx.x; i < cnt; i += LTHREADS) {
                 float u, v;
-                row_coord(cr, key0, i, u, v);
-                const float x = sample_plane(map, p.hm, p.wm, u, v);
-                const unsigned int key = __float_as_uint(fabsf(x));
-                bool sel = key < thr;
-                if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
-                if (sel) acc_point(x, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
-            }
-        }
-        {
-            const float *cr = coord_rows(p, rowid, false);
-            const uint32_t key1 = rand_key(p.seed, (uint64_t)rowid * 2 + 1);
-            const int per = (p.n_rand + CH - 1) / CH;
-            const int i0 = chunk * per, i1 = min(p.n_rand, i0 + per);
-            for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-                float u, v;
-                row_coord(cr, key1, i, u, v);
-                acc_point(sample_plane(map, p.hm, p.wm, u, v), sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+                if (cr) { v = cr[2 * i + 1]; } else { v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f); }
+                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+                const int y0 = (int)floorf(y);
+                if (y0 < ylo || y0 >= yhi) continue;
+                if (cr) { u = cr[2 * i]; } else { u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f); }
+                const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                const float xv = sample_part(sm, p.hm, p.wm, r0, x, y, (int)floorf(x), y0);
+                bool sel = true;
+                if (over) {
+                    const unsigned int key = __float_as_uint(fabsf(xv));
+                    sel = key < thr;
+                    if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+                }
+                if (sel) acc_point(xv, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
             }
         }
         bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        __syncthreads();
         if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
         __syncthreads();
         if (threadIdx.x < 4) {
             const int j = threadIdx.x;
-            p.part[(rowid * p.chunks + chunk) * 4 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < LTHREADS / 64; ++w) tot += red[w][j];
+            p.part[(rowid * p.chunks + part) * 4 + j] = tot;
         }
     }
 }
@@ -507,7 +558,7 @@ int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, i
     return S2D_OK;
 }
 
-static const int LOSS_CHUNKS = CH;
+static const int LOSS_CHUNKS = 8;   // >= number of map parts per row (partial-sum slots)
 
 long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm)
 {
@@ -551,14 +602,29 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
-    const dim3 g(PGRID);
-    hipLaunchKernelGGL(hist_kernel<0>, g, dim3(256), 0, stream, p);
+    const PartGeom pg = part_geom(hm, wm);
+    if ((wm & 3) || pg.rows_per_part < 1 || pg.nparts > LOSS_CHUNKS) return S2D_ERR_ARG;
+    p.chunks = pg.nparts;
+    const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 1) * wm;
+    const size_t lds_hist = lds_map + sizeof(float) * 2048;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int cap = PART_BYTES + 8192 + 4096;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const dim3 g(512);      // persistent: 2 blocks per CU's worth of items in flight
+    hipLaunchKernelGGL(hist_kernel<0>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<0>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(hist_kernel<1>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hist_kernel<1>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(hist_kernel<2>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(accumulate_kernel, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
