@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dense-breakdown", action="store_true", help="print per-shape time of the dense launches to stderr")
     ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
     args = ap.parse_args()
@@ -183,8 +184,8 @@ def main():
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
         if prof:
-            ms = sum(s.elapsed_time(e) for s, e, _ in prof)
-            fl = sum(f for _, _, f in prof)
+            ms = sum(s.elapsed_time(e) for s, e, *_ in prof)
+            fl = sum(f for _, _, f, *_ in prof)
             n = len(prof)
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dense]
@@ -197,6 +198,13 @@ def main():
                                "launches_per_step": n // args.steps, "avg_launch_us": round(1000 * ms / n, 2),
                                "kernel_ms_per_step": round(ms / args.steps, 2),
                                "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1)}
+        if prof and args.dense_breakdown:
+            import collections
+            agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for s_, e_, f_, tag in prof:
+                a = agg[tag]; a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
+            for tag, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+                print(f"{str(tag):44s} calls/step {n/args.steps:6.1f}  ms/step {t/args.steps:7.2f}  {f/t/1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res))

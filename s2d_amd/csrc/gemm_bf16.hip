@@ -370,6 +370,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
         __syncthreads();
     }
     const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
+    if (((p.N | p.ldc | p.ldr) & 3) == 0) {
+        // Vector epilogue: every wave parks its 64x64 tile in LDS (the operand ring is dead now) and streams it out
+        // row-wise, 16 B per lane: 4 rows x 256 B per wave instruction instead of 64 scalar stores per lane, with
+        // bias / scale read once and the residual read as float4.
+        __syncthreads();
+        float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 68;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] =
+                        accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+        const int c4 = lane & 15, rr = lane >> 4;
+        const int col = n0 + wn * 64 + c4 * 4;
+        if (col < p.N) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
+            if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            const int rbase = m0 + wm * 64 + rr;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = rbase + it * 4;
+                if (row >= p.M) break;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 4 + rr) * 68 + c4 * 4]);
+                v = v * sc + bi;
+                if (res) v += *reinterpret_cast<const f32x4 *>(res + (long)row * p.ldr + col);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int col = n0 + wn * 64 + tn * 32 + l32;
