@@ -309,14 +309,15 @@ __device__ __forceinline__ void stage_part(const float *__restrict__ map, int wm
 }
 
 // bilinear sample from the staged part; (y0 - r0, y0 + 1 - r0) are guaranteed inside the part for owned points
-__device__ __forceinline__ float sample_part(const float *__restrict__ sm, int hm, int wm, int r0, float x, float y, int x0, int y0)
+__device__ __forceinline__ float sample_part(const float *__restrict__ sm, int hm, int wm, int r0, int nr, float x, float y, int x0, int y0)
 {
     const int x1 = x0 + 1, y1 = y0 + 1;
     const float fx = x - x0, fy = y - y0;
     const float wxa = (x0 >= 0) ? 1.f - fx : 0.f, wxb = (x1 < wm) ? fx : 0.f;
     const float wya = (y0 >= 0) ? 1.f - fy : 0.f, wyb = (y1 < hm) ? fy : 0.f;
     const int xa = max(x0, 0), xb = min(x1, wm - 1);
-    const int ya = (max(y0, 0) - r0) * wm, yb = (min(y1, hm - 1) - r0) * wm;
+    // rows are clamped into the staged part, so points owned by another part still read valid LDS (result unused)
+    const int ya = min(max(y0 - r0, 0), nr - 1) * wm, yb = min(max(min(y1, hm - 1) - r0, 0), nr - 1) * wm;
     float acc = sm[ya + xa] * (wxa * wya);
     acc += sm[ya + xb] * (wxb * wya);
     acc += sm[yb + xa] * (wxa * wyb);
@@ -347,19 +348,33 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
         // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
-        for (int i = threadIdx.x; i < p.n_over; i += LTHREADS) {
-            float u, v;
-            if (cr) { v = cr[2 * i + 1]; } else { v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f); }
-            const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
-            const int y0 = (int)floorf(y);
-            if (y0 < ylo || y0 >= yhi) continue;
-            if (cr) { u = cr[2 * i]; } else { u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f); }
-            const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
-            const float xv = sample_part(sm, p.hm, p.wm, r0, x, y, (int)floorf(x), y0);
-            const unsigned int key = __float_as_uint(fabsf(xv));
-            if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
-            else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
-            else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+        // branch-free and 4-way unrolled: four independent hash -> tap -> key chains per thread hide the LDS latency
+        for (int i0 = threadIdx.x; i0 < p.n_over; i0 += 4 * LTHREADS) {
+            unsigned int key[4];
+            bool own[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * LTHREADS;
+                const int ic = min(i, p.n_over - 1);
+                float u, v;
+                if (cr) { u = cr[2 * ic]; v = cr[2 * ic + 1]; }
+                else {
+                    u = (float)(hash32(key0 + 2u * (uint32_t)ic) >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                }
+                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+                const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                const int y0 = (int)floorf(y);
+                own[j] = i < p.n_over && y0 >= ylo && y0 < yhi;
+                key[j] = __float_as_uint(fabsf(sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!own[j]) continue;
+                if (LEVEL == 0) atomicAdd(&h[key[j] >> 20], 1u);
+                else if (LEVEL == 1) { if ((key[j] >> 20) == (pre >> 20)) atomicAdd(&h[(key[j] >> 10) & 1023u], 1u); }
+                else { if ((key[j] >> 10) == (pre >> 10)) atomicAdd(&h[key[j] & 1023u], 1u); }
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < nb; i += LTHREADS)
@@ -440,22 +455,36 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
             const float *cr = coord_rows(p, rowid, over);
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
             const int cnt = over ? p.n_over : p.n_rand;
-            for (int i = threadIdx.x; i < cnt; i += LTHREADS) {
-                float u, v;
-                if (cr) { v = cr[2 * i + 1]; } else { v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f); }
-                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
-                const int y0 = (int)floorf(y);
-                if (y0 < ylo || y0 >= yhi) continue;
-                if (cr) { u = cr[2 * i]; } else { u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f); }
-                const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
-                const float xv = sample_part(sm, p.hm, p.wm, r0, x, y, (int)floorf(x), y0);
-                bool sel = true;
-                if (over) {
-                    const unsigned int key = __float_as_uint(fabsf(xv));
-                    sel = key < thr;
-                    if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+            for (int i0 = threadIdx.x; i0 < cnt; i0 += 4 * LTHREADS) {
+                float xv[4], uu[4], vv[4];
+                bool own[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * LTHREADS;
+                    const int ic = min(i, cnt - 1);
+                    float u, v;
+                    if (cr) { u = cr[2 * ic]; v = cr[2 * ic + 1]; }
+                    else {
+                        u = (float)(hash32(key0 + 2u * (uint32_t)ic) >> 8) * (1.0f / 16777216.0f);
+                        v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                    }
+                    const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+                    const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                    const int y0 = (int)floorf(y);
+                    own[j] = i < cnt && y0 >= ylo && y0 < yhi;
+                    xv[j] = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
+                    uu[j] = u; vv[j] = v;
                 }
-                if (sel) acc_point(xv, sample_plane(pl, p.H, p.W, u, v), bce, sgt, sg, ts);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool sel = own[j];
+                    if (over && sel) {
+                        const unsigned int key = __float_as_uint(fabsf(xv[j]));
+                        sel = key < thr;
+                        if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+                    }
+                    if (sel) acc_point(xv[j], sample_plane(pl, p.H, p.W, uu[j], vv[j]), bce, sgt, sg, ts);
+                }
             }
         }
         bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
