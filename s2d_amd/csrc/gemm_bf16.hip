@@ -425,6 +425,194 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// High-occupancy split-fp16 x3 variant: 128 x 64 x 32 tile, 4 waves of 64 x 32 (two f32 accumulator sets = 64
+// registers), single LDS buffer (27.6 KB operands, 36.9 KB with the epilogue staging).  ~4 workgroups = 16 waves per
+// CU: while one workgroup splits / stores / waits at its barriers, three others keep the matrix pipe busy (the
+// 128 x 128 kernel above is limited to 2 waves/SIMD by its 128 accumulator registers and leaves the pipe ~2/3 idle).
+template <bool CONV>
+__global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
+{
+    constexpr int BM = 128, BNs = 64, RPT = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *As = lds;                     // [BM][ROWW]
+    unsigned int *Bs = lds + BM * ROWW;         // [BNs][ROWW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int tiles_n = (p.N + BNs - 1) / BNs, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BNs;
+    const int bz = blockIdx.y;
+    const float *A = p.A + (long)bz * p.sA;
+    const float *B = p.B + (long)bz * p.sB;
+    float *C = p.C + (long)bz * p.sC;
+
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    constexpr unsigned int OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    unsigned int a_off[4], a_bad[4], b_off[2], b_bad[2];
+    int a_iy0[4], a_ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + RPT * i;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.Wout, t = mm / p.Wout, oy = t % p.Hout, n = t / p.Hout;
+            a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
+        } else {
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : 0u;
+            a_iy0[i] = a_ix0[i] = 0;
+        }
+        a_bad[i] = ok ? 0u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + r0 + RPT * i;
+        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : 0u;
+        b_bad[i] = n < p.N ? 0u : OOB;
+    }
+    f32x4 ra[4], rb[2];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + c4 * 4;
+        const unsigned int kmask = (unsigned int)((p.K - 1 - k) >> 31) & OOB;
+        int kh = 0, kw = 0, ci = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const unsigned int tmask = (unsigned int)(((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) >> 31)) & OOB;
+                off = (a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4)) | tmask | kmask;
+            } else {
+                off = (a_off[i] + (unsigned int)(k * 4)) | a_bad[i] | kmask;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsB, (int)((b_off[i] + (unsigned int)(k * 4)) | b_bad[i] | kmask), 0, 0));
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 hi, lo;
+            split4_f16(ra[i], hi, lo);
+            unsigned int *row = &As[(r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 hi, lo;
+            split4_f16(rb[i], hi, lo);
+            unsigned int *row = &Bs[(r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+    };
+    f32x16 accm[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accx[i][r] = 0.f; }
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();                                  // tile kt: registers -> (split) -> LDS
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);            // in flight during the MFMAs
+        const unsigned int *as = &As[(wm * 64 + l32) * ROWW + 4 * h];
+        const unsigned int *bs = &Bs[(wn * 32 + l32) * ROWW + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(bs + 8 * s);
+            const f16x8 bl = *reinterpret_cast<const f16x8 *>(bs + 16 + 8 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 8 * s);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 16 + 8 * s);
+                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i], 0, 0, 0);
+                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[i], 0, 0, 0);
+                accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                               // everyone done reading before the next store_tile
+    }
+    const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
+    if (((p.N | p.ldc | p.ldr) & 3) == 0) {
+        float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 36;     // 64 x 32 tile, row stride 36
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l32] = accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f);
+        const int c4e = lane & 7, rr = lane >> 3;                         // 8 lanes x 16 B = one 128-B row segment
+        const int col = n0 + wn * 32 + c4e * 4;
+        if (col < p.N) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
+            if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            const int rbase = m0 + wm * 64 + rr;
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + it * 8;
+                if (row >= p.M) break;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr) * 36 + c4e * 4]);
+                v = v * sc + bi;
+                if (res) v += *reinterpret_cast<const f32x4 *>(res + (long)row * p.ldr + col);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
+            }
+        }
+        return;
+    }
+    const int col = n0 + wn * 32 + l32;
+    if (col >= p.N) return;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= p.M) continue;
+            float v = (accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f)) * sc + bi;
+            if (res) v += res[(long)row * p.ldr + col];
+            if (p.relu) v = fmaxf(v, 0.f);
+            C[(long)row * p.ldc + col] = v;
+        }
+}
+
+template <bool CONV>
+int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * 4 * 64 * 36;   // 36.9 KB: epilogue staging >= operand tiles (27.6 KB)
+    const int nwg = cdiv(p.M, 128) * cdiv(p.N, 64);
+    hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV>), dim3(nwg, batch), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 template <bool CONV>
 int launch_f16(const GemmParams &p, int batch, hipStream_t st)
 {
@@ -470,7 +658,15 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets
     p.bytesA = (unsigned int)bA; p.bytesB = (unsigned int)bB;
     // 256-row tiles only when they still fill the chip
-    if (f16) return conv ? launch_f16<true>(p, batch, st) : launch_f16<false>(p, batch, st);
+    if (f16) {
+        // measured: the 16-waves/CU 128x64 kernel wins on the GEMMs / 1x1 convs (K <= 2048, epilogue- and
+        // latency-heavy), the 128x128 kernel (32 flop/B from L2) on the K >= 576 spatial convolutions
+        static int hi = -1;
+        if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }
+        const bool use_hi = hi == 2 ? !(conv && p.KH > 1) : hi == 1;
+        if (use_hi) return conv ? launch_f16_hi<true>(p, batch, st) : launch_f16_hi<false>(p, batch, st);
+        return conv ? launch_f16<true>(p, batch, st) : launch_f16<false>(p, batch, st);
+    }
     static int force = -1;
     if (force < 0) { const char *e = getenv("S2D_GEMM_WM"); force = e ? atoi(e) : 0; }
     bool big = (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= 256;
