@@ -231,6 +231,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
 {
+#ifdef S2D_EXP_NOSPLIT
+    hi[0] = __float_as_uint(v[0]); hi[1] = __float_as_uint(v[1]); lo[0] = __float_as_uint(v[2]); lo[1] = __float_as_uint(v[3]);
+    return;
+#endif
     const h16x2 ha = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), hb = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
     const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
     const f32x2 ra = (a - __builtin_convertvector(ha, f32x2)) * 2048.f, rb = (b - __builtin_convertvector(hb, f32x2)) * 2048.f;
