@@ -266,6 +266,156 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
     }
 }
 
+// N <= 32 targets: the two [Q x N] contractions on the f16 matrix cores with the split-fp16 x3 scheme of
+// gemm_bf16.hip (x = h + l*2^-11, main and cross accumulators): 12 MFMAs of 32 cycles per 32-sample batch instead of
+// 32 fp32-input MFMAs of 64 cycles, at fp32-class accuracy (~3*2^-22 relative).  |logit| < 65504 is required.
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, unsigned int &lo)
+{
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ha = (float)h[0], hb = (float)h[1];
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - ha) * 2048.f, (b - hb) * 2048.f);
+    hi = __builtin_bit_cast(unsigned int, h);
+    lo = __builtin_bit_cast(unsigned int, l);
+}
+
+__global__ __launch_bounds__(256) void matcher_cost_f16_kernel(CostParams p)
+{
+    constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
+    constexpr int TROW = 20;                               // words per target row: 16 data (32 fp16) + 4 pad
+    __shared__ __attribute__((aligned(16))) unsigned int Th[TN][TROW], Tl[TN][TROW];
+    __shared__ __attribute__((aligned(16))) int bqi[SB][4], bti[SB][4];      // per sample: 4 tap offsets / weights,
+    __shared__ __attribute__((aligned(16))) float bqw[SB][4], btw[SB][4];   // read back as one 16-B LDS load each
+    __shared__ float tpart[SLOTS][TN];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int pair = (bslot / CHM) * 8 + xcd, c = bslot % CHM;
+    if (pair >= p.NL * p.B * p.T) return;
+    const int prob = pair / p.T, t = pair % p.T;
+    const int b = prob % p.B;
+    const int N = min(p.tgt_count[b], p.Nmax);
+    if (N == 0 || N > 32) return;                           // N > 32: matcher_cost_kernel<4>
+    const int q = wv * 32 + l32;
+    const bool qok = q < p.Q;
+    const float *ml = p.ml + ((long)prob * p.T + t) * p.hm * p.wm * p.ldq + (qok ? q : 0);
+    const uint8_t *tg = p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W;
+    const long tplane = (long)p.T * p.H * p.W;
+    const float *cr = p.coords + (long)prob * p.P * 2;
+    const int tn = tid % TN, slot = tid / TN;
+
+    f32x16 aAm, aAx, aDm, aDx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aAm[r] = 0.f; aAx[r] = 0.f; aDm[r] = 0.f; aDx[r] = 0.f; }
+    float spsum = 0.f, sgsum = 0.f, tsum = 0.f;
+
+    for (int base = c * SB; base < p.P; base += CHM * SB) {
+        const int nvalid = min(SB, p.P - base);
+        __syncthreads();
+        if (tid < SB) {
+            float u = 0.f, v = 0.f;
+            if (tid < nvalid) { u = cr[2 * (base + tid)]; v = cr[2 * (base + tid) + 1]; }
+            const Bil a = bil_setup(u, v, p.hm, p.wm), d = bil_setup(u, v, p.H, p.W);
+            const bool tail = tid >= nvalid;
+            bqi[tid][0] = a.i00 < 0 ? 0 : a.i00 * p.ldq; bqi[tid][1] = a.i01 < 0 ? 0 : a.i01 * p.ldq;
+            bqi[tid][2] = a.i10 < 0 ? 0 : a.i10 * p.ldq; bqi[tid][3] = a.i11 < 0 ? 0 : a.i11 * p.ldq;
+            bqw[tid][0] = (a.i00 < 0 || tail) ? 0.f : a.w00; bqw[tid][1] = (a.i01 < 0 || tail) ? 0.f : a.w01;
+            bqw[tid][2] = (a.i10 < 0 || tail) ? 0.f : a.w10; bqw[tid][3] = (a.i11 < 0 || tail) ? 0.f : a.w11;
+            bti[tid][0] = max(d.i00, 0); bti[tid][1] = max(d.i01, 0); bti[tid][2] = max(d.i10, 0); bti[tid][3] = max(d.i11, 0);
+            btw[tid][0] = (d.i00 < 0 || tail) ? 0.f : d.w00; btw[tid][1] = (d.i01 < 0 || tail) ? 0.f : d.w01;
+            btw[tid][2] = (d.i10 < 0 || tail) ? 0.f : d.w10; btw[tid][3] = (d.i11 < 0 || tail) ? 0.f : d.w11;
+        }
+        __syncthreads();
+        // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and
+        // stores them as two fp16 pairs (hi / scaled lo) of row tn
+        {
+            const uint8_t *pl = tg + (long)(tn < N ? tn : 0) * tplane;
+            const float live = tn < N ? 1.f : 0.f;
+            float val[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int k = slot * SPT + j;
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[k]);
+                const f32x4 tw = *reinterpret_cast<const f32x4 *>(btw[k]);
+                const float v = (float)pl[ti[0]] * tw[0] + (float)pl[ti[1]] * tw[1] + (float)pl[ti[2]] * tw[2] + (float)pl[ti[3]] * tw[3];
+                val[j] = v * live;
+                tsum += val[j];
+            }
+            unsigned int h0, l0, h1, l1;
+            split_pair(val[0], val[1], h0, l0);
+            split_pair(val[2], val[3], h1, l1);
+            Th[tn][slot * 2] = h0; Th[tn][slot * 2 + 1] = h1;
+            Tl[tn][slot * 2] = l0; Tl[tn][slot * 2 + 1] = l1;
+        }
+        // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
+        unsigned int xh[2][4], xl[2][4], gh[2][4], gl[2][4];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                float xv[2], sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int k = 16 * st + 8 * h + 2 * jp + e;
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[k]);
+                    const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[k]);
+                    const float x = ((ml[qi[0]] * qw[0] + ml[qi[1]] * qw[1]) + ml[qi[2]] * qw[2]) + ml[qi[3]] * qw[3];
+                    const float liveq = (qok && k < nvalid) ? 1.f : 0.f;
+                    const float ex = __expf(-fabsf(x));
+                    const float inv = __builtin_amdgcn_rcpf(1.f + ex);
+                    const float sgm = (x >= 0.f ? inv : ex * inv) * liveq;
+                    spsum += (fmaxf(x, 0.f) + __logf(1.f + ex)) * liveq;
+                    sgsum += sgm;
+                    xv[e] = x * liveq; sv[e] = sgm;
+                }
+                split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
+                split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
+            }
+        __syncthreads();  // target tile complete
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[l32][8 * st + 4 * h]);
+            const f16x8 tl = *reinterpret_cast<const f16x8 *>(&Tl[l32][8 * st + 4 * h]);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 a0 = {xh[st][0], xh[st][1], xh[st][2], xh[st][3]}, a1 = {xl[st][0], xl[st][1], xl[st][2], xl[st][3]};
+            const u32x4 g0 = {gh[st][0], gh[st][1], gh[st][2], gh[st][3]}, g1 = {gl[st][0], gl[st][1], gl[st][2], gl[st][3]};
+            const f16x8 xhv = __builtin_bit_cast(f16x8, a0), xlv = __builtin_bit_cast(f16x8, a1);
+            const f16x8 ghv = __builtin_bit_cast(f16x8, g0), glv = __builtin_bit_cast(f16x8, g1);
+            aAx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlv, th, aAx, 0, 0, 0);
+            aAx = __builtin_amdgcn_mfma_f32_32x32x16_f16(xhv, tl, aAx, 0, 0, 0);
+            aAm = __builtin_amdgcn_mfma_f32_32x32x16_f16(xhv, th, aAm, 0, 0, 0);
+            aDx = __builtin_amdgcn_mfma_f32_32x32x16_f16(glv, th, aDx, 0, 0, 0);
+            aDx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, tl, aDx, 0, 0, 0);
+            aDm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, th, aDm, 0, 0, 0);
+        }
+    }
+    const long pc = (long)prob * p.chunks + (long)t * CHM + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        p.wsA[(pc * QP + qq) * NP + l32] = aAm[r] + aAx[r] * (1.0f / 2048.0f);
+        p.wsD[(pc * QP + qq) * NP + l32] = aDm[r] + aDx[r] * (1.0f / 2048.0f);
+    }
+    spsum += __shfl_xor(spsum, 32, 64);
+    sgsum += __shfl_xor(sgsum, 32, 64);
+    if (h == 0) {
+        p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
+        p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
+    }
+    tpart[slot][tn] = tsum;
+    __syncthreads();
+    if (tid < TN) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) sacc += tpart[k][tid];
+        p.wsV[(pc * 3 + 2) * 128 + tid] = sacc;
+    }
+}
+
 // C[prob][q][n] = w_mask*cost_mask + w_class*(-softmax(logits)[q][0]) + w_dice*cost_dice   (matcher.py:280-287)
 __global__ void matcher_finalize_kernel(CostParams p, const float *__restrict__ cls, float wc, float wm_, float wd,
                                         float *__restrict__ C)
@@ -458,7 +608,7 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     p.coords = raw2;
     const int npairs = nprob * T;
     const int grid = ((npairs + 7) / 8) * 8 * CHM;
-    hipLaunchKernelGGL(matcher_cost_kernel<1>, dim3(grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), 0, stream, p);
     if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
                        class_logits, w_class, w_mask, w_dice, C);
