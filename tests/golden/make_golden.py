@@ -482,17 +482,52 @@ def g_keymask():
          allc_same=pack(allc_same), matches_same=pack(matches_same), segmask_f2_o2=seg1)
 
 
-def g_visibility():
-    # identify_visibility_windows.py:108-231 needs JSON files on disk; K7 is host-side sklearn
-    # and is pinned by calling sklearn directly in the tests.  Nothing to generate.
-    pass
+def g_grouping():
+    """K7: identify_visibility_windows.py:108-231 and cotracker_matching.py:764-840 on synthetic curves / matches"""
+    import json, tempfile
+    iv = R.ref("identify_visibility_windows")
+    km = R.ref("cotracker_matching")
+    rng = synth.rng_for(95, 0)
+    T, n_obj = 24, 3
+    # per frame, n_obj masks; each mask's visibility curve = its object's occlusion schedule + noise
+    sched = [(2, 14), (8, 23), (0, 23)]
+    video_data, curves = [], []
+    for f in range(T):
+        data = []
+        for o in range(n_obj):
+            c = np.zeros(T, np.float32)
+            c[sched[o][0]:sched[o][1] + 1] = 1.0
+            c = np.clip(c * rng.uniform(0.6, 1.0, T) + rng.uniform(0, 0.15, T), 0, 1).astype(np.float32)
+            data.append({"object_id": o + 1, "visibility": c.tolist()})
+            curves.append(c)
+        video_data.append({"frame_id": f, "data": data})
+    with tempfile.TemporaryDirectory() as td:
+        out = iv.get_visibility_windows_for_video({"video_data": video_data}, "ds", "train", "vid", td, 0.3)
+    # match matrix: 3 groups of masks that matched each other + 2 unmatched rows
+    n = 30
+    grp = np.repeat(np.arange(3), 10)
+    mm = (grp[:, None] == grp[None, :]) & (rng.random((n, n)) > 0.08)
+    mm[7, :] = False; mm[19, :] = False
+    matches_data = []
+    lookup = [[{"frame_id": i // 3, "mask_id": i % 3 + 1, "overall_mask_id": i} for i in range(n)]]
+    for i in range(n):
+        matches_data.append({"cluster_id": 0, "overall_mask_id": i,
+                             "matches": [{"overall_mask_id": int(j)} for j in np.nonzero(mm[i])[0]]})
+    cids, vt = km.temporal_correspondance_clustering(matches_data, lookup, False)
+    lab = {}
+    for l, lst in vt[0]["overall_mask_ids_per_label"].items():
+        for e in lst:
+            lab[(e[0], e[1]) if isinstance(e, (tuple, list)) else str(e)] = l
+    save("grouping", curves=np.stack(curves), clusters_json=np.frombuffer(json.dumps(out["clusters"]).encode(), np.uint8),
+         match_matrix=mm.astype(np.float32), factor=vt[0]["visibility_to_temporal_factor"],
+         groups_json=np.frombuffer(json.dumps({str(k): v for k, v in vt[0]["overall_mask_ids_per_label"].items()}).encode(), np.uint8))
 
 
 def main():
     assert R.available(), "/root/reference not present: goldens can only be generated in the build container"
     R.install()
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask):
+               g_prepare_targets, g_keymask, g_grouping):
         print(fn.__name__)
         fn()
 
