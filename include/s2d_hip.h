@@ -166,7 +166,8 @@ int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, f
 int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, int T, int H, int W, int *nonempty,
                         hipStream_t stream);
 
-long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm);
+long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm, int num_points,
+                                    float oversample_ratio, float importance_ratio);
 
 /* loss_masks for NL layers at once (criterion.py:292-356, point_features.py:63-116): losses[layer][0] = loss_mask,
  * [1] = loss_dice, both already divided by num_masks = max(sum_b tgt_count[b] / world_size, 1) (:404-409).

@@ -172,6 +172,8 @@ struct LossParams {
     unsigned int *tie;        // [rows]
     float *part;              // [rows][chunks][4]
     int chunks;
+    float *xbuf;              // [xcap][n_over + n_rand]: sampled logits of the first xcap active rows (sampled ONCE)
+    int xcap;
 };
 
 // one block per layer: active flag + rank (= position among the kept rows of this layer, reference row order
@@ -288,11 +290,13 @@ __host__ __device__ inline PartGeom part_geom(int hm, int wm)
 // persistent item loop: item = (active row index li, part)
 struct PartIter {
     int w, n_items, nparts;
-    __device__ PartIter(const LossParams &p, int nparts_) : w(blockIdx.x), n_items(p.lcount[p.NL] * nparts_), nparts(nparts_) {}
-    __device__ bool next(const LossParams &p, long &rowid, int &part)
+    __device__ PartIter(const LossParams &p, int nparts_, int first_row = 0)
+        : w(blockIdx.x + first_row * nparts_), n_items(p.lcount[p.NL] * nparts_), nparts(nparts_) {}
+    __device__ bool next(const LossParams &p, long &rowid, int &part, int &li)
     {
         if (w >= n_items) return false;
-        rowid = p.list[w / nparts];
+        li = w / nparts;
+        rowid = p.list[li];
         part = w % nparts;
         w += gridDim.x;
         return true;
@@ -334,9 +338,9 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
     const PartGeom g = part_geom(p.hm, p.wm);
     unsigned int *h = reinterpret_cast<unsigned int *>(smem);
     float *sm = smem + 2048;
-    PartIter it(p, g.nparts);
-    long rowid; int part;
-    while (it.next(p, rowid, part)) {
+    PartIter it(p, g.nparts, LEVEL == 0 ? 0 : p.xcap);
+    long rowid; int part, li;
+    while (it.next(p, rowid, part, li)) {
         __syncthreads();
         for (int i = threadIdx.x; i < nb; i += LTHREADS) h[i] = 0u;
         const int r0 = part * g.rows_per_part;
@@ -366,7 +370,9 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
                 const int y0 = (int)floorf(y);
                 own[j] = i < p.n_over && y0 >= ylo && y0 < yhi;
-                key[j] = __float_as_uint(fabsf(sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0)));
+                const float xv = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
+                key[j] = __float_as_uint(fabsf(xv));
+                if (LEVEL == 0 && own[j] && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -376,10 +382,81 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 else { if ((key[j] >> 10) == (pre >> 10)) atomicAdd(&h[key[j] & 1023u], 1u); }
             }
         }
+        if (LEVEL == 0 && li < p.xcap) {
+            // the extra uniform points (point_features.py:112): sample their logits now too, so that the later passes
+            // of this row never touch the logit map again
+            const float *cr2 = coord_rows(p, rowid, false);
+            const uint32_t key1 = rand_key(p.seed, (uint64_t)rowid * 2 + 1);
+            for (int i = threadIdx.x; i < p.n_rand; i += LTHREADS) {
+                float u, v;
+                if (cr2) { u = cr2[2 * i]; v = cr2[2 * i + 1]; }
+                else {
+                    u = (float)(hash32(key1 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(hash32(key1 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                }
+                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+                const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                const int y0 = (int)floorf(y);
+                if (y0 >= ylo && y0 < yhi)
+                    p.xbuf[(long)li * (p.n_over + p.n_rand) + p.n_over + i] = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
+            }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < nb; i += LTHREADS)
             if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
     }
+}
+
+// levels 1 and 2 for the rows whose samples were kept: stream the stored logits (coalesced), no map, no RNG
+template <int LEVEL>
+__global__ __launch_bounds__(256) void hist_stream_kernel(LossParams p)
+{
+    __shared__ unsigned int h[1024];
+    constexpr int SCH = 8;                                       // chunks per row
+    const int nrows = min(p.lcount[p.NL], p.xcap);
+    for (int w = blockIdx.x; w < nrows * SCH; w += gridDim.x) {
+        const int li = w / SCH, chunk = w % SCH;
+        const long rowid = p.list[li];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0u;
+        __syncthreads();
+        const unsigned int pre = p.prefix[rowid];
+        const float *xb = p.xbuf + (long)li * (p.n_over + p.n_rand);
+        const int per = ((p.n_over + SCH - 1) / SCH + 3) & ~3;
+        const int i0 = chunk * per, i1 = min(p.n_over, i0 + per);
+        for (int i = i0 + threadIdx.x * 4; i < i1; i += 256 * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + i);          // n_over % 4 == 0 checked on the host
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i + j >= i1) break;
+                const unsigned int key = __float_as_uint(fabsf(v[j]));
+                if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
+                else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256)
+            if (h[i]) atomicAdd(&p.hist[rowid * 2048 + i], h[i]);
+    }
+}
+
+// bilinear sample of a bit-packed [H,W] plane held in LDS (bit = 1 -> 1.0f)
+__device__ __forceinline__ float sample_bits(const unsigned int *__restrict__ bits, int H, int W, float u, float v)
+{
+    const float gx = 2.f * u - 1.f, gy = 2.f * v - 1.f;
+    const float x = ((gx + 1.f) * W - 1.f) * 0.5f, y = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
+    const float fx = x - x0, fy = y - y0;
+    const float wxa = (x0 >= 0 && x0 < W) ? 1.f - fx : 0.f, wxb = (x1 >= 0 && x1 < W) ? fx : 0.f;
+    const float wya = (y0 >= 0 && y0 < H) ? 1.f - fy : 0.f, wyb = (y1 >= 0 && y1 < H) ? fy : 0.f;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1) * W, yb = min(max(y1, 0), H - 1) * W;
+    auto bit = [&](int idx) { return (float)((bits[idx >> 5] >> (idx & 31)) & 1u); };
+    float acc = bit(ya + xa) * (wxa * wya);
+    acc += bit(ya + xb) * (wxb * wya);
+    acc += bit(yb + xa) * (wxa * wyb);
+    acc += bit(yb + xb) * (wxb * wyb);
+    return acc;
 }
 
 // find the bin holding the krem-th smallest key; one block per row
@@ -431,9 +508,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
     const PartGeom g = part_geom(p.hm, p.wm);
     float *sm = smem;
     const int rows_l = p.B * p.maxm * p.T;
-    PartIter it(p, g.nparts);
-    long rowid; int part;
-    while (it.next(p, rowid, part)) {
+    PartIter it(p, g.nparts, p.xcap);
+    long rowid; int part, li;
+    while (it.next(p, rowid, part, li)) {
         __syncthreads();
         const int r0 = part * g.rows_per_part;
         const int nr = min(g.rows_per_part + 1, p.hm - r0);
@@ -497,6 +574,85 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
 #pragma unroll
             for (int w = 0; w < LTHREADS / 64; ++w) tot += red[w][j];
             p.part[(rowid * p.chunks + part) * 4 + j] = tot;
+        }
+    }
+}
+
+// accumulate for rows with stored samples: item = row.  The row's whole target plane is bit-packed into LDS
+// (H*W/8 bytes: 118 KB at 736x1280), the stored logits are streamed, only (u,v) is regenerated for the target taps.
+__global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int tbits[];
+    __shared__ float red[LTHREADS / 64][4];
+    const int rows_l = p.B * p.maxm * p.T;
+    const int nrows = min(p.lcount[p.NL], p.xcap);
+    const long HW = (long)p.H * p.W;
+    for (int li = blockIdx.x; li < nrows; li += gridDim.x) {
+        const long rowid = p.list[li];
+        const int layer = (int)(rowid / rows_l);
+        const int r = (int)(rowid % rows_l);
+        const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
+        const int prob = layer * p.B + b;
+        const int n = p.idx_t[(long)prob * p.maxm + s];
+        const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * HW;
+        __syncthreads();
+        // bit-pack the plane: each thread turns 32 bytes (two 16-B loads) into one word
+        for (long wd = threadIdx.x; wd < HW / 32; wd += LTHREADS) {
+            const uint4 a = reinterpret_cast<const uint4 *>(pl)[wd * 2], c = reinterpret_cast<const uint4 *>(pl)[wd * 2 + 1];
+            const unsigned int ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            unsigned int out = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned int w4 = ws[k];
+                out |= ((w4 & 0xFFu) ? 1u : 0u) << (4 * k);
+                out |= ((w4 & 0xFF00u) ? 1u : 0u) << (4 * k + 1);
+                out |= ((w4 & 0xFF0000u) ? 1u : 0u) << (4 * k + 2);
+                out |= ((w4 & 0xFF000000u) ? 1u : 0u) << (4 * k + 3);
+            }
+            tbits[wd] = out;
+        }
+        __syncthreads();
+        const unsigned int thr = p.prefix[rowid];
+        const unsigned int take = (unsigned int)p.krem[rowid];
+        const float *xb = p.xbuf + (long)li * (p.n_over + p.n_rand);
+        float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool over = pass == 0;
+            const float *cr = coord_rows(p, rowid, over);
+            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
+            const int cnt = over ? p.n_over : p.n_rand;
+            const float *xs = xb + (over ? 0 : p.n_over);
+            for (int i = threadIdx.x; i < cnt; i += LTHREADS) {
+                const float xv = xs[i];
+                bool sel = true;
+                if (over) {
+                    const unsigned int key = __float_as_uint(fabsf(xv));
+                    sel = key < thr;
+                    if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+                }
+                if (!sel) continue;
+                float u, v;
+                if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
+                else {
+                    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                }
+                acc_point(xv, sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+            }
+        }
+        bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int j = threadIdx.x;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < LTHREADS / 64; ++w) tot += red[w][j];
+            p.part[(rowid * p.chunks + 0) * 4 + j] = tot;
+#pragma unroll 1
+            for (int c = 1; c < p.chunks; ++c) p.part[(rowid * p.chunks + c) * 4 + j] = 0.f;
         }
     }
 }
@@ -589,11 +745,25 @@ int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, i
 
 static const int LOSS_CHUNKS = 8;   // >= number of map parts per row (partial-sum slots)
 
-long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm)
+static const long XBUF_MAX_ROWS = 4096;   // rows whose sampled logits are kept (8.5 GB at P = 160000); the rest recompute
+
+static void point_counts(int num_points, float oversample_ratio, float importance_ratio, int &n_over, int &n_unc, int &n_rand)
+{
+    n_over = (int)(num_points * oversample_ratio);                 // point_features.py:89
+    n_unc = (int)(importance_ratio * num_points);                  // :99
+    n_rand = num_points - n_unc;                                   // :100
+}
+
+long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm, int num_points,
+                                    float oversample_ratio, float importance_ratio)
 {
     const long maxm = Q < Nmax ? Q : Nmax;
     const long rows = (long)NL * B * maxm * T;
-    return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 4L * (NL + 1) + 512;
+    int n_over, n_unc, n_rand;
+    point_counts(num_points, oversample_ratio, importance_ratio, n_over, n_unc, n_rand);
+    const long xrows = rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS;
+    return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 4L * (NL + 1) + 1024 +
+           xrows * (long)(n_over + n_rand + 8) * 4;
 }
 
 int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
@@ -608,9 +778,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     p.idx_q = idx_q; p.idx_t = idx_t; p.n_match = n_match; p.coords_over = coords_over; p.coords_rand = coords_rand;
     p.seed = seed; p.NL = NL; p.B = B; p.Q = Q; p.ldq = ldq; p.T = T; p.hm = hm; p.wm = wm; p.H = H; p.W = W; p.Nmax = Nmax;
     p.maxm = Q < Nmax ? Q : Nmax;
-    p.n_over = (int)(num_points * oversample_ratio);                 // point_features.py:89
-    p.n_unc = (int)(importance_ratio * num_points);                  // :99
-    p.n_rand = num_points - p.n_unc;                                 // :100
+    point_counts(num_points, oversample_ratio, importance_ratio, p.n_over, p.n_unc, p.n_rand);
     p.drop = drop_empty; p.world_size = world_size; p.chunks = LOSS_CHUNKS;
     const long rows = (long)NL * B * p.maxm * T;
     if (rows == 0) return S2D_OK;
@@ -625,7 +793,12 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.hist = (unsigned int *)w; w += rows * 2048 * 4;
     p.part = (float *)w; w += rows * LOSS_CHUNKS * 16;
-    p.mq = (float *)w;
+    p.mq = (float *)w; w += rows * (long)hm * wm * 4;
+    w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    p.xbuf = (float *)w;
+    // samples are kept only when the target plane fits LDS as bits and vector loads line up
+    const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 150 * 1024);
+    p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
     if (hipMemsetAsync(p.hist, 0, (size_t)rows * 2048 * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
     if (hipMemsetAsync(p.tie, 0, (size_t)rows * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
@@ -642,18 +815,22 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
     const dim3 g(512);      // persistent: 2 blocks per CU's worth of items in flight
     hipLaunchKernelGGL(hist_kernel<0>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<0>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(hist_kernel<1>, g, dim3(LTHREADS), lds_hist, stream, p);
+    if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<1>, dim3(2048), dim3(256), 0, stream, p);
+    if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<1>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<1>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
+    if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<2>, dim3(2048), dim3(256), 0, stream, p);
+    if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
+    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p);
+    if (rows > p.xcap) hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
     S2D_CHECK_LAUNCH();
     return S2D_OK;

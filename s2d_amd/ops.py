@@ -271,7 +271,7 @@ def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dim
     NL, B = mask_logits.shape[:2]
     Q, T, hm, wm = dims
     Nmax, H, W = tgt.shape[1], tgt.shape[3], tgt.shape[4]
-    nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm)
+    nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm, int(P), float(oversample), float(importance))
     ws = torch.empty((nbytes,), device=tgt.device, dtype=torch.uint8)
     losses = torch.zeros((NL, 2), device=tgt.device, dtype=torch.float32)
     lib().call("s2d_point_loss_f32", mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand,
