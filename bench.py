@@ -189,20 +189,32 @@ def main():
             n = len(prof)
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dense]
+            # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (profiles/r1_pmc_traffic.json, fetch corrected x2 as MI355X_MICROARCH.md prescribes); null if absent
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+            if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
+                traffic = json.load(open(tp))["per_kernel_family"]["gemm"]["per_launch_bytes_corrected"]
             passes = 1 if args.dense == "f32" else 3
             res["roofline"] = {"bound": "mfma", "kernel": "dense NT GEMM / implicit-GEMM conv: " + DENSE_DESC[args.dense],
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None,
+                               "frac": round(ach / peak, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": int(sum(t[-1] for *_, t in prof) / n),
                                "mfma_flops_per_algorithmic_flop": passes, "mfma_pipe_frac": round(passes * ach / peak, 4),
                                "achieved_vs_fp32_mfma_peak_157.3": round(ach / 157.3, 4),
                                "launches_per_step": n // args.steps, "avg_launch_us": round(1000 * ms / n, 2),
                                "kernel_ms_per_step": round(ms / args.steps, 2),
                                "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1)}
+        # the north star states its target against the whole-step HBM roofline: 19.0 GB algorithmic per clip-frame
+        #  at 8 TB/s
+        if args.config == "c4":
+            res["hbm_roofline"] = {"algorithmic_GB_per_frame": 19.0, "peak_TBps": 8.0,
+                                   "frac": round(res["value"] * 19.0 / 8000.0, 4), "target_frac": 0.4}
         if prof and args.dense_breakdown:
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
             for s_, e_, f_, tag in prof:
-                a = agg[tag]; a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
+                a = agg[tag[:5]]; a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
             for tag, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
                 print(f"{str(tag):44s} calls/step {n/args.steps:6.1f}  ms/step {t/args.steps:7.2f}  {f/t/1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:

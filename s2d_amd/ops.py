@@ -61,7 +61,7 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
     sA = M * K if batched else 0
     sB = N * K if B.dim() == 3 else 0
     sC = M * ldc
-    with _Timed(2.0 * bs * M * N * K, ("gemm", bs, M, N, K)):
+    with _Timed(2.0 * bs * M * N * K, ("gemm", bs, M, N, K, 4.0 * bs * (M * K + N * K * (1 if B.dim() == 3 else 1.0 / bs) + M * N * (2 if res is not None else 1)))):
         lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, N,
                    M * N if res is not None and res.dim() == 3 else 0, int(relu), _stream())
     return out
@@ -76,7 +76,8 @@ def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=Fal
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * (3 if Cin == 4 else Cin), ("conv", KH, N * Ho * Wo, Cout, KH * KW * Cin)):   # stem: algorithmic Cin is 3
+    with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * (3 if Cin == 4 else Cin),
+                ("conv", KH, N * Ho * Wo, Cout, KH * KW * Cin, 4.0 * (x.numel() + w.numel() + N * Ho * Wo * Cout * (2 if res is not None else 1)))):   # stem: algorithmic Cin is 3
         lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu),
                    _stream())
     return y
