@@ -30,20 +30,25 @@ extern "C" {
 
 int s2d_abi_version(void);
 
-/* Arithmetic of the dense contractions below (process-wide): 1 (default) = split-bf16 x3 on the bf16 MFMA
- * (A.B^T ~= Ah.Bh^T + Ah.Bl^T + Al.Bh^T with f32 accumulation: fp32-class accuracy, ~1e-5 relative);
- * 0 = fp32-input MFMA (an exact f32 FMA chain, 1/16 of the bf16 rate). */
+/* Arithmetic of the dense contractions below (process-wide), all fp32 in / fp32 out:
+ * 2 (default) = split-fp16 x3 on the f16 MFMA (x = h + l*2^-11; A.B^T ~= Ah.Bh^T + 2^-11 (Ah.Bl^T + Al.Bh^T), f32
+ *     accumulation: ~5e-7 relative; operands must satisfy |x| < 65504);
+ * 1 = split-bf16 x3 on the bf16 MFMA (~5e-6 relative, no range limit);
+ * 0 = fp32-input MFMA (an exact f32 FMA chain, 1/16 of the 16-bit rate). */
 int s2d_set_dense_mode(int mode);
 
 /* ---- dense contractions (fp32-input MFMA) ------------------------------------------------------ */
 
 /* C[b][M,N] = act((A[b][M,K] * B[b][N,K]^T) * scale[N] + bias[N] + res[b][M,N]); scale/bias/res may be NULL.
+ * res_rows > 0: the residual is row-periodic, res[b][row % res_rows, :] (a per-position term shared by all frames, e.g.
+ * pos . W^T of "(src + pos) . W^T", ms_deform_attn.py:107-108 via msdeformattn.py:68); res_cols > 0: only columns
+ * < res_cols receive the residual (multiple of 4).
  * Replaces every nn.Linear / 1x1 Conv2d on the path (e.g. ms_deform_attn.py:98-104,124; msdeformattn.py:122-131;
  * video_mask2former_transformer_decoder.py:99-111,164-168,193-205) and the mask-logit einsum
  * "bqc,btchw->bqthw" (video_mask2former_transformer_decoder.py:455).  K, lda, ldb multiples of 4. */
 int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                     int batch, long strideA, long strideB, long strideC, const float *scale, const float *bias,
-                    const float *res, long ldr, long strideR, int relu, hipStream_t stream);
+                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, hipStream_t stream);
 
 /* NHWC convolution as implicit GEMM: x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
  * y [N,Ho,Wo,Cout] = act(conv(x,w) * scale[Cout] + bias[Cout] + res).  Replaces detectron2 Conv2d+FrozenBN+ReLU
@@ -75,7 +80,7 @@ int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const 
  * (ops/modules/ms_deform_attn.py:101-109) with the query's own pixel centre as reference point
  * (msdeformattn.py:141-153).  offs_logits [N,S,ldoa]: per query M*L*P*2 raw offsets then M*L*P raw logits.
  * Requires D == 32, L*P == 12 (the shipped geometry, msdeformattn.py:232-239). */
-int s2d_msda_fused_forward_f32(const float *value, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
                                int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream);
 
 /* ---- bandwidth-bound glue (HBM-bound, 16-B accesses) ----------------------------------------------- */

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p)
                 const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= p.M) continue;
                 float v = acc[tm][tn][r] * sc + bi;
-                if (res) v += res[(long)row * p.ldr + col];
+                if (res && col < p.res_cols) v += res[(long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col];
                 if (p.relu) v = fmaxf(v, 0.f);
                 C[(long)row * p.ldc + col] = v;
             }
@@ -190,12 +190,14 @@ extern "C" {
 // C[b][M,N] = act( (A[b][M,K] * B[b][N,K]^T) * scale[N] + bias[N] + res[b][M,N] )
 int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                     int batch, long strideA, long strideB, long strideC, const float *scale, const float *bias,
-                    const float *res, long ldr, long strideR, int relu, hipStream_t stream)
+                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, hipStream_t stream)
 {
+    if (res_rows < 0 || res_cols < 0 || res_cols > N) return S2D_ERR_ARG;
     GemmParams p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = strideA; p.sB = strideB; p.sC = strideC;
     p.scale = scale; p.bias = bias; p.res = res; p.ldr = ldr; p.sR = strideR; p.relu = relu;
+    p.res_rows = res_rows; p.res_cols = res_cols > 0 ? res_cols : N;
     return launch(p, false, batch, stream);
 }
 
@@ -213,13 +215,13 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
     p.A = x; p.B = w; p.C = y;
     p.M = N * p.Hout * p.Wout; p.N = Cout; p.K = KH * KW * Cin;
     p.lda = 4; p.ldb = p.K; p.ldc = Cout;
-    p.scale = scale; p.bias = bias; p.res = res; p.ldr = Cout; p.relu = relu;
+    p.scale = scale; p.bias = bias; p.res = res; p.ldr = Cout; p.relu = relu; p.res_cols = Cout;
     return launch(p, true, 1, stream);
 }
 
 }  // extern "C"
 
-extern "C" int s2d_abi_version(void) { return 1; }
+extern "C" int s2d_abi_version(void) { return 2; }
 
 extern "C" int s2d_set_dense_mode(int mode)
 {

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
                 const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= p.M) continue;
                 float v = acc[tm][tn][r] * sc + bi;
-                if (res) v += res[(long)row * p.ldr + col];
+                if (res && col < p.res_cols) v += res[(long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col];
                 if (p.relu) v = fmaxf(v, 0.f);
                 C[(long)row * p.ldc + col] = v;
             }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
         __syncthreads();
     }
     const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
-    if (((p.N | p.ldc | p.ldr) & 3) == 0) {
+    if (((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0) {
         // Vector epilogue: every wave parks its 64x64 tile in LDS (the operand ring is dead now) and streams it out
         // row-wise, 16 B per lane: 4 rows x 256 B per wave instruction instead of 64 scalar stores per lane, with
         // bias / scale read once and the residual read as float4.
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                 if (row >= p.M) break;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 4 + rr) * 68 + c4 * 4]);
                 v = v * sc + bi;
-                if (res) v += *reinterpret_cast<const f32x4 *>(res + (long)row * p.ldr + col);
+                if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                 const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= p.M) continue;
                 float v = (accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f)) * sc + bi;
-                if (res) v += res[(long)row * p.ldr + col];
+                if (res && col < p.res_cols) v += res[(long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col];
                 if (p.relu) v = fmaxf(v, 0.f);
                 C[(long)row * p.ldc + col] = v;
             }
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
         __syncthreads();                               // everyone done reading before the next store_tile
     }
     const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
-    if (((p.N | p.ldc | p.ldr) & 3) == 0) {
+    if (((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0) {
         float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 36;     // 64 x 32 tile, row stride 36
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
                 if (row >= p.M) break;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr) * 36 + c4e * 4]);
                 v = v * sc + bi;
-                if (res) v += *reinterpret_cast<const f32x4 *>(res + (long)row * p.ldr + col);
+                if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
             const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row >= p.M) continue;
             float v = (accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f)) * sc + bi;
-            if (res) v += res[(long)row * p.ldr + col];
+            if (res && col < p.res_cols) v += res[(long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col];
             if (p.relu) v = fmaxf(v, 0.f);
             C[(long)row * p.ldc + col] = v;
         }

@@ -10,6 +10,7 @@ struct GemmParams {
     long sA, sB, sC;  // batch strides (elements)
     const float *scale, *bias, *res;
     long ldr, sR;
+    int res_rows, res_cols;   // residual row = row % res_rows (0: row); columns >= res_cols get no residual
     int relu;
     // implicit-GEMM convolution (A = NHWC input)
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // ratios == 1).  `oa` [N,S,ldoa] holds, per query, the raw sampling offsets [M][L][P][2] followed by the raw
 // attention logits [M][L*P] (one GEMM output).  Softmax over L*P and loc = ref + off/(W_l,H_l) happen here.
 template <int LP_>
-__global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, Levels lv,
+__global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
                                                          int P, int blk_per_n, float *__restrict__ out)
 {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
     const float inv = 1.f / den;
-    const long rowstride = (long)M * D;
+    const long rowstride = ldv;
     f32x4 acc = f32x4(0.f);
 #pragma unroll
     for (int i = 0; i < LP_; ++i) {
@@ -250,16 +250,16 @@ int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const i
     return S2D_OK;
 }
 
-int s2d_msda_fused_forward_f32(const float *value, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
                                int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream)
 {
     Levels lv;
     if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
-    if (D != 32 || L * P != 12 || ldoa < M * L * P * 3) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
+    if (D != 32 || L * P != 12 || ldoa < M * L * P * 3 || ldv < M * D || (ldv & 3)) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
     if (N <= 0) return S2D_OK;
     const long items = (long)S * M * 8;
     const int nb = cdiv(items, 256);
-    hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, lv, offs_logits, ldoa, S, M, L,
+    hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L,
                        P, nb, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;

@@ -101,6 +101,8 @@ class KDVideoMaskFormer(nn.Module):
         self.num_predictions_distillation = num_predictions_distillation
         self.score_threshold_distillation = score_threshold_distillation
         self.accum_iter, self.eval_student = accum_iter, eval_student
+        self.overlap_criteria = True                      # GT criterion on the second stream beside the KD criterion
+        self.overlap_teacher, self._side = True, None     # teacher forward on a second HIP stream (forward_losses)
 
     @classmethod
     def from_config(cls, cfg):  # kd_video_maskformer_model.py:130-231
@@ -141,14 +143,35 @@ class KDVideoMaskFormer(nn.Module):
     @torch.no_grad()
     def forward_losses(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None):
         """the device-side hot path from normalised frames to the weighted loss dict (no host sync)"""
-        student = self.student(images, True)
-        teacher = self.teacher(images, True)
-        losses = self.criterion(student, gt_targets, False, coords_gt)
         Hp, Wp = images.shape[1:3]
         kd_nmax = kd_nmax or min(self.num_predictions_distillation, self.num_queries)
-        tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
-                                            self.score_threshold_distillation, self.num_predictions_distillation)
-        kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd)
+        # The teacher forward (+ its pseudo-target selection) is independent of the student forward and the GT
+        # criterion: it runs on a second HIP stream so the launch tails and the small decoder kernels of one network
+        # fill the CUs the other leaves idle.  Every kernel is deterministic, so the schedule does not change results.
+        main = torch.cuda.current_stream()
+        if self.overlap_teacher:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=images.device)
+            side = self._side
+            side.wait_stream(main)        # images are ready; all earlier main-stream readers of side-pool memory are done
+        else:
+            side = main
+        with torch.cuda.stream(side):
+            teacher = self.teacher(images, True)
+            tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                                self.score_threshold_distillation, self.num_predictions_distillation)
+        student = self.student(images, True)
+        if self.overlap_teacher and self.overlap_criteria:
+            side.wait_stream(main)        # student outputs ready
+            main.wait_stream(side)        # pseudo targets ready
+            with torch.cuda.stream(side):
+                losses = self.criterion(student, gt_targets, False, coords_gt)
+            kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd)
+            main.wait_stream(side)
+        else:
+            losses = self.criterion(student, gt_targets, False, coords_gt)
+            main.wait_stream(side)
+            kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd)
         for k, v in kd.items():
             losses[k.replace("loss_", "kd_loss_")] = v
         wd = self.criterion.weight_dict                                   # :319-325

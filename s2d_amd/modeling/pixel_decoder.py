@@ -47,22 +47,30 @@ class MSDeformAttn(nn.Module):
         nn.init.constant_(self.output_proj.bias.data, 0.)
 
     def packed(self):
-        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight, self.attention_weights.bias)
+        """[sampling_offsets | attention_weights | value_proj] as one [288 + C, C] weight (one pass over src), with
+        bias [0 | b_value]: the offsets/logits bias travels in the row-periodic pos term of forward_fused."""
+        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight, self.attention_weights.bias,
+              self.value_proj.weight, self.value_proj.bias)
         key = tuple(p._version for p in ps) + (ps[0].device,)
         if self._packed is None or self._packed[0] != key:
-            w = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
-            b = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
-            self._packed = (key, w, b)
+            w_oa = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
+            b_oa = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
+            w_all = torch.cat([w_oa, ps[4].detach()], 0).contiguous()
+            b_all = torch.cat([torch.zeros_like(b_oa), ps[5].detach()], 0).contiguous()
+            self._packed = (key, w_all, b_all, w_oa, b_oa)
         return self._packed[1:]
 
-    def forward_fused(self, query, src, shapes, res):
-        """self-attention over the flattened pyramid (query positions == value positions).  Returns
-        output_proj(msda(...)) + res."""
+    def forward_fused(self, src, pos, shapes, res):
+        """self-attention over the flattened pyramid with query = src + pos (query positions == value positions;
+        pos [S, C] is shared by all N frames).  Returns output_proj(msda(...)) + res.
+        (src + pos) . W_oa^T = src . W_oa^T + pos . W_oa^T: the second term is one small [S, 288] product per layer and
+        enters the merged projection as a row-periodic residual, so src is read once and src + pos is never stored."""
         N, S, C = src.shape
-        w_oa, b_oa = self.packed()
-        oa = ops.gemm_nt(query.view(-1, C), w_oa, bias=b_oa).view(N, S, -1)
-        value = ops.gemm_nt(src.view(-1, C), self.value_proj.weight, bias=self.value_proj.bias).view(N, S, C)
-        samp = ops.msda_fused_forward(value, shapes, oa, self.n_heads, self.n_points)
+        w_all, b_all, w_oa, b_oa = self.packed()
+        n_oa = w_oa.shape[0]
+        pos_oa = ops.gemm_nt(pos.view(S, C), w_oa, bias=b_oa)
+        both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa).view(N, S, n_oa + C)
+        samp = ops.msda_fused_forward(both[..., n_oa:], shapes, both[..., :n_oa], self.n_heads, self.n_points)
         out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C))
         return out.view(N, S, C)
 
@@ -103,8 +111,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             raise NotImplementedError("dropout > 0 (training noise) is not on the measured fwd+loss parity path; "
                                       "set MODEL.MASK_FORMER.DROPOUT 0.0 (SURVEY.md Appendix C)")
         N, S, C = src.shape
-        q = ops.add_bcast(src, pos)
-        x = self.self_attn.forward_fused(q, src, shapes, res=src)
+        x = self.self_attn.forward_fused(src, pos, shapes, res=src)
         src = ops.layernorm(x, self.norm1.weight, self.norm1.bias)
         h = ops.gemm_nt(src.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
         x = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=src.view(-1, C)).view(N, S, C)

@@ -44,9 +44,10 @@ def set_dense_mode(mode):
     lib().call("s2d_set_dense_mode", {"f32": 0, "bf16x3": 1, "f16x3": 2}[mode])
 
 
-def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
+def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0):
     """out[..., M, N] = act(A[..., M, K] @ B[(...), N, K]^T * scale + bias + res).
-    A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch)."""
+    A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch).  res_rows > 0: res is [res_rows, ldr] and row r of the
+    output receives res[r % res_rows]; res_cols > 0: only the first res_cols columns receive it (ldr = res.shape[-1])."""
     for t in (A, B, scale, bias, res, out):
         _chk(t)
     batched = A.dim() == 3
@@ -62,8 +63,10 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None):
     sB = N * K if B.dim() == 3 else 0
     sC = M * ldc
     with _Timed(2.0 * bs * M * N * K, ("gemm", bs, M, N, K, 4.0 * bs * (M * K + N * K * (1 if B.dim() == 3 else 1.0 / bs) + M * N * (2 if res is not None else 1)))):
-        lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, N,
-                   M * N if res is not None and res.dim() == 3 else 0, int(relu), _stream())
+        ldr = res.shape[-1] if res is not None else N
+        assert res is None or (ldr >= (res_cols or N) and res.shape[-2] == (res_rows or M))
+        lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, ldr,
+                   res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), _stream())
     return out
 
 
@@ -117,14 +120,17 @@ def msda_backward(value, shapes, level_start, loc, attn_w, grad_out):
 
 
 def msda_fused_forward(value, shapes, offs_logits, M=8, P=4):
-    """value [N,S,M*D]; offs_logits [N,S,>=M*L*P*3] -> [N,S,M*D]."""
-    _chk(value); _chk(offs_logits)
+    """value [N,S,M*D]; offs_logits [N,S,>=M*L*P*3] -> [N,S,M*D].  Both may be column slices of one wider row-major
+    buffer (row strides ldv / ldoa): the merged [offsets|logits|value] projection writes them side by side."""
     N, S, C = value.shape
+    for t in (value, offs_logits):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(0) != S * t.stride(1) or t.storage_offset() % 4:
+            raise RuntimeError("msda_fused_forward needs f32 CUDA tensors with unit column stride and dense rows")
     sh = _host_i64(shapes)
     L = sh.shape[0]
     out = torch.empty((N, S, C), device=value.device, dtype=torch.float32)
-    lib().call("s2d_msda_fused_forward_f32", value, sh, offs_logits, offs_logits.shape[-1], N, S, M, C // M, L, P, out,
-               _stream())
+    lib().call("s2d_msda_fused_forward_f32", value, value.stride(1), sh, offs_logits, offs_logits.stride(1), N, S, M, C // M, L, P,
+               out, _stream())
     return out
 
 

@@ -38,6 +38,22 @@ def test_gemm_nt(oracle, M, N, K, batch):
     np.testing.assert_allclose(out2, ref2, rtol=1e-4, atol=1e-4 * np.abs(ref2).max())
 
 
+@pytest.mark.parametrize("frames,S,N,K,rc", [(3, 70, 544, 256, 288), (2, 333, 288, 64, 0), (4, 129, 100, 256, 0)])
+def test_gemm_row_periodic_residual(oracle, frames, S, N, K, rc):
+    """res[row % S] on the first rc columns only: the pos . W^T term of the merged MSDeformAttn projection"""
+    from s2d_amd import ops
+    M = frames * S
+    A = synth.randn(2, 1, (M, K))
+    B = synth.randn(2, 2, (N, K))
+    bi = synth.randn(2, 3, (N,))
+    ldr = rc or N
+    res = synth.randn(2, 4, (S, ldr))
+    ref = np.einsum("mk,nk->mn", A.astype(np.float64), B.astype(np.float64)) + bi
+    ref[:, :ldr] += np.tile(res, (frames, 1))
+    out = ops.gemm_nt(_dev(A), _dev(B), bias=_dev(bi), res=_dev(res), res_rows=S, res_cols=rc).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(2, 16, 24, 64, 64, 3, 1, 1), (1, 33, 47, 4, 64, 7, 2, 3),
                                                    (2, 16, 24, 256, 128, 1, 2, 0), (1, 20, 20, 128, 128, 3, 2, 1),
                                                    (1, 8, 12, 512, 2048, 1, 1, 0)])

@@ -59,6 +59,10 @@ def test_msda_fused_vs_oracle_720p_shapes(oracle):
                            loc.astype(np.float32), aw.astype(np.float32))
     out = ops.msda_fused_forward(_dev(value), np.array(shapes), _dev(oa)).cpu().numpy()
     close(out, ref, 1e-5)
+    # value / offsets+logits as column slices of one [N,S,288+256] buffer (the merged projection's output)
+    both = _dev(np.concatenate([oa, value], -1))
+    out1 = ops.msda_fused_forward(both[..., oa.shape[-1]:], np.array(shapes), both[..., :oa.shape[-1]]).cpu().numpy()
+    assert np.array_equal(out1, out)
     # and the drop-in form on the same data
     out2 = ops.msda_forward(_dev(value.reshape(N, S, M, D)), np.array(shapes), oracle.level_start_index(shapes),
                             _dev(loc.astype(np.float32)), _dev(aw.astype(np.float32))).cpu().numpy()
