@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the teacher forward on the main stream (default: second HIP stream)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="experimental: teacher forward + GT criterion on a second HIP stream (faster, but not bitwise "
+                         "reproducible on this stack: see DESIGN.md section 6); default is one stream")
     ap.add_argument("--dense-breakdown", action="store_true", help="print per-shape time of the dense launches to stderr")
     ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
@@ -140,7 +142,7 @@ def main():
     B, T, H0, W0, Q, P, N = CONFIGS[args.config]
     model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
     model.train()
-    model.overlap_teacher = not args.no_overlap
+    model.overlap_teacher = model.overlap_criteria = args.overlap
     frames, masks = synth_batch(rank, B, T, H0, W0, N, dev)
     gt = TargetSet.from_list(masks, device=dev)
     calibrate_teacher(model, ops.normalize_pad(frames))
@@ -160,7 +162,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    live_events = not args.no_kernel_events and args.no_overlap
+    live_events = not args.no_kernel_events and not args.overlap
     if live_events:
         ops.PROFILE = []
     t0 = time.perf_counter()
@@ -174,14 +176,14 @@ def main():
         # In the timed region the two networks' launches share the GPU on two streams, so an event pair around one launch
         # brackets other kernels' work too.  The per-launch durations for the roofline come from one extra step, after
         # the timed region, with everything on one stream (the same launches, isolated); --no-overlap times them live.
-        model.overlap_teacher = False
+        model.overlap_teacher = model.overlap_criteria = False
         ops.PROFILE = []
         step()
         fence()
         prof, ops.PROFILE = ops.PROFILE, None
-        model.overlap_teacher = True
+        model.overlap_teacher = model.overlap_criteria = True
         events_note = ("HIP events around every dense launch of one extra single-stream step after the timed region "
-                       "(the timed region overlaps the two networks on two HIP streams; bench.py --no-overlap times them live)")
+                       "(--overlap: the timed region runs the two networks on two HIP streams)")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -198,7 +200,7 @@ def main():
                "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
                                       f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
-                          "streams": 1 if args.no_overlap else 2,
+                          "streams": 2 if args.overlap else 1,
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)

@@ -97,7 +97,9 @@ int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float 
 
 /* y = GroupNorm_G(x)*gamma+beta [+ bilinear_resize(up [N,hu,wu,C] -> (H,W), align_corners=False)] [relu]; x NHWC.
  * nn.GroupNorm(32,256) at msdeformattn.py:213-226 and detectron2 get_norm("GN") at :261-281; the fused
- * upsample-add is msdeformattn.py:349.  stats_ws: 2*N*G doubles of workspace. */
+ * upsample-add is msdeformattn.py:349.  stats_ws: s2d_groupnorm_workspace_doubles(N,H,W,G) doubles (statistics + the
+ * per-block partials they are reduced from in a fixed order: no atomics, bitwise reproducible). */
+long s2d_groupnorm_workspace_doubles(int N, int H, int W, int G);
 int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, const float *gamma, const float *beta,
                            float eps, const float *up, int hu, int wu, int relu, double *stats_ws, float *y,
                            hipStream_t stream);

@@ -9,7 +9,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, "..", "include", "s2d_hip.h")
-LIBPATH = os.path.join(_HERE, "csrc", "libs2d_hip.so")
+LIBPATH = os.environ.get("S2D_HIP_LIB") or os.path.join(_HERE, "csrc", "libs2d_hip.so")   # override: kernel experiments only
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
            "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "hipStream_t": ctypes.c_void_p,

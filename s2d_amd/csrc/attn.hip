@@ -17,6 +17,7 @@
 // (the accumulator registers) are directly the B operand of O^T[d][q] += V^T . P^T -- no LDS round trip
 // for P and no cross-lane rescale.  Partial (O, m, l) per key split are merged by a second tiny kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,6 +27,9 @@ constexpr int LSTR = 36;         // LDS row stride (floats)
 
 // ------------------------------------------------------------------------------------------------
 // attention-mask builder: 32 lanes per key, lane g owns queries 4g..4g+3
+// COHERENT: system-scope loads of the mask logits (diagnostic variant used to pin down the two-stream stale-read
+// hazard described in DESIGN.md section 6; the shipped launch uses plain loads)
+template <bool COHERENT>
 __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
                                                         int hl, int wl, uint32_t *__restrict__ bits,
                                                         uint32_t *__restrict__ unmasked)
@@ -54,7 +58,14 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (q0 + j < Q) {
-                    v[j] = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
+                    float a00, a01, a10, a11;
+                    if (COHERENT) {
+                        a00 = __hip_atomic_load(p00 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        a01 = __hip_atomic_load(p01 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        a10 = __hip_atomic_load(p10 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        a11 = __hip_atomic_load(p11 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else { a00 = p00[j]; a01 = p01[j]; a10 = p10[j]; a11 = p11[j]; }
+                    v[j] = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
                     valid |= 1u << j;
                     // sigmoid(v) < 0.5  <=>  v < 0   (:463)
                     if (v[j] < 0.f) nib |= 1u << j;
@@ -248,9 +259,9 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
     if (Q > 128 || Q <= 0 || ldq < Q) return S2D_ERR_ARG;
     const long K = (long)T * hl * wl;
     if (B == 0 || K == 0) return S2D_OK;
-    if (hipMemsetAsync(unmasked, 0, sizeof(uint32_t) * QW * B, stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_mask_kernel, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl, wl,
-                       bits, unmasked);
+    if (s2d_zero_async(unmasked, sizeof(uint32_t) * QW * B, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_mask_kernel<false>, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl,
+                       wl, bits, unmasked);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

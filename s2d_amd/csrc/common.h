@@ -18,6 +18,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` bytes with a kernel on `stream`.  Used instead of hipMemsetAsync: the
+// runtime may run a memset on a different engine than the kernels around it, and with two streams sharing the GPU the
+// kernel that followed such a memset was observed reading its predecessor's output before it was complete.  A fill
+// kernel is an ordinary dispatch in the stream's queue.  (elem.hip)
+int s2d_zero_async(void *p, size_t bytes, hipStream_t stream);
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float wave_sum(float v)
 {

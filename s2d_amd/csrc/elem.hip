@@ -58,12 +58,13 @@ __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm over NHWC tokens x [N, HW, C]: stats[n][g] = (sum, sumsq) in double via one atomic per block.
+// GroupNorm over NHWC tokens x [N, HW, C]: per-block partial (sum, sumsq) in double, reduced in a fixed order by
+// gn_reduce_kernel (no atomics: the statistics, and with them every downstream value, are bitwise reproducible).
 // 256 threads: thread t owns channel quad c4 = t % (C/4) for rows r = t / (C/4) + k * (256/(C/4)).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int HW, int C, int G, int rows_per_blk,
-                                                       double *__restrict__ stats)
+                                                       double *__restrict__ part)
 {
-    extern __shared__ double sh[];  // [2][C/4]
+    __shared__ double sh[2][256];   // [sum | sumsq][rslot * q + c4]
     const int n = blockIdx.y;
     const int q = C / 4, tpr = 256 / q;  // threads per row-slot
     const int c4 = threadIdx.x % q, rslot = threadIdx.x / q;
@@ -77,21 +78,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
             s += (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
             ss += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
         }
-    }
-    for (int i = threadIdx.x; i < 2 * q; i += 256) sh[i] = 0.;
-    __syncthreads();
-    if (rslot < tpr) {
-        atomicAdd(&sh[c4], s);
-        atomicAdd(&sh[q + c4], ss);
+        sh[0][threadIdx.x] = s;
+        sh[1][threadIdx.x] = ss;
     }
     __syncthreads();
     const int cpg4 = (C / G) / 4;  // float4s per group
     if (threadIdx.x < G) {
         double a = 0., b = 0.;
-        for (int k = 0; k < cpg4; ++k) { a += sh[threadIdx.x * cpg4 + k]; b += sh[q + threadIdx.x * cpg4 + k]; }
-        atomicAdd(&stats[((long)n * G + threadIdx.x) * 2], a);
-        atomicAdd(&stats[((long)n * G + threadIdx.x) * 2 + 1], b);
+        for (int k = 0; k < cpg4; ++k)
+            for (int rs = 0; rs < tpr; ++rs) { a += sh[0][rs * q + threadIdx.x * cpg4 + k]; b += sh[1][rs * q + threadIdx.x * cpg4 + k]; }
+        double *o = part + (((long)n * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
+        o[0] = a; o[1] = b;
     }
+}
+
+__global__ void gn_reduce_kernel(const double *__restrict__ part, int nblk, int G, double *__restrict__ stats)
+{
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    double a = 0., b = 0.;
+    for (int k = 0; k < nblk; ++k) { a += part[(((long)n * nblk + k) * G + g) * 2]; b += part[(((long)n * nblk + k) * G + g) * 2 + 1]; }
+    stats[((long)n * G + g) * 2] = a;
+    stats[((long)n * G + g) * 2 + 1] = b;
 }
 
 // y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
@@ -224,6 +232,34 @@ __global__ void pe_sine_kernel(int T, int H, int W, int F, const float *__restri
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t *__restrict__ p, size_t n, uint8_t *__restrict__ tail, int ntail)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+}  // namespace
+
+int s2d_zero_async(void *p, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return S2D_OK;
+    uint8_t *b = reinterpret_cast<uint8_t *>(p);
+    const int head = (int)((4 - ((uintptr_t)b & 3)) & 3);           // unaligned leading bytes (views)
+    if ((size_t)head >= bytes) {
+        hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, stream, nullptr, (size_t)0, b, (int)bytes);
+        S2D_CHECK_LAUNCH();
+        return S2D_OK;
+    }
+    if (head) hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, stream, nullptr, (size_t)0, b, head);
+    const size_t n = (bytes - head) / 4;
+    const int ntail = (int)((bytes - head) & 3);
+    const int nb = (int)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+    hipLaunchKernelGGL(zero_kernel, dim3(nb), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(b + head), n, b + head + 4 * n,
+                       ntail);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 extern "C" {
 
 int s2d_normalize_pad_nhwc4_f32(const uint8_t *frames, int F, int H0, int W0, int Hp, int Wp, const float *mean3_host,
@@ -250,6 +286,15 @@ int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float 
     return S2D_OK;
 }
 
+static int gn_rows_per_blk(long HW) { return (int)max(256L, (long)cdiv(HW, 240L)); }
+
+long s2d_groupnorm_workspace_doubles(int N, int H, int W, int G)
+{
+    const long HW = (long)H * W;
+    if (N <= 0 || HW <= 0) return 0;
+    return 2L * N * G * (1 + cdiv(HW, (long)gn_rows_per_blk(HW)));
+}
+
 int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, const float *gamma, const float *beta,
                            float eps, const float *up, int hu, int wu, int relu, double *stats_ws, float *y,
                            hipStream_t stream)
@@ -257,10 +302,11 @@ int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, co
     if ((C & 3) || C / 4 > 256 || 256 % (C / 4) || C % G || (C / G) & 3 || G > 256) return S2D_ERR_ARG;
     const long HW = (long)H * W;
     if (N == 0 || HW == 0) return S2D_OK;
-    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * N * G, stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    const int rows_per_blk = 256;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(HW, rows_per_blk), N), dim3(256), sizeof(double) * 2 * (C / 4), stream,
-                       x, (int)HW, C, G, rows_per_blk, stats_ws);
+    const int rows_per_blk = gn_rows_per_blk(HW);
+    const int nblk = (int)cdiv(HW, (long)rows_per_blk);
+    double *part = stats_ws + 2L * N * G;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, (int)HW, C, G, rows_per_blk, part);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(N), dim3(256), 0, stream, part, nblk, G, stats_ws);
     const long total = (long)N * HW * (C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W, C,
                        G, eps, up, hu, wu, relu, y);

@@ -134,7 +134,7 @@ extern "C" {
 
 int s2d_tracks_to_masks_u8(const float *tracks, int T, int Np, int H, int W, uint8_t *masks, hipStream_t stream)
 {
-    if (hipMemsetAsync(masks, 0, (size_t)T * H * W, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(masks, (size_t)T * H * W, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     const long n = (long)T * Np;
     if (n == 0) return S2D_OK;
     hipLaunchKernelGGL(scatter_tracks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, tracks, T, Np, H, W, masks);
@@ -147,8 +147,8 @@ int s2d_point_id_counts(const uint8_t *point_masks, const int64_t *idmap, int T,
 {
     if (max_id < 0 || max_id > 8190) return S2D_ERR_ARG;
     if (T == 0) return S2D_OK;
-    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T * (max_id + 1), stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    if (hipMemsetAsync(total, 0, sizeof(int) * (size_t)T, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(counts, sizeof(int) * (size_t)T * (max_id + 1), stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(total, sizeof(int) * (size_t)T, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(point_id_hist_kernel, dim3(32, T), dim3(256), sizeof(int) * (max_id + 2), stream, point_masks, idmap, H, W,
                        Hi, Wi, max_id, counts, total);
     S2D_CHECK_LAUNCH();
@@ -159,7 +159,7 @@ int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_i
 {
     if (max_id < 0 || max_id > 8190) return S2D_ERR_ARG;
     if (T == 0) return S2D_OK;
-    if (hipMemsetAsync(presence, 0, (size_t)T * (max_id + 1), stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(presence, (size_t)T * (max_id + 1), stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(id_presence_kernel, dim3(32, T), dim3(256), sizeof(int) * (max_id + 1), stream, idmap, (long)Hi * Wi, max_id,
                        presence);
     S2D_CHECK_LAUNCH();

@@ -584,6 +584,13 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int tbits[];
     __shared__ float red[LTHREADS / 64][4];
+    // Points whose |logit| equals the top-k threshold exactly: the `take` of them with the smallest point index are kept
+    // (a fixed rule, so the loss is bitwise reproducible whatever else shares the GPU).  They are parked in a small
+    // list, ranked by index and evaluated by thread = rank; a row with more ties than the list holds (a constant logit
+    // map) takes the block-scan path below.
+    constexpr int TIECAP = 512;
+    __shared__ unsigned int tie_n, tie_base, wtie[LTHREADS / 64];
+    __shared__ int tie_idx[TIECAP], tie_sorted[TIECAP];
     const int rows_l = p.B * p.maxm * p.T;
     const int nrows = min(p.lcount[p.NL], p.xcap);
     const long HW = (long)p.H * p.W;
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             }
             tbits[wd] = out;
         }
+        if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
         __syncthreads();
         const unsigned int thr = p.prefix[rowid];
         const unsigned int take = (unsigned int)p.krem[rowid];
@@ -629,7 +637,10 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 if (over) {
                     const unsigned int key = __float_as_uint(fabsf(xv));
                     sel = key < thr;
-                    if (key == thr) sel = atomicAdd(&p.tie[rowid], 1u) < take;
+                    if (key == thr) {
+                        const unsigned int slot = atomicAdd(&tie_n, 1u);
+                        if (slot < TIECAP) tie_idx[slot] = i;
+                    }
                 }
                 if (!sel) continue;
                 float u, v;
@@ -639,6 +650,50 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
                 acc_point(xv, sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+            }
+        }
+        __syncthreads();
+        const unsigned int nties = tie_n;
+        if (nties > 0u && take > 0u) {                        // uniform over the workgroup
+            const float *cr = coord_rows(p, rowid, true);
+            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
+            auto tie_point = [&](int i) {
+                float u, v;
+                if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
+                else {
+                    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                }
+                acc_point(xb[i], sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+            };
+            if (nties <= (unsigned int)TIECAP) {
+                for (unsigned int j = threadIdx.x; j < nties; j += LTHREADS) {
+                    const int mine = tie_idx[j];
+                    unsigned int rank = 0u;
+                    for (unsigned int k2 = 0; k2 < nties; ++k2) rank += tie_idx[k2] < mine ? 1u : 0u;
+                    tie_sorted[rank] = mine;
+                }
+                __syncthreads();
+                for (unsigned int j = threadIdx.x; j < min(nties, take); j += LTHREADS) tie_point(tie_sorted[j]);
+            } else {
+                const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+                for (int i0 = 0; i0 < p.n_over; i0 += LTHREADS) {
+                    const int i = i0 + threadIdx.x;
+                    const bool istie = i < p.n_over && __float_as_uint(fabsf(xb[i])) == thr;
+                    const unsigned long long bal = __ballot(istie);
+                    if (lane_ == 0) wtie[wv_] = (unsigned int)__popcll(bal);
+                    __syncthreads();
+                    unsigned int rank = tie_base + (unsigned int)__popcll(bal & ((1ull << lane_) - 1ull));
+                    for (int w = 0; w < wv_; ++w) rank += wtie[w];
+                    if (istie && rank < take) tie_point(i);
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        unsigned int tot = 0u;
+                        for (int w = 0; w < LTHREADS / 64; ++w) tot += wtie[w];
+                        tie_base += tot;
+                    }
+                    __syncthreads();
+                }
             }
         }
         bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
@@ -688,8 +743,7 @@ __global__ void class_loss_kernel(const float *__restrict__ cls, const int *__re
                                   int B, int Q, int maxm, float eos, float *__restrict__ out)
 {
     __shared__ unsigned char matched[128];
-    __shared__ double snum, sden;
-    if (threadIdx.x == 0) { snum = 0.; sden = 0.; }
+    __shared__ double wnum[16], wden[16];
     double num = 0., den = 0.;
     for (int b = 0; b < B; ++b) {
         __syncthreads();
@@ -709,9 +763,13 @@ __global__ void class_loss_kernel(const float *__restrict__ cls, const int *__re
         }
     }
     num = wave_sum_d(num); den = wave_sum_d(den);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&snum, num); atomicAdd(&sden, den); }
+    if ((threadIdx.x & 63) == 0) { wnum[threadIdx.x >> 6] = num; wden[threadIdx.x >> 6] = den; }
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (float)(snum / sden);
+    if (threadIdx.x == 0) {
+        double sn = 0., sd = 0.;
+        for (unsigned int w = 0; w < (blockDim.x + 63) / 64; ++w) { sn += wnum[w]; sd += wden[w]; }   // fixed order
+        out[0] = (float)(sn / sd);
+    }
 }
 
 }  // namespace
@@ -724,7 +782,7 @@ int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, f
 {
     if (Q > 128 || Nmax > 128) return S2D_ERR_ARG;
     if (B == 0) return S2D_OK;
-    if (hipMemsetAsync(nonempty, 0, sizeof(int) * (size_t)B * Nmax * T, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(nonempty, sizeof(int) * (size_t)B * Nmax * T, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(kd_select_kernel, dim3(B), dim3(128), 0, stream, t_class_logits, Q, topk < Q ? topk : Q, score_thr,
                        Nmax, count, kept_q);
     hipLaunchKernelGGL(kd_upsample_kernel, dim3(cdiv(W, 256), H, B * T), dim3(256), 0, stream, t_mask_logits, ldq, T, hm, wm,
@@ -799,8 +857,8 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     // samples are kept only when the target plane fits LDS as bits and vector loads line up
     const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 150 * 1024);
     p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
-    if (hipMemsetAsync(p.hist, 0, (size_t)rows * 2048 * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    if (hipMemsetAsync(p.tie, 0, (size_t)rows * 4, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(p.hist, (size_t)rows * 2048 * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(p.tie, (size_t)rows * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);

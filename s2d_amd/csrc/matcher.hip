@@ -14,6 +14,7 @@
 // Mask logits are read PIXEL-MAJOR ([T*hm*wm][ldq], the row-major output of the mask-logit GEMM): the four
 // bilinear corners of a sample point are four contiguous Q-float rows, one coalesced 128-B segment per wave.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -282,13 +283,17 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
     lo = __builtin_bit_cast(unsigned int, l);
 }
 
-__global__ __launch_bounds__(256) void matcher_cost_f16_kernel(CostParams p)
+__global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
 {
     constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
     constexpr int TROW = 20;                               // words per target row: 16 data (32 fp16) + 4 pad
-    __shared__ __attribute__((aligned(16))) unsigned int Th[TN][TROW], Tl[TN][TROW];
-    __shared__ __attribute__((aligned(16))) int bqi[SB][4], bti[SB][4];      // per sample: 4 tap offsets / weights,
-    __shared__ __attribute__((aligned(16))) float bqw[SB][4], btw[SB][4];   // read back as one 16-B LDS load each
+    // The kernel is bound by gather latency (2 waves/SIMD), so a batch's 64 logit gathers and 16 target gathers per lane
+    // are all issued before anything consumes them, and the loop has ONE barrier per batch: the tap tables live in a
+    // ring of 3 (batch i: query side in use; batch i+1: target gathers in flight; batch i+2: being set up by two
+    // half-waves from coordinates loaded at the top of the iteration), the target tile in a ring of 2.
+    __shared__ __attribute__((aligned(16))) unsigned int Th[2][TN][TROW], Tl[2][TN][TROW];
+    __shared__ __attribute__((aligned(16))) int bqi[3][SB][4], bti[3][SB][4];      // per sample: 4 tap offsets / weights,
+    __shared__ __attribute__((aligned(16))) float bqw[3][SB][4], btw[3][SB][4];   // read back as one 16-B LDS load each
     __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
@@ -299,87 +304,149 @@ __global__ __launch_bounds__(256) void matcher_cost_f16_kernel(CostParams p)
     const int N = min(p.tgt_count[b], p.Nmax);
     if (N == 0 || N > 32) return;                           // N > 32: matcher_cost_kernel<4>
     const int q = wv * 32 + l32;
-    const bool qok = q < p.Q;
-    const float *ml = p.ml + ((long)prob * p.T + t) * p.hm * p.wm * p.ldq + (qok ? q : 0);
-    const uint8_t *tg = p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W;
+    // Rows q >= Q and target columns >= N are computed on clamped (valid) data and never read by the finalize kernel:
+    // a row of the contraction depends on its own query only, a column on its own target only.  All gathers are buffer
+    // loads with 32-bit byte offsets (tap offset from LDS + a per-lane constant: one v_add per load, no 64-bit math).
+    const long mapf = (long)p.hm * p.wm * p.ldq;
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.ml + ((long)prob * p.T + t) * mapf), 0, (int)(mapf * 4), 0x00020000);
+    const unsigned int q4 = (unsigned int)(q < p.Q ? q : 0) * 4u;
     const long tplane = (long)p.T * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W), 0,
+        (int)((long)p.Nmax * tplane - (long)t * p.H * p.W), 0x00020000);
     const float *cr = p.coords + (long)prob * p.P * 2;
     const int tn = tid % TN, slot = tid / TN;
+    const unsigned int toff = (unsigned int)((long)(tn < N ? tn : 0) * tplane);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    // tap setup: lanes 0..31 of wave 0 do the logit-map side of sample l32, lanes 0..31 of wave 1 the target side
+    const bool setq = tid < SB, sett = tid >= 64 && tid < 64 + SB;
 
     f32x16 aAm, aAx, aDm, aDx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aAm[r] = 0.f; aAx[r] = 0.f; aDm[r] = 0.f; aDx[r] = 0.f; }
-    float spsum = 0.f, sgsum = 0.f, tsum = 0.f;
+    float relusum = 0.f, lg2sum = 0.f, sgsum = 0.f, tsum = 0.f;
 
-    for (int base = c * SB; base < p.P; base += CHM * SB) {
+    // out-of-image corners (zero padding): the offset is clamped to a valid element and the weight zeroed, so every
+    // gather is unconditional
+    auto setup = [&](int buf, float u, float v, bool tail) {
+        if (setq) {
+            const Bil a = bil_setup(u, v, p.hm, p.wm);
+            const int rowb = p.ldq * 4;      // byte offsets into the (problem, frame) logit map
+            const i32x4 o = {a.i00 < 0 ? 0 : a.i00 * rowb, a.i01 < 0 ? 0 : a.i01 * rowb, a.i10 < 0 ? 0 : a.i10 * rowb,
+                             a.i11 < 0 ? 0 : a.i11 * rowb};
+            const f32x4 w = {(a.i00 < 0 || tail) ? 0.f : a.w00, (a.i01 < 0 || tail) ? 0.f : a.w01,
+                             (a.i10 < 0 || tail) ? 0.f : a.w10, (a.i11 < 0 || tail) ? 0.f : a.w11};
+            *reinterpret_cast<i32x4 *>(bqi[buf][l32]) = o;
+            *reinterpret_cast<f32x4 *>(bqw[buf][l32]) = w;
+        } else if (sett) {
+            const Bil d = bil_setup(u, v, p.H, p.W);
+            const i32x4 o = {max(d.i00, 0), max(d.i01, 0), max(d.i10, 0), max(d.i11, 0)};
+            const f32x4 w = {(d.i00 < 0 || tail) ? 0.f : d.w00, (d.i01 < 0 || tail) ? 0.f : d.w01,
+                             (d.i10 < 0 || tail) ? 0.f : d.w10, (d.i11 < 0 || tail) ? 0.f : d.w11};
+            *reinterpret_cast<i32x4 *>(bti[buf][l32]) = o;
+            *reinterpret_cast<f32x4 *>(btw[buf][l32]) = w;
+        }
+    };
+    // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and stores them
+    // as two fp16 pairs (hi / scaled lo) of row tn
+    auto target_gather = [&](int tb, unsigned char (&tv)[SPT][4]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[tb][slot * SPT + j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tv[j][e] = __builtin_amdgcn_raw_buffer_load_b8(rsT, (int)(toff + (unsigned int)ti[e]), 0, 0);
+        }
+    };
+    auto target_tile = [&](int tb, int buf, const unsigned char (&tv)[SPT][4]) {
+        float val[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const f32x4 tw = *reinterpret_cast<const f32x4 *>(btw[tb][slot * SPT + j]);
+            val[j] = fmaf((float)tv[j][3], tw[3], fmaf((float)tv[j][2], tw[2], fmaf((float)tv[j][1], tw[1], (float)tv[j][0] * tw[0])));
+            tsum += val[j];
+        }
+        unsigned int h0, l0, h1, l1;
+        split_pair(val[0], val[1], h0, l0);
+        split_pair(val[2], val[3], h1, l1);
+        Th[buf][tn][slot * 2] = h0; Th[buf][tn][slot * 2 + 1] = h1;
+        Tl[buf][tn][slot * 2] = l0; Tl[buf][tn][slot * 2 + 1] = l1;
+    };
+    auto load_uv = [&](int base, float &u, float &v, bool &tail) {
+        u = 0.f; v = 0.f;
+        tail = base + l32 >= p.P;
+        if ((setq || sett) && !tail) { u = cr[2 * (base + l32)]; v = cr[2 * (base + l32) + 1]; }
+    };
+
+    const int base0 = c * SB, bstep = CHM * SB;
+    if (base0 < p.P) {
+        float u, v; bool tail;
+        load_uv(base0, u, v, tail);
+        setup(0, u, v, tail);
+        load_uv(base0 + bstep, u, v, tail);                // all-tail (zero weights, no load) past the end
+        setup(1, u, v, tail);
+        __syncthreads();
+        unsigned char tv[SPT][4];
+        target_gather(0, tv);
+        target_tile(0, 0, tv);
+    }
+    int r0 = 0, cur = 0;                                    // r0 = i % 3, cur = i & 1
+    for (int base = base0; base < p.P; base += bstep, cur ^= 1, r0 = (r0 == 2 ? 0 : r0 + 1)) {
+        const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
         const int nvalid = min(SB, p.P - base);
-        __syncthreads();
-        if (tid < SB) {
-            float u = 0.f, v = 0.f;
-            if (tid < nvalid) { u = cr[2 * (base + tid)]; v = cr[2 * (base + tid) + 1]; }
-            const Bil a = bil_setup(u, v, p.hm, p.wm), d = bil_setup(u, v, p.H, p.W);
-            const bool tail = tid >= nvalid;
-            bqi[tid][0] = a.i00 < 0 ? 0 : a.i00 * p.ldq; bqi[tid][1] = a.i01 < 0 ? 0 : a.i01 * p.ldq;
-            bqi[tid][2] = a.i10 < 0 ? 0 : a.i10 * p.ldq; bqi[tid][3] = a.i11 < 0 ? 0 : a.i11 * p.ldq;
-            bqw[tid][0] = (a.i00 < 0 || tail) ? 0.f : a.w00; bqw[tid][1] = (a.i01 < 0 || tail) ? 0.f : a.w01;
-            bqw[tid][2] = (a.i10 < 0 || tail) ? 0.f : a.w10; bqw[tid][3] = (a.i11 < 0 || tail) ? 0.f : a.w11;
-            bti[tid][0] = max(d.i00, 0); bti[tid][1] = max(d.i01, 0); bti[tid][2] = max(d.i10, 0); bti[tid][3] = max(d.i11, 0);
-            btw[tid][0] = (d.i00 < 0 || tail) ? 0.f : d.w00; btw[tid][1] = (d.i01 < 0 || tail) ? 0.f : d.w01;
-            btw[tid][2] = (d.i10 < 0 || tail) ? 0.f : d.w10; btw[tid][3] = (d.i11 < 0 || tail) ? 0.f : d.w11;
-        }
-        __syncthreads();
-        // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and
-        // stores them as two fp16 pairs (hi / scaled lo) of row tn
-        {
-            const uint8_t *pl = tg + (long)(tn < N ? tn : 0) * tplane;
-            const float live = tn < N ? 1.f : 0.f;
-            float val[SPT];
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-                const int k = slot * SPT + j;
-                typedef int i32x4 __attribute__((ext_vector_type(4)));
-                const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[k]);
-                const f32x4 tw = *reinterpret_cast<const f32x4 *>(btw[k]);
-                const float v = (float)pl[ti[0]] * tw[0] + (float)pl[ti[1]] * tw[1] + (float)pl[ti[2]] * tw[2] + (float)pl[ti[3]] * tw[3];
-                val[j] = v * live;
-                tsum += val[j];
-            }
-            unsigned int h0, l0, h1, l1;
-            split_pair(val[0], val[1], h0, l0);
-            split_pair(val[2], val[3], h1, l1);
-            Th[tn][slot * 2] = h0; Th[tn][slot * 2 + 1] = h1;
-            Tl[tn][slot * 2] = l0; Tl[tn][slot * 2 + 1] = l1;
-        }
+        float un, vn; bool tailn;
+        load_uv(base + 2 * bstep, un, vn, tailn);
+        unsigned char tv[SPT][4];
+        target_gather(r1, tv);                              // batch i+1 (all-tail tables past the end: offsets 0)
         // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
+        float m[16][4];
+#pragma unroll
+        for (int s16 = 0; s16 < 16; ++s16) {
+            const int k = 16 * (s16 >> 3) + 8 * h + (s16 & 7);
+            const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                m[s16][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, (int)((unsigned int)qi[e] + q4), 0, 0));
+        }
+        // softplus(x) = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)): the two sums are kept apart and ln2 is applied once.
+        // A tail sample (zero tap weights) has x == 0 exactly; only the one partial batch of a chunk pays for the masks.
         unsigned int xh[2][4], xl[2][4], gh[2][4], gl[2][4];
+        auto query_side = [&](auto masked) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                float xv[2], sv[2];
+                for (int jp = 0; jp < 4; ++jp) {
+                    float xv[2], sv[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int k = 16 * st + 8 * h + 2 * jp + e;
-                    typedef int i32x4 __attribute__((ext_vector_type(4)));
-                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[k]);
-                    const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[k]);
-                    const float x = ((ml[qi[0]] * qw[0] + ml[qi[1]] * qw[1]) + ml[qi[2]] * qw[2]) + ml[qi[3]] * qw[3];
-                    const float liveq = (qok && k < nvalid) ? 1.f : 0.f;
-                    const float ex = __expf(-fabsf(x));
-                    const float inv = __builtin_amdgcn_rcpf(1.f + ex);
-                    const float sgm = (x >= 0.f ? inv : ex * inv) * liveq;
-                    spsum += (fmaxf(x, 0.f) + __logf(1.f + ex)) * liveq;
-                    sgsum += sgm;
-                    xv[e] = x * liveq; sv[e] = sgm;
+                    for (int e = 0; e < 2; ++e) {
+                        const int s16 = 8 * st + 2 * jp + e, k = 16 * st + 8 * h + 2 * jp + e;
+                        const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
+                        const float x = fmaf(m[s16][3], qw[3], fmaf(m[s16][2], qw[2], fmaf(m[s16][1], qw[1], m[s16][0] * qw[0])));
+                        const float ex = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
+                        const float den = 1.f + ex;
+                        const float inv = __builtin_amdgcn_rcpf(den);
+                        float sgm = x >= 0.f ? inv : ex * inv;
+                        float lg = __builtin_amdgcn_logf(den);
+                        if constexpr (decltype(masked)::value) {
+                            const float liveq = k < nvalid ? 1.f : 0.f;
+                            sgm *= liveq; lg *= liveq;
+                        }
+                        relusum += fmaxf(x, 0.f);
+                        lg2sum += lg;
+                        sgsum += sgm;
+                        xv[e] = x; sv[e] = sgm;
+                    }
+                    split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
+                    split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
                 }
-                split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
-                split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
-            }
-        __syncthreads();  // target tile complete
+        };
+        if (nvalid == SB) query_side(std::false_type{}); else query_side(std::true_type{});
+        setup(r2, un, vn, tailn);
+        __syncthreads();  // target tile [cur] (written last iteration) and taps [r2] complete
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[l32][8 * st + 4 * h]);
-            const f16x8 tl = *reinterpret_cast<const f16x8 *>(&Tl[l32][8 * st + 4 * h]);
+            const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[cur][l32][8 * st + 4 * h]);
+            const f16x8 tl = *reinterpret_cast<const f16x8 *>(&Tl[cur][l32][8 * st + 4 * h]);
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 a0 = {xh[st][0], xh[st][1], xh[st][2], xh[st][3]}, a1 = {xl[st][0], xl[st][1], xl[st][2], xl[st][3]};
             const u32x4 g0 = {gh[st][0], gh[st][1], gh[st][2], gh[st][3]}, g1 = {gl[st][0], gl[st][1], gl[st][2], gl[st][3]};
@@ -392,6 +459,7 @@ __global__ __launch_bounds__(256) void matcher_cost_f16_kernel(CostParams p)
             aDx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, tl, aDx, 0, 0, 0);
             aDm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, th, aDm, 0, 0, 0);
         }
+        target_tile(r1, cur ^ 1, tv);
     }
     const long pc = (long)prob * p.chunks + (long)t * CHM + c;
 #pragma unroll
@@ -400,6 +468,7 @@ __global__ __launch_bounds__(256) void matcher_cost_f16_kernel(CostParams p)
         p.wsA[(pc * QP + qq) * NP + l32] = aAm[r] + aAx[r] * (1.0f / 2048.0f);
         p.wsD[(pc * QP + qq) * NP + l32] = aDm[r] + aDx[r] * (1.0f / 2048.0f);
     }
+    float spsum = relusum + 0.693147181f * lg2sum;
     spsum += __shfl_xor(spsum, 32, 64);
     sgsum += __shfl_xor(sgsum, 32, 64);
     if (h == 0) {

@@ -274,9 +274,9 @@ int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const 
     if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
     if (D != 32) return S2D_ERR_ARG;
     if (N <= 0 || Lq <= 0) return S2D_OK;
-    if (hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    if (hipMemsetAsync(grad_loc, 0, sizeof(float) * (size_t)N * Lq * M * L * P * 2, stream) != hipSuccess) return S2D_ERR_LAUNCH;
-    if (hipMemsetAsync(grad_attn_w, 0, sizeof(float) * (size_t)N * Lq * M * L * P, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(grad_value, sizeof(float) * (size_t)N * S * M * D, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(grad_loc, sizeof(float) * (size_t)N * Lq * M * L * P * 2, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(grad_attn_w, sizeof(float) * (size_t)N * Lq * M * L * P, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     const long items = (long)Lq * M * D;
     hipLaunchKernelGGL(msda_bwd_kernel, dim3(cdiv(items, 256), N), dim3(256), 0, stream, value, lv, loc, attn_w,
                        grad_out, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w);

@@ -101,8 +101,12 @@ class KDVideoMaskFormer(nn.Module):
         self.num_predictions_distillation = num_predictions_distillation
         self.score_threshold_distillation = score_threshold_distillation
         self.accum_iter, self.eval_student = accum_iter, eval_student
-        self.overlap_criteria = True                      # GT criterion on the second stream beside the KD criterion
-        self.overlap_teacher, self._side = True, None     # teacher forward on a second HIP stream (forward_losses)
+        # Optional two-stream schedule of forward_losses (teacher forward / GT criterion on a second HIP stream): ~8 % faster,
+        # but OFF by default -- with two queues sharing the GPU a kernel was observed reading its in-stream predecessor's
+        # output stale (attention-mask bits computed from a few not-yet-visible mask logits), which
+        # breaks the bitwise reproducibility the single-stream path has.
+        self.overlap_criteria = False
+        self.overlap_teacher, self._side = False, None
 
     @classmethod
     def from_config(cls, cfg):  # kd_video_maskformer_model.py:130-231

@@ -162,7 +162,7 @@ def groupnorm_nhwc(x, G, gamma, beta, up=None, relu=False, eps=1e-5):
     for t in (x, gamma, beta, up):
         _chk(t)
     N, H, W, C = x.shape
-    ws = torch.empty((N * G * 2,), device=x.device, dtype=torch.float64)
+    ws = torch.empty((lib().call("s2d_groupnorm_workspace_doubles", N, H, W, G),), device=x.device, dtype=torch.float64)
     y = torch.empty_like(x)
     hu, wu = (up.shape[1], up.shape[2]) if up is not None else (0, 0)
     lib().call("s2d_groupnorm_nhwc_f32", x, N, H, W, C, G, gamma, beta, float(eps), up, hu, wu, int(relu), ws, y, _stream())

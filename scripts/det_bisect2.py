@@ -1,0 +1,104 @@
+"""per-sublayer bisect of the teacher decoder's run-to-run differences under two-stream overlap"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from s2d_amd import ops
+from s2d_amd.modeling import build_kd_model
+dev = torch.device("cuda:0")
+B, T, H0, W0, Q, P, N = bench.CONFIGS["c4"]
+model = build_kd_model(num_queries=Q, num_frames=T, num_points=P).to(dev)
+frames, masks = bench.synth_batch(0, B, T, H0, W0, N, dev)
+bench.calibrate_teacher(model, ops.normalize_pad(frames))
+images = ops.normalize_pad(frames)
+side = torch.cuda.Stream()
+side2 = torch.cuda.Stream()
+main = torch.cuda.current_stream()
+rec = {}
+pred = model.teacher[1].predictor
+active = [False]
+def hook(name):
+    def f(mod, inp, out):
+        if active[0]: rec[name] = out
+    return f
+for i in range(pred.num_layers):
+    pred.transformer_cross_attention_layers[i].register_forward_hook(hook(f"L{i}.cross"))
+    pred.transformer_self_attention_layers[i].register_forward_hook(hook(f"L{i}.self"))
+    pred.transformer_ffn_layers[i].register_forward_hook(hook(f"L{i}.ffn"))
+orig_bits, orig_attn, orig_gemm = ops.attn_mask_bits, ops.masked_attn, ops.gemm_nt
+cnt = [0, 0]
+def bits_wrap(*a, **k):
+    r = orig_bits(*a, **k)
+    if active[0]:
+        rec[f"bits{cnt[0]}"] = r[0]; rec[f"unm{cnt[0]}"] = r[1]; cnt[0] += 1
+    return r
+gcnt = [0]
+def gemm_wrap(A, Bm, *a, **kw):
+    r = orig_gemm(A, Bm, *a, **kw)
+    if active[0] and A.dim() == 2 and A.shape[0] == 200 and Bm.shape[0] == 256 and kw.get("res") is None:
+        rec[f"g{gcnt[0]:03d}.{tuple(Bm.shape)}"] = r; gcnt[0] += 1
+    return r
+def attn_wrap(q, k, v, *a, **kw):
+    r = orig_attn(q, k, v, *a, **kw)
+    if active[0]:
+        rec[f"attn{cnt[1]}.q"] = q; rec[f"attn{cnt[1]}.k"] = k; rec[f"attn{cnt[1]}.v"] = v; rec[f"attn{cnt[1]}.out"] = r; cnt[1] += 1
+    return r
+ops.attn_mask_bits = bits_wrap; ops.masked_attn = attn_wrap; ops.gemm_nt = gemm_wrap
+import s2d_amd.modeling.video_decoder as vd
+vd.ops.attn_mask_bits = bits_wrap; vd.ops.masked_attn = attn_wrap
+
+def run():
+    rec.clear(); cnt[0] = cnt[1] = 0; gcnt[0] = 0
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        active[0] = True
+        o = model.teacher(images, True)
+        active[0] = False
+        for j in range(o.mask_logits.shape[0]):
+            rec[f"zlogits{j}"] = o.mask_logits[j]
+        rec["mask_logits"] = o.mask_logits
+    if os.environ.get("S2D_EXP_TWO_SIDE"):
+        side2.wait_stream(main)
+        with torch.cuda.stream(side2):
+            s = model.student(images, True)
+        main.wait_stream(side2)
+    else:
+        s = model.student(images, True)
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in rec.items()}
+
+ref = run()
+for rep in range(6):
+    cur = run()
+    bad = [k for k in ref if not torch.equal(ref[k], cur[k])]
+    print("rep", rep, "first differing:", sorted(bad)[:3], [k for k in bad if k.startswith(("g", "z"))][:8], "of", len(bad), flush=True)
+    ref = cur
+
+# which run is right?  recompute bits8 from the recorded slot-8 logits in isolation
+print("---- recompute check", flush=True)
+sizes = [(23, 40), (46, 80), (92, 160)]
+for rep in range(6):
+    cur = run()
+    ml = cur["mask_logits"]
+    hm, wm = 184, 320
+    good = orig_bits(ml[8], B, Q, T, hm, wm, 92, 160)[0]
+    torch.cuda.synchronize()
+    d = (good != cur["bits8"])
+    nz = d.nonzero()
+    print("rep", rep, "bits8 words wrong vs isolated recompute:", int(d.sum()), "of", d.numel(),
+          "first", nz[:3].tolist(), "last", nz[-3:].tolist() if len(nz) else [], flush=True)
+    for (bb, kk, ww) in nz[:5].tolist():
+        gw, bw = int(good[bb, kk, ww]) & 0xFFFFFFFF, int(cur["bits8"][bb, kk, ww]) & 0xFFFFFFFF
+        x = kk % 160; y = (kk // 160) % 92; t = kk // (160 * 92)
+        print(f"     b{bb} key{kk} (t{t},y{y},x{x}) word{ww}: good {gw:08x} bad {bw:08x} xor {gw ^ bw:08x}", flush=True)
+        # logits of the 2x2 source pixels for the flipped queries
+        xr = gw ^ bw
+        for bit in range(32):
+            if (xr >> bit) & 1:
+                qq = ww * 32 + bit
+                vals = [float(ml[8][bb, (t * 184 + 2 * y + dy) * 320 + 2 * x + dx, qq]) for dy in (0, 1) for dx in (0, 1)]
+                print(f"        q{qq} src logits {vals}", flush=True)
+    for j in (2, 5):
+        g2 = orig_bits(ml[j], B, Q, T, hm, wm, 92, 160)[0]
+        print("   bits%d wrong:" % j, int((g2 != cur["bits%d" % j]).sum()), flush=True)

@@ -1,0 +1,18 @@
+"""time the matcher cost launch sequence at the c4 shapes (kernel experiments: S2D_HIP_LIB selects the library)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from s2d_amd import ops
+NL, B, Q, T, hm, wm, H, W, N, P = 10, 2, 100, 8, 184, 320, 736, 1280, 10, 160000
+dev = torch.device("cuda")
+ml = torch.randn((NL, B, T * hm * wm, Q), device=dev)
+cls = torch.randn((NL, B, Q, 2), device=dev)
+tgt = (torch.rand((B, N, T, H, W), device=dev) > 0.7).to(torch.uint8)
+cnt = torch.full((B,), N, dtype=torch.int32, device=dev)
+for _ in range(2):
+    C = ops.matcher_cost(ml, cls, tgt, cnt, (Q, T, hm, wm), P, (0.0, 5.0, 5.0), seed=1)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    C = ops.matcher_cost(ml, cls, tgt, cnt, (Q, T, hm, wm), P, (0.0, 5.0, 5.0), seed=1)
+torch.cuda.synchronize()
+print(os.environ.get("S2D_HIP_LIB", "default"), f"{(time.perf_counter() - t0) / 5 * 1e3:.2f} ms/call", flush=True)
