@@ -667,7 +667,7 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         // latency-heavy), the 128x128 kernel (32 flop/B from L2) on the K >= 576 spatial convolutions
         static int hi = -1;
         if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }
-        const bool use_hi = hi == 2 ? !(conv && p.KH > 1) : hi == 1;
+        const bool use_hi = hi == 2 ? (!(conv && p.KH > 1) || p.N <= 64) : hi == 1;   // N <= 64: half a 128-wide tile would idle
         if (use_hi) return conv ? launch_f16_hi<true>(p, batch, st) : launch_f16_hi<false>(p, batch, st);
         return conv ? launch_f16<true>(p, batch, st) : launch_f16<false>(p, batch, st);
     }
