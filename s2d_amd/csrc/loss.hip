@@ -244,9 +244,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(LossParams p)
     if (!any) return;
     const float *src = p.ml + (((long)prob * p.T + t) * hw + pix0) * p.ldq;
     const int npix = min(64, hw - pix0);
-    for (int e = threadIdx.x; e < npix * p.ldq; e += 256) {
-        const int px = e / p.ldq, q = e % p.ldq;
-        if (q < 128) tile[px][q] = src[e];
+    // the tile is one contiguous run of npix * ldq floats (ldq % 4 == 0, 16-B aligned): 16-B loads, scalar LDS writes
+    // (odd row stride: the column reads below stay conflict-free)
+    const int l4 = p.ldq >> 2;
+    for (int e = threadIdx.x; e < npix * l4; e += 256) {
+        const int px = e / l4, q = (e - px * l4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long)e * 4);
+        if (q < 128) { tile[px][q] = v[0]; tile[px][q + 1] = v[1]; tile[px][q + 2] = v[2]; tile[px][q + 3] = v[3]; }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * HW;
         __syncthreads();
         // bit-pack the plane: each thread turns 32 bytes (two 16-B loads) into one word
+#pragma unroll 4
         for (long wd = threadIdx.x; wd < HW / 32; wd += LTHREADS) {
             const uint4 a = reinterpret_cast<const uint4 *>(pl)[wd * 2], c = reinterpret_cast<const uint4 *>(pl)[wd * 2 + 1];
             const unsigned int ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
@@ -631,8 +636,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
             const int cnt = over ? p.n_over : p.n_rand;
             const float *xs = xb + (over ? 0 : p.n_over);
-            for (int i = threadIdx.x; i < cnt; i += LTHREADS) {
-                const float xv = xs[i];
+            auto one_point = [&](int i, float xv) {
                 bool sel = true;
                 if (over) {
                     const unsigned int key = __float_as_uint(fabsf(xv));
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                         if (slot < TIECAP) tie_idx[slot] = i;
                     }
                 }
-                if (!sel) continue;
+                if (!sel) return;
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else {
@@ -650,7 +654,17 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
                 acc_point(xv, sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+            };
+            // the stored logits are streamed 16 B per lane (4 consecutive points), two loads in flight: with one
+            // workgroup per CU the loop is bound by the round trip of each load, not by bandwidth
+            const int cnt4 = ((reinterpret_cast<uintptr_t>(xs) & 15) == 0) ? cnt >> 2 : 0;
+#pragma unroll 2
+            for (int i4 = threadIdx.x; i4 < cnt4; i4 += LTHREADS) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) one_point(4 * i4 + j, x4[j]);
             }
+            for (int i = 4 * cnt4 + threadIdx.x; i < cnt; i += LTHREADS) one_point(i, xs[i]);
         }
         __syncthreads();
         const unsigned int nties = tie_n;
@@ -830,7 +844,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
                        int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
                        float world_size, void *workspace, float *losses, hipStream_t stream)
 {
-    if (Q > 128 || Nmax > 128 || ldq > 128 || ldq < Q) return S2D_ERR_ARG;
+    if (Q > 128 || Nmax > 128 || ldq > 128 || ldq < Q || (ldq & 3)) return S2D_ERR_ARG;
     LossParams p;
     p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count; p.nonempty = nonempty;
     p.idx_q = idx_q; p.idx_t = idx_t; p.n_match = n_match; p.coords_over = coords_over; p.coords_rand = coords_rand;
