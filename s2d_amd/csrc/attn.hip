@@ -52,23 +52,33 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
         const float *base = ml + ((long)b * T + t) * hm * wm * ldq;
         const int q0 = 4 * g;
         if (q0 < Q) {
-            float v[4];
             const float *p00 = base + ((long)y0 * wm + x0) * ldq + q0, *p01 = base + ((long)y0 * wm + x1) * ldq + q0;
             const float *p10 = base + ((long)y1 * wm + x0) * ldq + q0, *p11 = base + ((long)y1 * wm + x1) * ldq + q0;
+            f32x4 a00, a01, a10, a11;
+            if (q0 + 3 < Q && !COHERENT && (ldq & 3) == 0) {      // rows are 16-B aligned: one 16-B load per tap
+                a00 = *reinterpret_cast<const f32x4 *>(p00); a01 = *reinterpret_cast<const f32x4 *>(p01);
+                a10 = *reinterpret_cast<const f32x4 *>(p10); a11 = *reinterpret_cast<const f32x4 *>(p11);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = q0 + j < Q;
+                    if (COHERENT) {
+                        a00[j] = ok ? __hip_atomic_load(p00 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                        a01[j] = ok ? __hip_atomic_load(p01 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                        a10[j] = ok ? __hip_atomic_load(p10 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                        a11[j] = ok ? __hip_atomic_load(p11 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                    } else {
+                        a00[j] = ok ? p00[j] : 0.f; a01[j] = ok ? p01[j] : 0.f; a10[j] = ok ? p10[j] : 0.f; a11[j] = ok ? p11[j] : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (q0 + j < Q) {
-                    float a00, a01, a10, a11;
-                    if (COHERENT) {
-                        a00 = __hip_atomic_load(p00 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        a01 = __hip_atomic_load(p01 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        a10 = __hip_atomic_load(p10 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        a11 = __hip_atomic_load(p11 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    } else { a00 = p00[j]; a01 = p01[j]; a10 = p10[j]; a11 = p11[j]; }
-                    v[j] = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+                    const float v = hy * (hx * a00[j] + lx * a01[j]) + ly * (hx * a10[j] + lx * a11[j]);
                     valid |= 1u << j;
                     // sigmoid(v) < 0.5  <=>  v < 0   (:463)
-                    if (v[j] < 0.f) nib |= 1u << j;
+                    if (v < 0.f) nib |= 1u << j;
                 }
             }
         }
