@@ -243,7 +243,7 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
     lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
 }
 
-template <bool CONV>
+template <bool CONV, bool PIPE>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 {
     constexpr int BM = 128, RPT = 32;
@@ -342,6 +342,149 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
     const int nk = (p.K + BK - 1) / BK;
+    if constexpr (PIPE) {
+        // Software pipeline inside one wave (no branches in the loop body, so it is one scheduling region):
+        // the 24 MFMAs of k-tile kt are interleaved with the fp16 split + LDS stores of k-tile kt+1 (whose global loads
+        // were issued one iteration earlier, group by group, into the same registers) and with the loads of k-tile
+        // kt+2; operand fragments are read one group ahead.  Per MFMA (32 cycles of the matrix pipe) the wave issues
+        // ~5 VALU + LDS/VMEM instructions in its shadow instead of running them as a separate phase after the MFMAs.
+        // k-tile being loaded: this thread's k, its (kh, kw, ci) decode for the implicit GEMM and the past-K mask.  The
+        // decode advances incrementally (one wrap per 32-wide step when Cin >= 32), so the loop body has no division.
+        int lk = c4 * 4, lkh = 0, lkw = 0, lci = 0;
+        unsigned int lkmask = 0u;
+        auto decode_set = [&](int kt) {
+            lk = kt * BK + c4 * 4;
+            lkmask = (unsigned int)((p.K - 1 - lk) >> 31) & OOB;
+            if (CONV) {
+                const int tap = lk / p.Cin;
+                lci = lk - tap * p.Cin;
+                lkh = tap / p.KW;
+                lkw = tap - lkh * p.KW;
+            }
+        };
+        auto decode_next = [&]() {
+            lk += BK;
+            lkmask = (unsigned int)((p.K - 1 - lk) >> 31) & OOB;
+            if (CONV) {
+                lci += BK;
+                const int wrap = lci >= p.Cin ? 1 : 0;
+                lci -= wrap ? p.Cin : 0;
+                lkw += wrap;
+                const int w2 = lkw == p.KW ? 1 : 0;
+                lkw = w2 ? 0 : lkw;
+                lkh += w2;
+            }
+        };
+        auto load_slot = [&](int i) {       // row slot i of the k-tile described by (lk, lkh, lkw, lci); zeros past K
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + lkh, ix = a_ix0[i] + lkw;
+                const unsigned int tmask = (unsigned int)(((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) >> 31)) & OOB;
+                off = (a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + lci) * 4)) | tmask | lkmask;
+            } else {
+                off = (a_off[i] + (unsigned int)(lk * 4)) | a_bad[i] | lkmask;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsB, (int)((b_off[i] + (unsigned int)(lk * 4)) | b_bad[i] | lkmask), 0, 0));
+        };
+        auto store_slot = [&](int buf, int i) {
+            u32x2 hi, lo;
+            split4_f16(ra[i], hi, lo);
+            unsigned int *row = &As[(buf * BM + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+            split4_f16(rb[i], hi, lo);
+            row = &Bs[(buf * BN + r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        };
+        const bool incr = !CONV || p.Cin >= BK;      // one wrap per step at most (the Cin = 4 stem decodes by division)
+        decode_set(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_slot(i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_slot(0, i);
+        decode_set(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_slot(i);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (incr) decode_next(); else decode_set(kt + 2);
+            const unsigned int *as = &As[(cur * BM + wm * 64 + l32) * ROWW + 4 * h];
+            const unsigned int *bs = &Bs[(cur * BN + wn * 64 + l32) * ROWW + 4 * h];
+            f16x8 bh[2][2], bl[2][2], ah[2], al[2];      // [s & 1] / [group parity]: fragments one group ahead
+            auto read_b = [&](int s) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bh[s][t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 8 * s);
+                    bl[s][t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 16 + 8 * s);
+                }
+            };
+            auto read_a = [&](int s, int i, int slot) {
+                ah[slot] = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 8 * s);
+                al[slot] = *reinterpret_cast<const f16x8 *>(as + i * 32 * ROWW + 16 + 8 * s);
+            };
+            read_b(0); read_a(0, 0, 0);
+            // One chunk = 1 MFMA + ~5 VALU (a third of one float4's fp16 split) [+ its LDS stores / the slot's loads];
+            // sched_barrier(0) pins the chunk order, so every MFMA has independent work issuing in its shadow.
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int s = g >> 1, i = g & 1, fs = g & 1;
+                h16x2 ha0, ha1, hb0, hb1;
+                f32x2 fa0, fa1, fb0, fb1;
+                unsigned int *rowA = &As[((cur ^ 1) * BM + r0 + RPT * g) * ROWW];
+                unsigned int *rowB = &Bs[((cur ^ 1) * BN + r0 + RPT * g) * ROWW];
+                const f32x4 va = ra[g], vb = rb[g];
+                // chunk 0
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[fs], bh[s][0], accx[i][0], 0, 0, 0);
+                if (g == 0) read_a(0, 1, 1);
+                if (g == 1) { read_b(1); read_a(1, 0, 0); }
+                if (g == 2) read_a(1, 1, 1);
+                ha0 = __builtin_amdgcn_cvt_pkrtz(va[0], va[1]); ha1 = __builtin_amdgcn_cvt_pkrtz(va[2], va[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk 1   (dependent MFMAs on one accumulator are kept two chunks apart)
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[fs], bh[s][1], accx[i][1], 0, 0, 0);
+                fa0 = __builtin_convertvector(ha0, f32x2); fa1 = __builtin_convertvector(ha1, f32x2);
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk 2
+                accm[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bh[s][0], accm[i][0], 0, 0, 0);
+                {
+                    const f32x2 a0 = {va[0], va[1]}, a1 = {va[2], va[3]};
+                    const f32x2 r0_ = (a0 - fa0) * 2048.f, r1_ = (a1 - fa1) * 2048.f;
+                    const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(r0_[0], r0_[1]), l1 = __builtin_amdgcn_cvt_pkrtz(r1_[0], r1_[1]);
+                    const u32x2 hi = {__builtin_bit_cast(unsigned int, ha0), __builtin_bit_cast(unsigned int, ha1)};
+                    const u32x2 lo = {__builtin_bit_cast(unsigned int, l0), __builtin_bit_cast(unsigned int, l1)};
+                    *reinterpret_cast<u32x2 *>(rowA + c4 * 2) = hi;
+                    *reinterpret_cast<u32x2 *>(rowA + 16 + c4 * 2) = lo;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk 3
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bl[s][0], accx[i][0], 0, 0, 0);
+                hb0 = __builtin_amdgcn_cvt_pkrtz(vb[0], vb[1]); hb1 = __builtin_amdgcn_cvt_pkrtz(vb[2], vb[3]);
+                fb0 = __builtin_convertvector(hb0, f32x2); fb1 = __builtin_convertvector(hb1, f32x2);
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk 4
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bl[s][1], accx[i][1], 0, 0, 0);
+                {
+                    const f32x2 b0 = {vb[0], vb[1]}, b1 = {vb[2], vb[3]};
+                    const f32x2 r0_ = (b0 - fb0) * 2048.f, r1_ = (b1 - fb1) * 2048.f;
+                    const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(r0_[0], r0_[1]), l1 = __builtin_amdgcn_cvt_pkrtz(r1_[0], r1_[1]);
+                    const u32x2 hi = {__builtin_bit_cast(unsigned int, hb0), __builtin_bit_cast(unsigned int, hb1)};
+                    const u32x2 lo = {__builtin_bit_cast(unsigned int, l0), __builtin_bit_cast(unsigned int, l1)};
+                    *reinterpret_cast<u32x2 *>(rowB + c4 * 2) = hi;
+                    *reinterpret_cast<u32x2 *>(rowB + 16 + c4 * 2) = lo;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // chunk 5
+                accm[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bh[s][1], accm[i][1], 0, 0, 0);
+                load_slot(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    } else {
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -372,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
+    }
     }
     const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
     if (((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0) {
@@ -617,19 +761,19 @@ int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
     return S2D_OK;
 }
 
-template <bool CONV>
+template <bool CONV, bool PIPE>
 int launch_f16(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV>), dim3(nwg, batch), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE>), dim3(nwg, batch), dim3(256), lds, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -669,7 +813,10 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }
         const bool use_hi = hi == 2 ? (!(conv && p.KH > 1) || p.N <= 64) : hi == 1;   // N <= 64: half a 128-wide tile would idle
         if (use_hi) return conv ? launch_f16_hi<true>(p, batch, st) : launch_f16_hi<false>(p, batch, st);
-        return conv ? launch_f16<true>(p, batch, st) : launch_f16<false>(p, batch, st);
+        static int pipe = -1;
+        if (pipe < 0) { const char *e = getenv("S2D_GEMM_PIPE"); pipe = e ? atoi(e) : 1; }   // measured +6..12 %
+        if (pipe) return conv ? launch_f16<true, true>(p, batch, st) : launch_f16<false, true>(p, batch, st);
+        return conv ? launch_f16<true, false>(p, batch, st) : launch_f16<false, false>(p, batch, st);
     }
     static int force = -1;
     if (force < 0) { const char *e = getenv("S2D_GEMM_WM"); force = e ? atoi(e) : 0; }
