@@ -48,7 +48,15 @@ int s2d_set_dense_mode(int mode);
  * "bqc,btchw->bqthw" (video_mask2former_transformer_decoder.py:455).  K, lda, ldb multiples of 4. */
 int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                     int batch, long strideA, long strideB, long strideC, const float *scale, const float *bias,
-                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, hipStream_t stream);
+                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, const void *B_split,
+                    hipStream_t stream);
+
+/* Static weights can be split into their fp16 hi/lo image once (dense mode 2) instead of in every launch that reads
+ * them: out = s2d_split_weights_words(N,K) 32-bit words, laid out [N][ceil(K/32)][16 words hi | 16 words lo] (the LDS
+ * row image of the kernels, zero padded past K).  Pass it as B_split / w_split together with the fp32 weights (the
+ * other dense modes read those); NULL = split on the fly.  Results are bit-identical either way.  Unbatched B only. */
+long s2d_split_weights_words(int N, int K);
+int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hipStream_t stream);
 
 /* NHWC convolution as implicit GEMM: x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
  * y [N,Ho,Wo,Cout] = act(conv(x,w) * scale[Cout] + bias[Cout] + res).  Replaces detectron2 Conv2d+FrozenBN+ReLU
@@ -56,7 +64,7 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
  * 3x3 output conv (msdeformattn.py:264-281). */
 int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, const float *scale, const float *bias, const float *res,
-                        int relu, hipStream_t stream);
+                        int relu, const void *w_split, hipStream_t stream);
 
 /* ---- multi-scale deformable attention (HBM/L2-bound gather, no MFMA) --------------------------------- */
 

@@ -172,7 +172,11 @@ int launch(const GemmParams &p, bool conv, int batch, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return S2D_OK;
     if (p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return S2D_ERR_ARG;
-    if (g_dense_mode >= 1) return s2d_launch_gemm_bf16x3(p, conv, batch, st, g_dense_mode == 2);
+    if (g_dense_mode >= 1) {
+        GemmParams q = p;
+        if (g_dense_mode != 2) q.Bsplit = nullptr;      // the pre-split image is fp16 hi/lo: only mode 2 reads it
+        return s2d_launch_gemm_bf16x3(q, conv, batch, st, g_dense_mode == 2);
+    }
     const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
     dim3 grid(nwg, batch);
     if (conv)
@@ -190,10 +194,12 @@ extern "C" {
 // C[b][M,N] = act( (A[b][M,K] * B[b][N,K]^T) * scale[N] + bias[N] + res[b][M,N] )
 int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                     int batch, long strideA, long strideB, long strideC, const float *scale, const float *bias,
-                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, hipStream_t stream)
+                    const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, const void *B_split,
+                    hipStream_t stream)
 {
     if (res_rows < 0 || res_cols < 0 || res_cols > N) return S2D_ERR_ARG;
     GemmParams p{};
+    p.Bsplit = reinterpret_cast<const unsigned int *>(B_split);
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sA = strideA; p.sB = strideB; p.sC = strideC;
     p.scale = scale; p.bias = bias; p.res = res; p.ldr = ldr; p.sR = strideR; p.relu = relu;
@@ -205,10 +211,11 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
 // y [N,Ho,Wo,Cout] = act( conv(x,w) * scale[Cout] + bias[Cout] + res[N,Ho,Wo,Cout] )
 int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, const float *scale, const float *bias, const float *res,
-                        int relu, hipStream_t stream)
+                        int relu, const void *w_split, hipStream_t stream)
 {
     if (Cin & 3) return S2D_ERR_ARG;
     GemmParams p{};
+    p.Bsplit = reinterpret_cast<const unsigned int *>(w_split);
     p.Hin = H; p.Win = W; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Hout = (H + 2 * pad - KH) / stride + 1;
     p.Wout = (W + 2 * pad - KW) / stride + 1;
@@ -221,7 +228,15 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
 
 }  // extern "C"
 
-extern "C" int s2d_abi_version(void) { return 2; }
+extern "C" long s2d_split_weights_words(int N, int K) { return (long)N * ((K + 31) / 32) * 32; }
+
+extern "C" int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hipStream_t stream)
+{
+    if (N < 0 || K <= 0 || ldw < K) return S2D_ERR_ARG;
+    return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream);
+}
+
+extern "C" int s2d_abi_version(void) { return 3; }
 
 extern "C" int s2d_set_dense_mode(int mode)
 {

@@ -243,7 +243,7 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
     lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
 }
 
-template <bool CONV, bool PIPE>
+template <bool CONV, bool PIPE, bool BSPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 {
     constexpr int BM = 128, RPT = 32;
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
     const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
     constexpr unsigned int OOB = 0xFFFFFFF0u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = BSPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;     // BSPLIT: this thread's 4 words of a pre-split row block
     unsigned int a_off[4], b_off[4], a_bad[4], b_bad[4];
     int a_iy0[4], a_ix0[4];
 #pragma unroll
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             a_iy0[i] = a_ix0[i] = 0;
         }
         const int n = n0 + r0 + RPT * i;
-        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : 0u;
+        b_off[i] = n < p.N ? (unsigned int)(BSPLIT ? (long)n * p.kblocks * 128L + wsel * 4 : (long)n * p.ldb * 4L) : 0u;
         a_bad[i] = ok ? 0u : OOB;
         b_bad[i] = n < p.N ? 0u : OOB;
     }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             }
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsB, (int)((b_off[i] + (unsigned int)(k * 4)) | b_bad[i] | kmask), 0, 0));
+                rsB, (int)((b_off[i] + (unsigned int)(BSPLIT ? kt * 128 : k * 4)) | b_bad[i] | (BSPLIT ? 0u : kmask)), 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -327,8 +330,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             unsigned int *row = &As[(buf * BM + r0 + RPT * i) * ROWW];
             *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
             *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
-            split4_f16(rb[i], hi, lo);
             row = &Bs[(buf * BN + r0 + RPT * i) * ROWW];
+            if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; continue; }
+            split4_f16(rb[i], hi, lo);
             *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
             *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
         }
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             }
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsB, (int)((b_off[i] + (unsigned int)(lk * 4)) | b_bad[i] | lkmask), 0, 0));
+                rsB, (int)((b_off[i] + (unsigned int)(BSPLIT ? (lk >> 5) * 128 : lk * 4)) | b_bad[i] | (BSPLIT ? ((unsigned int)((p.kblocks * 32 - 1 - lk) >> 31) & OOB) : lkmask)), 0, 0));
         };
         auto store_slot = [&](int buf, int i) {
             u32x2 hi, lo;
@@ -394,8 +398,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
             unsigned int *row = &As[(buf * BM + r0 + RPT * i) * ROWW];
             *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
             *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
-            split4_f16(rb[i], hi, lo);
             row = &Bs[(buf * BN + r0 + RPT * i) * ROWW];
+            if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; return; }
+            split4_f16(rb[i], hi, lo);
             *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
             *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
         };
@@ -462,12 +467,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                 __builtin_amdgcn_sched_barrier(0);
                 // chunk 3
                 accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bl[s][0], accx[i][0], 0, 0, 0);
-                hb0 = __builtin_amdgcn_cvt_pkrtz(vb[0], vb[1]); hb1 = __builtin_amdgcn_cvt_pkrtz(vb[2], vb[3]);
-                fb0 = __builtin_convertvector(hb0, f32x2); fb1 = __builtin_convertvector(hb1, f32x2);
+                if (BSPLIT) *reinterpret_cast<f32x4 *>(rowB + wsel) = vb;
+                else {
+                    hb0 = __builtin_amdgcn_cvt_pkrtz(vb[0], vb[1]); hb1 = __builtin_amdgcn_cvt_pkrtz(vb[2], vb[3]);
+                    fb0 = __builtin_convertvector(hb0, f32x2); fb1 = __builtin_convertvector(hb1, f32x2);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // chunk 4
                 accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fs], bl[s][1], accx[i][1], 0, 0, 0);
-                {
+                if (!BSPLIT) {
                     const f32x2 b0 = {vb[0], vb[1]}, b1 = {vb[2], vb[3]};
                     const f32x2 r0_ = (b0 - fb0) * 2048.f, r1_ = (b1 - fb1) * 2048.f;
                     const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(r0_[0], r0_[1]), l1 = __builtin_amdgcn_cvt_pkrtz(r1_[0], r1_[1]);
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 // registers), single LDS buffer (27.6 KB operands, 36.9 KB with the epilogue staging).  ~4 workgroups = 16 waves per
 // CU: while one workgroup splits / stores / waits at its barriers, three others keep the matrix pipe busy (the
 // 128 x 128 kernel above is limited to 2 waves/SIMD by its 128 accumulator registers and leaves the pipe ~2/3 idle).
-template <bool CONV>
+template <bool CONV, bool BSPLIT>
 __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
 {
     constexpr int BM = 128, BNs = 64, RPT = 32;
@@ -606,7 +614,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
     const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
     constexpr unsigned int OOB = 0xFFFFFFF0u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = BSPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;     // BSPLIT: this thread's 4 words of a pre-split row block
     unsigned int a_off[4], a_bad[4], b_off[2], b_bad[2];
     int a_iy0[4], a_ix0[4];
 #pragma unroll
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = n0 + r0 + RPT * i;
-        b_off[i] = n < p.N ? (unsigned int)((long)n * p.ldb * 4L) : 0u;
+        b_off[i] = n < p.N ? (unsigned int)(BSPLIT ? (long)n * p.kblocks * 128L + wsel * 4 : (long)n * p.ldb * 4L) : 0u;
         b_bad[i] = n < p.N ? 0u : OOB;
     }
     f32x4 ra[4], rb[2];
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsB, (int)((b_off[i] + (unsigned int)(k * 4)) | b_bad[i] | kmask), 0, 0));
+                rsB, (int)((b_off[i] + (unsigned int)(BSPLIT ? kt * 128 : k * 4)) | b_bad[i] | (BSPLIT ? 0u : kmask)), 0, 0));
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -671,8 +682,9 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             u32x2 hi, lo;
-            split4_f16(rb[i], hi, lo);
             unsigned int *row = &Bs[(r0 + RPT * i) * ROWW];
+            if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; continue; }
+            split4_f16(rb[i], hi, lo);
             *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
             *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
         }
@@ -756,7 +768,25 @@ int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(float) * 4 * 64 * 36;   // 36.9 KB: epilogue staging >= operand tiles (27.6 KB)
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, 64);
-    hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV>), dim3(nwg, batch), dim3(256), lds, st, p);
+    if (p.Bsplit) hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, true>), dim3(nwg, batch), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, false>), dim3(nwg, batch), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+template <bool CONV, bool PIPE, bool BSPLIT>
+int launch_f16_v(const GemmParams &p, int batch, hipStream_t st)
+{
+    const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE, BSPLIT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE, BSPLIT>), dim3(nwg, batch), dim3(256), lds, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -764,18 +794,7 @@ int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
 template <bool CONV, bool PIPE>
 int launch_f16(const GemmParams &p, int batch, hipStream_t st)
 {
-    const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return S2D_ERR_LAUNCH;
-        attr_set = true;
-    }
-    const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE>), dim3(nwg, batch), dim3(256), lds, st, p);
-    S2D_CHECK_LAUNCH();
-    return S2D_OK;
+    return p.Bsplit ? launch_f16_v<CONV, PIPE, true>(p, batch, st) : launch_f16_v<CONV, PIPE, false>(p, batch, st);
 }
 
 template <int WM, bool CONV>
@@ -796,7 +815,39 @@ int launch_t(const GemmParams &p, int batch, hipStream_t st)
     return S2D_OK;
 }
 
+// static weights -> [N][kblocks][16 words hi | 16 words lo]: the LDS row image of the split-fp16 kernels, zero padded past K
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ W, int N, int K, long ldw, int kblocks,
+                                                            unsigned int *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * kblocks * 8) return;
+    const int c4 = (int)(i & 7);
+    const long nb = i >> 3;
+    const int kb = (int)(nb % kblocks);
+    const long n = nb / kblocks;
+    const int k = kb * 32 + c4 * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k + j < K) v[j] = W[n * ldw + k + j];
+    u32x2 hi, lo;
+    split4_f16(v, hi, lo);
+    unsigned int *o = out + nb * 32;
+    *reinterpret_cast<u32x2 *>(o + c4 * 2) = hi;
+    *reinterpret_cast<u32x2 *>(o + 16 + c4 * 2) = lo;
+}
+
 }  // namespace
+
+int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st)
+{
+    const int kblocks = (K + 31) / 32;
+    const long n = (long)N * kblocks * 8;
+    if (n == 0) return S2D_OK;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStream_t st, int f16)
 {
@@ -805,6 +856,10 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     const long bB = ((long)(p.N - 1) * p.ldb + p.K) * 4L;
     if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets
     p.bytesA = (unsigned int)bA; p.bytesB = (unsigned int)bB;
+    if (p.Bsplit) {
+        if (!f16 || (batch > 1 && p.sB != 0) || (long)p.N * ((p.K + 31) / 32) * 128L > 0xFFFFFF00L) return S2D_ERR_ARG;
+        p.kblocks = (p.K + 31) / 32;
+    }
     // 256-row tiles only when they still fill the chip
     if (f16) {
         // measured: the 16-waves/CU 128x64 kernel wins on the GEMMs / 1x1 convs (K <= 2048, epilogue- and

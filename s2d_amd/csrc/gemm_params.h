@@ -16,7 +16,12 @@ struct GemmParams {
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     // byte extents of one batch slice of A and B (buffer-descriptor bounds of the split-bf16 kernel)
     unsigned int bytesA, bytesB;
+    // optional pre-split B (static weights): [N][kblocks][16 words fp16 hi | 16 words fp16 lo] per 32-wide k block, zero
+    // padded past K; NULL = split on the fly
+    const unsigned int *Bsplit;
+    int kblocks;
 };
 
 
+int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st);
 int s2d_launch_gemm_bf16x3(const GemmParams &p, bool conv, int batch, hipStream_t st, int f16);

@@ -49,7 +49,7 @@ class ConvBN(nn.Module):
             if w.shape[-1] % 4:
                 w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1] % 4))  # stem: Cin 3 -> 4 (input is NHWC4)
             scale, shift = self.norm.fold()
-            self._packed = (key, w.contiguous().float(), scale.float(), shift.float())
+            self._packed = (key, ops.mark_static(w.contiguous().float()), scale.float(), shift.float())
         return self._packed[1:]
 
     def forward(self, x, res=None, relu=True):

@@ -57,7 +57,7 @@ class MSDeformAttn(nn.Module):
             b_oa = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
             w_all = torch.cat([w_oa, ps[4].detach()], 0).contiguous()
             b_all = torch.cat([torch.zeros_like(b_oa), ps[5].detach()], 0).contiguous()
-            self._packed = (key, w_all, b_all, w_oa, b_oa)
+            self._packed = (key, ops.mark_static(w_all), b_all, ops.mark_static(w_oa), b_oa)
         return self._packed[1:]
 
     def forward_fused(self, src, pos, shapes, res):
@@ -153,7 +153,7 @@ class _ConvGN(nn.Module):
     def packed(self):
         key = (self.weight._version, self.weight.device)
         if self._packed is None or self._packed[0] != key:
-            self._packed = (key, self.weight.detach().permute(0, 2, 3, 1).contiguous())
+            self._packed = (key, ops.mark_static(self.weight.detach().permute(0, 2, 3, 1).contiguous()))
         return self._packed[1]
 
 

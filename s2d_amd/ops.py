@@ -38,10 +38,44 @@ def _chk(t, dtype=torch.float32):
         raise RuntimeError(f"s2d op needs a contiguous {dtype} CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+_MODE = "f16x3"
+_SPLIT = {}      # (data_ptr, shape, row stride) -> (split image, version of the owning tensor, the owning tensor)
+
+
+def mark_static(t):
+    """Declare a tensor a static weight (a packed / concatenated copy of parameters that its module caches): dense launches
+    reading it as the B operand may then use a cached pre-split fp16 image instead of splitting it in every launch."""
+    t._s2d_static = True
+    return t
+
+
+def clear_weight_cache():
+    _SPLIT.clear()
+
+
+def _static_split(B, N, K, ldb):
+    """cached fp16 hi/lo image of a static weight matrix, or None (dynamic tensor / other dense mode)"""
+    if _MODE != "f16x3" or N * ((K + 31) // 32) * 128 > 0xFFFFFF00:
+        return None
+    base = B._base if B._base is not None else B
+    if not (isinstance(base, torch.nn.Parameter) or getattr(base, "_s2d_static", False) or getattr(B, "_s2d_static", False)):
+        return None
+    key = (B.data_ptr(), N, K, ldb)
+    ent = _SPLIT.get(key)
+    if ent is None or ent[1] != base._version or ent[2] is not base:
+        img = torch.empty((lib().call("s2d_split_weights_words", N, K),), device=B.device, dtype=torch.int32)
+        lib().call("s2d_split_weights_f16", B, N, K, ldb, img, _stream())
+        ent = (img, base._version, base)        # holding `base` keeps the address from being recycled under the key
+        _SPLIT[key] = ent
+    return ent[0]
+
+
 def set_dense_mode(mode):
     """"f16x3" (default: split-fp16 x3 on the f16 MFMA, ~3e-7 relative), "bf16x3" (split-bf16 x3, ~5e-6, no range
     limit) or "f32" (fp32-input MFMA, exact f32 FMA chain)."""
+    global _MODE
     lib().call("s2d_set_dense_mode", {"f32": 0, "bf16x3": 1, "f16x3": 2}[mode])
+    _MODE = mode
 
 
 def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0):
@@ -62,11 +96,12 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     sA = M * K if batched else 0
     sB = N * K if B.dim() == 3 else 0
     sC = M * ldc
+    Bs = _static_split(B, N, K, K) if B.dim() == 2 else None
     with _Timed(2.0 * bs * M * N * K, ("gemm", bs, M, N, K, 4.0 * bs * (M * K + N * K * (1 if B.dim() == 3 else 1.0 / bs) + M * N * (2 if res is not None else 1)))):
         ldr = res.shape[-1] if res is not None else N
         assert res is None or (ldr >= (res_cols or N) and res.shape[-2] == (res_rows or M))
         lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, ldr,
-                   res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), _stream())
+                   res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), Bs, _stream())
     return out
 
 
@@ -79,9 +114,10 @@ def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=Fal
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    ws = _static_split(w, Cout, KH * KW * Cin, KH * KW * Cin)
     with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * (3 if Cin == 4 else Cin),
                 ("conv", KH, N * Ho * Wo, Cout, KH * KW * Cin, 4.0 * (x.numel() + w.numel() + N * Ho * Wo * Cout * (2 if res is not None else 1)))):   # stem: algorithmic Cin is 3
-        lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu),
+        lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu), ws,
                    _stream())
     return y
 

@@ -70,3 +70,30 @@ def test_conv_nhwc(oracle, N, H, W, Cin, Cout, k, s, p):
     y = ops.conv2d_nhwc(_dev(x.transpose(0, 2, 3, 1)), _dev(w.transpose(0, 2, 3, 1)), s, p, _dev(sc), _dev(bi),
                         _dev(res.transpose(0, 2, 3, 1)), relu=True).cpu().numpy().transpose(0, 3, 1, 2)
     np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_presplit_static_weights(oracle, dense_mode):
+    """a static B (nn.Parameter / marked tensor) goes through the cached pre-split fp16 image: bit-identical to the
+    on-the-fly split, refreshed when the parameter changes in place, never used for unmarked tensors"""
+    from s2d_amd import ops
+    M, N, K = 700, 288, 260
+    A = _dev(synth.randn(3, 1, (M, K)))
+    W = torch.nn.Parameter(_dev(synth.randn(3, 2, (N, K))), requires_grad=False)
+    ops.clear_weight_cache()
+    ref = ops.gemm_nt(A, W.data.clone())                  # plain tensor: split on the fly
+    n0 = len(ops._SPLIT)
+    out = ops.gemm_nt(A, W)
+    assert torch.equal(out, ref)
+    assert len(ops._SPLIT) == n0 + (1 if dense_mode == "f16x3" else 0)
+    out_v = ops.gemm_nt(A, W[32:160])                      # a row view of the parameter
+    assert torch.equal(out_v, ref[:, 32:160])
+    with torch.no_grad():
+        W.mul_(2.0)                                        # in-place update bumps the version: the image is rebuilt
+    assert torch.equal(ops.gemm_nt(A, W), ops.gemm_nt(A, W.data.clone()))
+    # conv weights marked static
+    x = _dev(synth.randn(3, 3, (2, 20, 24, 64)))
+    w = _dev(synth.randn(3, 4, (128, 3, 3, 64)) * 0.05)
+    y0 = ops.conv2d_nhwc(x, w, 1, 1)
+    y1 = ops.conv2d_nhwc(x, ops.mark_static(w.clone()), 1, 1)
+    assert torch.equal(y0, y1)
+    ops.clear_weight_cache()
