@@ -226,6 +226,14 @@ int s2d_visibility_curve_f32(const uint8_t *visibility, int T, int Np, float *cu
 int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float *support, int T, int Np, int H, int W, int C,
                        int r, float *corr, hipStream_t stream);
 
+/* ---- timing helpers for the benchmark's per-launch roofline (not on the data path) ------------------------ */
+
+/* HIP events created with hipEventDisableSystemFence (handles are opaque integers, 0 = failure). */
+long s2d_prof_event_create(void);
+int s2d_prof_event_record(long ev, hipStream_t stream);
+int s2d_prof_event_elapsed(long ev_start, long ev_end, double *out_ms_host);
+int s2d_prof_event_destroy(long ev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,4 +342,33 @@ int s2d_pe_sine_f32(int T, int H, int W, int num_pos_feats, const float *add_c, 
     return S2D_OK;
 }
 
+/* ---- timing helpers (bench.py roofline): HIP events without the system-scope fence of the default flags, so that
+ * bracketing every dense launch does not flush the caches the next kernel wants warm ------------------------------- */
+long s2d_prof_event_create(void)
+{
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return 0;
+    return (long)(intptr_t)e;
+}
+
+int s2d_prof_event_record(long ev, hipStream_t stream)
+{
+    return hipEventRecord((hipEvent_t)(intptr_t)ev, stream) == hipSuccess ? S2D_OK : S2D_ERR_LAUNCH;
+}
+
+/* milliseconds between two recorded events as a double stored through `out_ms` (host pointer); synchronises on `b` */
+int s2d_prof_event_elapsed(long a, long b, double *out_ms)
+{
+    float ms = 0.f;
+    if (hipEventSynchronize((hipEvent_t)(intptr_t)b) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)(intptr_t)a, (hipEvent_t)(intptr_t)b) != hipSuccess) return S2D_ERR_LAUNCH;
+    *out_ms = (double)ms;
+    return S2D_OK;
+}
+
+int s2d_prof_event_destroy(long ev)
+{
+    return hipEventDestroy((hipEvent_t)(intptr_t)ev) == hipSuccess ? S2D_OK : S2D_ERR_LAUNCH;
+}
+
 }  // extern "C"

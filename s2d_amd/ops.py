@@ -12,6 +12,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Ev:
+    """HIP event without the default flags' system-scope fence (s2d_prof_event_*): cheap enough to bracket every dense launch"""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        self.h = lib().call("s2d_prof_event_create")
+        if not self.h:
+            raise RuntimeError("hipEventCreateWithFlags failed")
+
+    def record(self):
+        lib().call("s2d_prof_event_record", self.h, _stream())
+
+    def elapsed_time(self, other):
+        import ctypes
+        ms = ctypes.c_double(0.0)
+        lib().call("s2d_prof_event_elapsed", self.h, other.h, ctypes.addressof(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().call("s2d_prof_event_destroy", self.h)
+        except Exception:
+            pass
+
+
 class _Timed:
     """HIP-event bracket around one dense-contraction launch on the current stream (bench.py roofline)."""
 
@@ -21,8 +46,7 @@ class _Timed:
 
     def __enter__(self):
         if PROFILE is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
+            self.s, self.e = _Ev(), _Ev()
             self.s.record()
 
     def __exit__(self, *a):
