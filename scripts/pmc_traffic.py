@@ -1,0 +1,48 @@
+"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/<out>.json.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE -o run -- python3 bench.py ... (same)
+    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH gpurun_out/pmc_WRITE profiles/r1_pmc_traffic.json
+
+Counter unit is KB.  FETCH_SIZE is doubled for the "corrected" figures (MI355X_MICROARCH.md: it under-reports wide
+coalesced reads 2x on gfx950); WRITE_SIZE is used as is.  Launch counts include the calibration forward and the warmup
+step: 1 + 1 + 2 steps minus the loss-free calibration = 3.5 step-equivalents of forward work."""
+import collections, csv, glob, json, sys
+
+STEP_EQUIV = 3.5
+
+
+def family(name):
+    if "gemm" in name: return "gemm"
+    if "msda" in name: return "msda"
+    if "matcher_cost" in name: return "matcher_cost"
+    if any(k in name for k in ("hist_", "accumulate", "gather_rows", "select_kernel", "loss_finalize", "row_prep", "row_list")): return "loss"
+    return "other"
+
+
+def load(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    agg, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            fam = family(r["Kernel_Name"])
+            agg[fam] += float(r["Counter_Value"]) * 1024.0
+            n[fam] += 1
+    return agg, n
+
+
+fetch, n = load(sys.argv[1], "FETCH_SIZE")
+write, _ = load(sys.argv[2], "WRITE_SIZE")
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events (separate passes)",
+       "note": __doc__.split("\n\n")[-1].replace("\n", " "), "per_kernel_family": {}}
+tot_raw = tot_cor = 0.0
+for fam in sorted(fetch, key=lambda k: -fetch[k]):
+    raw = (fetch[fam] + write[fam]) / STEP_EQUIV
+    cor = (2 * fetch[fam] + write[fam]) / STEP_EQUIV
+    tot_raw += raw; tot_cor += cor
+    out["per_kernel_family"][fam] = {"launches": n[fam], "fetch_GB_raw": round(fetch[fam] / 1e9, 2), "write_GB": round(write[fam] / 1e9, 2),
+                                     "per_step_GB_raw": round(raw / 1e9, 2), "per_step_GB_corrected": round(cor / 1e9, 2),
+                                     "per_launch_bytes_corrected": int((2 * fetch[fam] + write[fam]) / max(n[fam], 1))}
+out["whole_step"] = {"per_step_GB_raw": round(tot_raw / 1e9, 1), "per_step_GB_corrected": round(tot_cor / 1e9, 1), "algorithmic_GB_per_step_SURVEY_8d": 304}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["whole_step"]), {k: v["per_step_GB_corrected"] for k, v in out["per_kernel_family"].items()})
