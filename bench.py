@@ -117,9 +117,9 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="experimental: teacher forward + GT criterion on a second HIP stream (faster, but not bitwise "
-                         "reproducible on this stack: see DESIGN.md section 6); default is one stream")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run everything on one stream (default: teacher forward + GT criterion on a second HIP stream; the "
+                         "two schedules give bitwise identical losses, which this script re-checks after the timed region)")
     ap.add_argument("--dense-breakdown", action="store_true", help="print per-shape time of the dense launches to stderr")
     ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
@@ -142,7 +142,8 @@ def main():
     B, T, H0, W0, Q, P, N = CONFIGS[args.config]
     model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
     model.train()
-    model.overlap_teacher = model.overlap_criteria = args.overlap
+    overlap = not args.no_overlap
+    model.overlap_teacher = model.overlap_criteria = overlap
     frames, masks = synth_batch(rank, B, T, H0, W0, N, dev)
     gt = TargetSet.from_list(masks, device=dev)
     calibrate_teacher(model, ops.normalize_pad(frames))
@@ -153,25 +154,59 @@ def main():
         losses = model.forward_losses(images, gt)
         return sum(losses.values())
 
+    def seeded_step(two_streams):
+        model.overlap_teacher = model.overlap_criteria = two_streams
+        model.criterion.seed = 12345
+        model.criterion.matcher.seed = 12345
+        images = ops.normalize_pad(frames, 32, mean, std)
+        return torch.stack(list(model.forward_losses(images, gt).values()))
+
     def fence():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    live_events = not args.no_kernel_events and not args.overlap
-    if live_events:
-        ops.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        total = step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    def timed(live):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        if live:
+            ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tot = step()
+        fence()
+        el = time.perf_counter() - t0
+        pr, ops.PROFILE = ops.PROFILE, None
+        return el, tot, pr
+
+    live_events = not args.no_kernel_events and not overlap
+    dt, total, prof = timed(live_events)
     events_note = "HIP events around every dense launch inside the timed region"
+    schedule_note = "one stream"
+    if overlap:
+        # the two-stream schedule must not change a single bit of the result: same seeds, both schedules, all 42 losses
+        a = seeded_step(True)
+        b = seeded_step(False)
+        fence()
+        same = torch.equal(a, b)
+        if world > 1:                       # all ranks take the same branch (the fallback re-times with barriers)
+            import torch.distributed as dist
+            flag = torch.tensor([1 if same else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item())
+        if same:
+            schedule_note = "two streams; losses re-checked bitwise against the one-stream schedule after the timed region"
+            model.overlap_teacher = model.overlap_criteria = True
+        else:
+            print("bench.py: two-stream losses differ from the one-stream losses -> timing the one-stream schedule instead",
+                  file=sys.stderr)
+            overlap = False
+            model.overlap_teacher = model.overlap_criteria = False
+            live_events = not args.no_kernel_events
+            dt, total, prof = timed(live_events)
+            schedule_note = "one stream (the two-stream schedule failed the bitwise re-check on this machine)"
     if not args.no_kernel_events and not live_events:
         # In the timed region the two networks' launches share the GPU on two streams, so an event pair around one launch
         # brackets other kernels' work too.  The per-launch durations for the roofline come from one extra step, after
@@ -183,7 +218,7 @@ def main():
         prof, ops.PROFILE = ops.PROFILE, None
         model.overlap_teacher = model.overlap_criteria = True
         events_note = ("HIP events around every dense launch of one extra single-stream step after the timed region "
-                       "(--overlap: the timed region runs the two networks on two HIP streams)")
+                       "(the timed region runs the two networks on two HIP streams; --no-overlap times them live)")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -200,7 +235,7 @@ def main():
                "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
                                       f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
-                          "streams": 2 if args.overlap else 1,
+                          "streams": 2 if overlap else 1, "schedule": schedule_note,
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)

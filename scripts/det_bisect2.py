@@ -27,9 +27,16 @@ for i in range(pred.num_layers):
     pred.transformer_ffn_layers[i].register_forward_hook(hook(f"L{i}.ffn"))
 orig_bits, orig_attn, orig_gemm = ops.attn_mask_bits, ops.masked_attn, ops.gemm_nt
 cnt = [0, 0]
+_dummy = torch.zeros(64, device=dev)
 def bits_wrap(*a, **k):
+    if os.environ.get("S2D_EXP_DUMMY"):
+        for _ in range(int(os.environ["S2D_EXP_DUMMY"])):
+            _dummy.add_(1.0)                 # tiny kernels between the mask GEMM and attn_mask, same stream
     r = orig_bits(*a, **k)
     if active[0]:
+        if os.environ.get("S2D_EXP_TWICE"):
+            r2 = orig_bits(*a, **k)          # the same launch again, right behind the first
+            rec[f"again{cnt[0]}"] = r2[0]
         rec[f"bits{cnt[0]}"] = r[0]; rec[f"unm{cnt[0]}"] = r[1]; cnt[0] += 1
     return r
 gcnt = [0]
@@ -86,6 +93,10 @@ for rep in range(6):
     torch.cuda.synchronize()
     d = (good != cur["bits8"])
     nz = d.nonzero()
+    if "again8" in cur:
+        for j in (2, 5, 8):
+            gj = orig_bits(ml[j], B, Q, T, hm, wm, 92, 160)[0]
+            print(f"   slot{j}: first launch wrong {int((gj != cur['bits%d' % j]).sum())}, second launch wrong {int((gj != cur['again%d' % j]).sum())}", flush=True)
     print("rep", rep, "bits8 words wrong vs isolated recompute:", int(d.sum()), "of", d.numel(),
           "first", nz[:3].tolist(), "last", nz[-3:].tolist() if len(nz) else [], flush=True)
     for (bb, kk, ww) in nz[:5].tolist():

@@ -50,3 +50,19 @@ def test_fullsize_properties(setup):
     assert (kd3 == kd1[::-1]).all()
     # ... and the class loss (no point sampling involved) is unchanged up to summation order over clips
     np.testing.assert_allclose(l3["kd_loss_ce"], l1["kd_loss_ce"], rtol=1e-6, atol=1e-7)
+
+
+def test_two_stream_schedule_bitwise(setup):
+    """the optional two-stream schedule (teacher forward + GT criterion on a second HIP stream) changes no bit of the
+    losses, the assignments or the teacher's pseudo targets -- repeated, since a violation would be a race"""
+    model, frames, masks, _ = setup
+    try:
+        model.overlap_teacher = model.overlap_criteria = False
+        ref = _run(model, frames, masks)
+        model.overlap_teacher = model.overlap_criteria = True
+        for _ in range(8):
+            cur = _run(model, frames, masks)
+            assert cur[0] == ref[0]
+            assert all((a == b).all() for a, b in zip(cur[1], ref[1])) and (cur[2] == ref[2]).all()
+    finally:
+        model.overlap_teacher = model.overlap_criteria = False
