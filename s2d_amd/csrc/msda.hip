@@ -13,7 +13,6 @@
 // contiguous band of queries: a band's sampling footprint (~1/8 of a 20 MB value map) then stays in that
 // XCD's 4 MB L2.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -56,41 +55,6 @@ __device__ __forceinline__ void sample_accum(typename Vec<V>::T &acc, const floa
     if (h1 <= H - 1 && w1 <= W - 1) v4 = *reinterpret_cast<const VT *>(vbase + ((long)h1 * W + w1) * rowstride);
     const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
     acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
-}
-
-// Branch-free form of sample_accum for a batch of NB samples: out-of-image corners are clamped to a valid pixel with a
-// zero weight (and a sample wholly outside gets four zero weights), so all 4*NB 16-B corner loads are issued back to
-// back before anything is consumed -- the guarded form above costs an exec-mask branch per corner and keeps only ~4
-// loads in flight.  Sums are formed in the same order with the same products, so results are unchanged.
-template <int NB>
-__device__ __forceinline__ void sample_accum_batch(f32x4 &acc, const float *const (&vbase)[NB], long rowstride, const int (&H)[NB],
-                                                   const int (&W)[NB], const float (&h_im)[NB], const float (&w_im)[NB],
-                                                   const float (&aw)[NB])
-{
-    f32x4 v[NB][4];
-    float cw[NB][4];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const bool inside = h_im[b] > -1.f && w_im[b] > -1.f && h_im[b] < (float)H[b] && w_im[b] < (float)W[b];  // cuh:293
-        const float hf = floorf(h_im[b]), wf = floorf(w_im[b]);
-        const int h0 = (int)fmaxf(fminf(hf, 1.0e6f), -1.0e6f), w0 = (int)fmaxf(fminf(wf, 1.0e6f), -1.0e6f), h1 = h0 + 1, w1 = w0 + 1;
-        const float lh = h_im[b] - hf, lw = w_im[b] - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool a0 = h0 >= 0 && h0 <= H[b] - 1, a1 = h1 >= 0 && h1 <= H[b] - 1;
-        const bool b0 = w0 >= 0 && w0 <= W[b] - 1, b1 = w1 >= 0 && w1 <= W[b] - 1;
-        cw[b][0] = (inside && a0 && b0) ? hh * hw : 0.f;
-        cw[b][1] = (inside && a0 && b1) ? hh * lw : 0.f;
-        cw[b][2] = (inside && a1 && b0) ? lh * hw : 0.f;
-        cw[b][3] = (inside && a1 && b1) ? lh * lw : 0.f;
-        const int hc0 = min(max(h0, 0), H[b] - 1), hc1 = min(max(h1, 0), H[b] - 1);
-        const int wc0 = min(max(w0, 0), W[b] - 1), wc1 = min(max(w1, 0), W[b] - 1);
-        v[b][0] = *reinterpret_cast<const f32x4 *>(vbase[b] + ((long)hc0 * W[b] + wc0) * rowstride);
-        v[b][1] = *reinterpret_cast<const f32x4 *>(vbase[b] + ((long)hc0 * W[b] + wc1) * rowstride);
-        v[b][2] = *reinterpret_cast<const f32x4 *>(vbase[b] + ((long)hc1 * W[b] + wc0) * rowstride);
-        v[b][3] = *reinterpret_cast<const f32x4 *>(vbase[b] + ((long)hc1 * W[b] + wc1) * rowstride);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        acc += (cw[b][0] * v[b][0] + cw[b][1] * v[b][1] + cw[b][2] * v[b][2] + cw[b][3] * v[b][3]) * aw[b];
 }
 
 // Drop-in form: sampling locations and attention weights are inputs (the reference op's signature).
@@ -143,61 +107,6 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
     const int m = (int)((item / dv) % M);
     const int q = (int)(item / ((long)dv * M));
     // which level does query q live on, and where
-    int lq = 0;
-    while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
-    const int qi = q - (int)lv.start[lq];
-    const int qy = qi / lv.W[lq], qx = qi - qy * lv.W[lq];
-    const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
-    const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
-
-    const float *row = oa + ((long)n * S + q) * ldoa;
-    const float *offp = row + m * (LP_ * 2);
-    const float *lgp = row + M * LP_ * 2 + m * LP_;
-    float lg[LP_];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < LP_; ++i) { lg[i] = lgp[i]; mx = fmaxf(mx, lg[i]); }
-    float den = 0.f;
-#pragma unroll
-    for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
-    const float inv = 1.f / den;
-    const long rowstride = ldv;
-    f32x4 acc = f32x4(0.f);
-#pragma unroll
-    for (int i0 = 0; i0 < LP_; i0 += 4) {
-        const float *vb[4];
-        int Hs[4], Ws[4];
-        float hi[4], wi[4], aw[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + b, l = i / P;
-            Hs[b] = lv.H[l]; Ws[b] = lv.W[l];
-            vb[b] = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
-            const float lx = ref_x + offp[2 * i] / (float)Ws[b];       // ms_deform_attn.py:106-109
-            const float ly = ref_y + offp[2 * i + 1] / (float)Hs[b];
-            hi[b] = ly * Hs[b] - 0.5f; wi[b] = lx * Ws[b] - 0.5f; aw[b] = lg[i] * inv;
-        }
-        sample_accum_batch<4>(acc, vb, rowstride, Hs, Ws, hi, wi, aw);
-    }
-    *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
-}
-
-// Head-major mapping of the same arithmetic: one workgroup = QB consecutive queries of ONE head (8 lanes per query), so
-// the bilinear corners of neighbouring queries -- which overlap heavily along an image row -- are re-used out of the
-// CU's 32 KB L1 instead of each being an L2 round trip (the query-major kernel above touches 8 heads x 48 corner rows
-// per wave: ~100 KB per workgroup, no L1 reuse).  Blocks are ordered [query block][head] inside the XCD band.
-template <int LP_, int QB>
-__global__ __launch_bounds__(QB * 8) void msda_fused_hm_kernel(const float *__restrict__ value, int ldv, Levels lv,
-                                                              const float *__restrict__ oa, int ldoa, int S, int M, int L,
-                                                              int P, int blk_per_n, float *__restrict__ out)
-{
-    constexpr int D = 32, V = 4, dv = D / V;
-    const int n = blockIdx.y;
-    const int bid = xcd_band(blockIdx.x, blk_per_n);
-    const int m = bid % M;
-    const int q = (bid / M) * QB + (int)(threadIdx.x / dv);
-    const int c = threadIdx.x % dv;
-    if (q >= S) return;
     int lq = 0;
     while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
     const int qi = q - (int)lv.start[lq];
@@ -348,25 +257,10 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
     if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
     if (D != 32 || L * P != 12 || ldoa < M * L * P * 3 || ldv < M * D || (ldv & 3)) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
     if (N <= 0) return S2D_OK;
-    static const int hm = getenv("S2D_MSDA_HM") ? atoi(getenv("S2D_MSDA_HM")) : 0;
-    if (hm == 32) {
-        const int nb = cdiv(S, 32) * M;
-        hipLaunchKernelGGL((msda_fused_hm_kernel<12, 32>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M,
-                           L, P, nb, out);
-    } else if (hm == 16) {
-        const int nb = cdiv(S, 16) * M;
-        hipLaunchKernelGGL((msda_fused_hm_kernel<12, 16>), dim3(nb, N), dim3(128), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M,
-                           L, P, nb, out);
-    } else if (hm == 64) {
-        const int nb = cdiv(S, 64) * M;
-        hipLaunchKernelGGL((msda_fused_hm_kernel<12, 64>), dim3(nb, N), dim3(512), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M,
-                           L, P, nb, out);
-    } else {
-        const long items = (long)S * M * 8;
-        const int nb = cdiv(items, 256);
-        hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L,
-                           P, nb, out);
-    }
+    const long items = (long)S * M * 8;
+    const int nb = cdiv(items, 256);
+    hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L,
+                       P, nb, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
