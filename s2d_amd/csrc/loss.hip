@@ -595,6 +595,8 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     constexpr int TIECAP = 512;
     __shared__ unsigned int tie_n, tie_base, wtie[LTHREADS / 64];
     __shared__ int tie_idx[TIECAP], tie_sorted[TIECAP];
+    __shared__ int cq_idx[LTHREADS / 64][128];
+    __shared__ float cq_val[LTHREADS / 64][128];
     const int rows_l = p.B * p.maxm * p.T;
     const int nrows = min(p.lcount[p.NL], p.xcap);
     const long HW = (long)p.H * p.W;
@@ -636,17 +638,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
             const int cnt = over ? p.n_over : p.n_rand;
             const float *xs = xb + (over ? 0 : p.n_over);
-            auto one_point = [&](int i, float xv) {
-                bool sel = true;
-                if (over) {
-                    const unsigned int key = __float_as_uint(fabsf(xv));
-                    sel = key < thr;
-                    if (key == thr) {
-                        const unsigned int slot = atomicAdd(&tie_n, 1u);
-                        if (slot < TIECAP) tie_idx[slot] = i;
-                    }
-                }
-                if (!sel) return;
+            auto heavy = [&](int i, float xv) {           // one selected point: regenerate (u,v), sample the target bits
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else {
@@ -655,16 +647,69 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
                 acc_point(xv, sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
             };
+            // Only ~1 in 4 oversampled points passes the threshold, scattered over the lanes: evaluating them in place
+            // would run the heavy path at 25 % lane utilisation.  Each wave instead compacts its selected points (ballot
+            // + prefix count) into a small LDS queue and evaluates a full wave of 64 whenever one is ready; the order is
+            // a function of the point indices only, so the sums stay reproducible.
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            int *qi = cq_idx[wv];
+            float *qx = cq_val[wv];
+            int qn = 0;                                   // wave-uniform
+            auto push = [&](bool sel, int i, float xv) {
+                const unsigned long long m = __ballot(sel);
+                if (sel) {
+                    const int pos = qn + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    qi[pos] = i; qx[pos] = xv;
+                }
+                qn += (int)__popcll(m);
+                if (qn >= 64) {
+                    heavy(qi[lane], qx[lane]);
+                    const int rest = qn - 64;             // < 64
+                    int ti = 0; float tx = 0.f;
+                    if (lane < rest) { ti = qi[64 + lane]; tx = qx[64 + lane]; }
+                    if (lane < rest) { qi[lane] = ti; qx[lane] = tx; }
+                    qn = rest;
+                }
+            };
+            auto test = [&](int i, float xv, bool live) {
+                bool sel = live;
+                if (over) {
+                    const unsigned int key = __float_as_uint(fabsf(xv));
+                    sel = live && key < thr;
+                    if (live && key == thr) {
+                        const unsigned int slot = atomicAdd(&tie_n, 1u);
+                        if (slot < TIECAP) tie_idx[slot] = i;
+                    }
+                }
+                push(sel, i, xv);
+            };
             // the stored logits are streamed 16 B per lane (4 consecutive points), two loads in flight: with one
             // workgroup per CU the loop is bound by the round trip of each load, not by bandwidth
             const int cnt4 = ((reinterpret_cast<uintptr_t>(xs) & 15) == 0) ? cnt >> 2 : 0;
-#pragma unroll 2
-            for (int i4 = threadIdx.x; i4 < cnt4; i4 += LTHREADS) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
+            const int it4 = (cnt4 + LTHREADS - 1) / LTHREADS;         // uniform trip counts: ballots need whole waves
+            auto load4 = [&](int k) {
+                const int i4 = k * LTHREADS + threadIdx.x;
+                f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+                if (i4 < cnt4) x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
+                return x4;
+            };
+            f32x4 nx0 = load4(0), nx1 = load4(1);                  // two loads ahead of the consumer
+            for (int k = 0; k < it4; ++k) {
+                const int i4 = k * LTHREADS + threadIdx.x;
+                const bool live = i4 < cnt4;
+                const f32x4 x4 = nx0;
+                nx0 = nx1;
+                nx1 = load4(k + 2);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) one_point(4 * i4 + j, x4[j]);
+                for (int j = 0; j < 4; ++j) test(4 * i4 + j, x4[j], live);
             }
-            for (int i = 4 * cnt4 + threadIdx.x; i < cnt; i += LTHREADS) one_point(i, xs[i]);
+            const int tail0 = 4 * cnt4, itt = (cnt - tail0 + LTHREADS - 1) / LTHREADS;
+            for (int k = 0; k < itt; ++k) {
+                const int i = tail0 + k * LTHREADS + threadIdx.x;
+                const bool live = i < cnt;
+                test(i, live ? xs[i] : 0.f, live);
+            }
+            if (lane < qn) heavy(qi[lane], qx[lane]);     // drain
         }
         __syncthreads();
         const unsigned int nties = tie_n;
@@ -869,7 +914,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.xbuf = (float *)w;
     // samples are kept only when the target plane fits LDS as bits and vector loads line up
-    const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 150 * 1024);
+    const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 140 * 1024);   // + ~13 KB of static LDS (queues, tie lists) under the 160 KB of a CU
     p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
     if (s2d_zero_async(p.hist, (size_t)rows * 2048 * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     if (s2d_zero_async(p.tie, (size_t)rows * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
@@ -888,7 +933,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
