@@ -1,4 +1,5 @@
-"""fused MSDA at the c4 pyramid: query-major vs head-major mapping (S2D_MSDA_HM=16|32|64)"""
+"""timing harness for the fused MSDA launch at the c4 pyramid (used for the head-major / branch-free / LDS-staged
+experiments recorded in DESIGN.md section 5; the shipped kernel is the direct gather)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,4 +17,4 @@ def t(n=10):
     for _ in range(n): y = ops.msda_fused_forward(value, np.array(shapes), oa)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n, y
 dt, y = t()
-print(f"HM={os.environ.get('S2D_MSDA_HM','0')}: {dt*1e3:.3f} ms  checksum {float(y.double().sum()):.6f} {float(y.abs().max()):.6f}", flush=True)
+print(f"msda_fused_forward: {dt*1e3:.3f} ms  checksum {float(y.double().sum()):.6f} {float(y.abs().max()):.6f}", flush=True)
