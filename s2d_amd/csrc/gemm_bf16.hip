@@ -862,11 +862,21 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     }
     // 256-row tiles only when they still fill the chip
     if (f16) {
-        // measured: the 16-waves/CU 128x64 kernel wins on the GEMMs / 1x1 convs (K <= 2048, epilogue- and
-        // latency-heavy), the 128x128 kernel (32 flop/B from L2) on the K >= 576 spatial convolutions
+        // measured (scripts/mb_shapes.py, mb_pipe.py): the pipelined 128x128 kernel wins on the spatial convolutions and, once
+        // the weights arrive pre-split, on the GEMMs with K >= 512 (+9..23 %) and on K = 256 when 128-wide tiles waste no
+        // more columns than 64-wide ones; the 16-waves/CU 128x64 kernel keeps the short-K (<= 128: two to four k-steps,
+        // all prologue/epilogue), narrow (N <= 64) and dynamic-B launches
         static int hi = -1;
         if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }
-        const bool use_hi = hi == 2 ? (!(conv && p.KH > 1) || p.N <= 64) : hi == 1;   // N <= 64: half a 128-wide tile would idle
+        bool use_hi;
+        if (hi != 2) use_hi = hi == 1;
+        else if (conv && p.KH > 1) use_hi = p.N <= 64;     // N <= 64: half a 128-wide tile would idle
+        else if (p.N <= 64 || p.K <= 128 || !p.Bsplit) use_hi = true;
+        else if (p.K >= 512) use_hi = false;
+        else {
+            const float w128 = (float)(cdiv(p.N, 128) * 128) / p.N, w64 = (float)(cdiv(p.N, 64) * 64) / p.N;
+            use_hi = w128 > w64 + 0.1f;
+        }
         if (use_hi) return conv ? launch_f16_hi<true>(p, batch, st) : launch_f16_hi<false>(p, batch, st);
         static int pipe = -1;
         if (pipe < 0) { const char *e = getenv("S2D_GEMM_PIPE"); pipe = e ? atoi(e) : 1; }   // measured +6..12 %
