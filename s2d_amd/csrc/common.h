@@ -24,6 +24,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // kernel is an ordinary dispatch in the stream's queue.  (elem.hip)
 int s2d_zero_async(void *p, size_t bytes, hipStream_t stream);
 
+// stable LSD radix sort of (key, value) pairs on bits [0, end_bit) (sort.hip)
+int s2d_radix_sort_pairs_u32(const unsigned int *keys_in, unsigned int *keys_out, const unsigned int *vals_in, unsigned int *vals_out,
+                             size_t n, int end_bit, void *temp, size_t temp_bytes, hipStream_t stream);
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float wave_sum(float v)
 {

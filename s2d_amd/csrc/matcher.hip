@@ -69,15 +69,14 @@ struct CostParams {
 };
 
 constexpr int CHM = 16;      // blocks per (problem, frame) pair; they walk the sorted points together (interleaved batches)
-constexpr int BANDS = 16;    // buckets per radix pass of the row sort (2 passes: 256 >= hm rows)
 
-// ---- points: generation (RNG mode) and a stable sort by logit-map row ---------------------------------------
+// ---- points: generation (RNG mode) and a stable sort by logit-map cell -----------------------------------------
 // The P points of a problem are i.i.d. uniform; every cost term is a SUM over points, so the order is free.
-// They are sorted by the row of the mask-logit map they fall on (stable 2-pass LSD radix sort, 4 bits per pass,
-// each pass a count + an ordered-ballot fill: deterministic).  The CHM blocks of one (problem, frame) pair run on
-// one XCD and walk this list together, so the ~3 logit rows (128 KB each) and target rows they are sampling at
-// any moment are fetched from HBM once and shared through that XCD's L2, instead of every bilinear corner being
-// an L2 miss on the 188 MB per-problem logit tensor (measured before: 12 % L2 hit rate, 47 GB fetched per launch).
+// They are sorted by the cell of the mask-logit map their upper-left tap falls in (stable LSD radix sort of
+// (problem * cells + cell, index) pairs, sort.hip: deterministic).  The CHM blocks of one (problem, frame) pair run on one
+// XCD and walk this list together, so the few logit rows and target rows they are sampling at any moment are fetched from
+// HBM once and shared through that XCD's L2 (measured before any sorting: 12 % L2 hit rate, 47 GB fetched per launch),
+// and each 32-point batch touches one short run of pixels that the f16 kernel stages in LDS.
 __global__ void gen_points_kernel(float *__restrict__ out, uint64_t seed, int P)
 {
     const int prob = blockIdx.y;
@@ -89,56 +88,29 @@ __global__ void gen_points_kernel(float *__restrict__ out, uint64_t seed, int P)
     out[((long)prob * P + i) * 2 + 1] = v;
 }
 
-__device__ __forceinline__ int band_of(float v, int rows, int shift)
+// sort key of a point: the logit-map cell of its upper-left bilinear tap (clamped into the map), problem-major
+__global__ __launch_bounds__(256) void cell_key_kernel(const float *__restrict__ coords, int P, int hm, int wm, unsigned int *__restrict__ keys,
+                                                       unsigned int *__restrict__ vals)
 {
-    const int r = min(rows - 1, max(0, (int)(v * rows)));
-    return (r >> shift) & (BANDS - 1);
+    const int prob = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const long g = (long)prob * P + i;
+    const float u = coords[2 * g], v = coords[2 * g + 1];
+    const float fx = ((2.f * u - 1.f + 1.f) * wm - 1.f) * 0.5f, fy = ((2.f * v - 1.f + 1.f) * hm - 1.f) * 0.5f;   // as bil_setup
+    const int cx = min(max((int)floorf(fx), 0), wm - 1), cy = min(max((int)floorf(fy), 0), hm - 1);
+    keys[g] = (unsigned int)prob * (unsigned int)(hm * wm) + (unsigned int)(cy * wm + cx);
+    vals[g] = (unsigned int)g;
 }
 
-__global__ __launch_bounds__(256) void band_count_kernel(const float *__restrict__ in, int P, int rows, int shift,
-                                                         int *__restrict__ counts)
+__global__ __launch_bounds__(256) void gather_points_kernel(const float *__restrict__ coords, const unsigned int *__restrict__ vals, long n,
+                                                            float *__restrict__ out)
 {
-    const int band = blockIdx.x, prob = blockIdx.y;
-    const float *c = in + (long)prob * P * 2;
-    int n = 0;
-    for (int i = threadIdx.x; i < P; i += 256) n += band_of(c[2 * i + 1], rows, shift) == band;
-    __shared__ int red[4];
-    int w = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[prob * BANDS + band] = red[0] + red[1] + red[2] + red[3];
-}
-
-// stable: members of a band keep their original relative order (ordered ballot compaction)
-__global__ __launch_bounds__(256) void band_fill_kernel(const float *__restrict__ in, int P, int rows, int shift,
-                                                        const int *__restrict__ counts, float *__restrict__ out)
-{
-    const int band = blockIdx.x, prob = blockIdx.y;
-    const float *c = in + (long)prob * P * 2;
-    float *o = out + (long)prob * P * 2;
-    int base = 0;
-    for (int k = 0; k < band; ++k) base += counts[prob * BANDS + k];
-    __shared__ int wcnt[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i0 = 0; i0 < P; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        float u = 0.f, v = 0.f;
-        bool mine = false;
-        if (i < P) { u = c[2 * i]; v = c[2 * i + 1]; mine = band_of(v, rows, shift) == band; }
-        const unsigned long long m = __ballot(mine);
-        if (lane == 0) wcnt[wv] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; ++w) off += wcnt[w];
-        if (mine) {
-            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-            o[2 * pos] = u; o[2 * pos + 1] = v;
-        }
-        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-    }
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const unsigned int src = vals[j];
+    out[2 * j] = coords[2L * src];
+    out[2 * j + 1] = coords[2L * src + 1];
 }
 
 template <int NT>
@@ -283,17 +255,23 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
     lo = __builtin_bit_cast(unsigned int, l);
 }
 
+constexpr int SPANMAX = 24;     // staged logit rows per tap row (upper / lower): a 32-point batch spans ~12 cells at S2D density
 __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
 {
     constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
     constexpr int TROW = 20;                               // words per target row: 16 data (32 fp16) + 4 pad
-    // The kernel is bound by gather latency (2 waves/SIMD), so a batch's 64 logit gathers and 16 target gathers per lane
-    // are all issued before anything consumes them, and the loop has ONE barrier per batch: the tap tables live in a
-    // ring of 3 (batch i: query side in use; batch i+1: target gathers in flight; batch i+2: being set up by two
-    // half-waves from coordinates loaded at the top of the iteration), the target tile in a ring of 2.
+    // The points arrive sorted by the logit-map cell they fall in (cell_key_kernel + radix sort), so the 32 points of a
+    // batch touch a short run of consecutive pixels [cmin, cmax+1] in the row of their upper taps and the same run one
+    // row below.  Those ~2 x 14 pixel rows (Q logits each) are copied into LDS once per batch -- coalesced 16-B loads
+    // issued one batch ahead -- and the 64 taps a lane needs are LDS reads: a batch costs ~28 row fetches from L2 instead of
+    // 128, and no lane waits on a gather.  A batch whose run is longer than SPANMAX (sparse or injected points) takes the
+    // direct-gather path.  One barrier per batch: tap tables in a ring of 3 (batch i in use, i+1 target gathers and row
+    // loads in flight, i+2 being set up), staged rows and target tile in rings of 2.
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];          // [2][2 * SPANMAX][128]
     __shared__ __attribute__((aligned(16))) unsigned int Th[2][TN][TROW], Tl[2][TN][TROW];
     __shared__ __attribute__((aligned(16))) int bqi[3][SB][4], bti[3][SB][4];      // per sample: 4 tap offsets / weights,
     __shared__ __attribute__((aligned(16))) float bqw[3][SB][4], btw[3][SB][4];   // read back as one 16-B LDS load each
+    __shared__ int bmeta[3][4];                                                  // cmin, span, staged
     __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
@@ -305,12 +283,14 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     if (N == 0 || N > 32) return;                           // N > 32: matcher_cost_kernel<4>
     const int q = wv * 32 + l32;
     // Rows q >= Q and target columns >= N are computed on clamped (valid) data and never read by the finalize kernel:
-    // a row of the contraction depends on its own query only, a column on its own target only.  All gathers are buffer
-    // loads with 32-bit byte offsets (tap offset from LDS + a per-lane constant: one v_add per load, no 64-bit math).
+    // a row of the contraction depends on its own query only, a column on its own target only.  All global accesses are
+    // buffer loads with 32-bit byte offsets.
     const long mapf = (long)p.hm * p.wm * p.ldq;
+    const int npix = p.hm * p.wm;
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.ml + ((long)prob * p.T + t) * mapf), 0, (int)(mapf * 4), 0x00020000);
-    const unsigned int q4 = (unsigned int)(q < p.Q ? q : 0) * 4u;
+    const int qr = q < p.Q ? q : 0;
+    const unsigned int q4 = (unsigned int)qr * 4u;
     const long tplane = (long)p.T * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W), 0,
@@ -321,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     // tap setup: lanes 0..31 of wave 0 do the logit-map side of sample l32, lanes 0..31 of wave 1 the target side
     const bool setq = tid < SB, sett = tid >= 64 && tid < 64 + SB;
+    const int l4 = p.ldq >> 2;
 
     f32x16 aAm, aAx, aDm, aDx;
 #pragma unroll
@@ -328,17 +309,39 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     float relusum = 0.f, lg2sum = 0.f, sgsum = 0.f, tsum = 0.f;
 
     // out-of-image corners (zero padding): the offset is clamped to a valid element and the weight zeroed, so every
-    // gather is unconditional
+    // access is unconditional
     auto setup = [&](int buf, float u, float v, bool tail) {
-        if (setq) {
+        if (tid < 64) {                                     // wave 0: lanes 0..31 hold a sample each, 32..63 are neutral
             const Bil a = bil_setup(u, v, p.hm, p.wm);
-            const int rowb = p.ldq * 4;      // byte offsets into the (problem, frame) logit map
-            const i32x4 o = {a.i00 < 0 ? 0 : a.i00 * rowb, a.i01 < 0 ? 0 : a.i01 * rowb, a.i10 < 0 ? 0 : a.i10 * rowb,
-                             a.i11 < 0 ? 0 : a.i11 * rowb};
-            const f32x4 w = {(a.i00 < 0 || tail) ? 0.f : a.w00, (a.i01 < 0 || tail) ? 0.f : a.w01,
-                             (a.i10 < 0 || tail) ? 0.f : a.w10, (a.i11 < 0 || tail) ? 0.f : a.w11};
-            *reinterpret_cast<i32x4 *>(bqi[buf][l32]) = o;
-            *reinterpret_cast<f32x4 *>(bqw[buf][l32]) = w;
+            const float fx = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f, fy = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+            const int cx = min(max((int)floorf(fx), 0), p.wm - 1), cy = min(max((int)floorf(fy), 0), p.hm - 1);
+            const bool mine = setq && !tail;
+            int cmin = mine ? cy * p.wm + cx : 0x7fffffff, cmax = mine ? cy * p.wm + cx : -1;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { cmin = min(cmin, __shfl_xor(cmin, o, 64)); cmax = max(cmax, __shfl_xor(cmax, o, 64)); }
+            if (cmax < 0) { cmin = 0; cmax = 0; }            // all-tail batch
+            const int span = cmax - cmin + 2;
+            const bool staged = span <= SPANMAX;
+            if (setq) {
+                const int ii[4] = {a.i00, a.i01, a.i10, a.i11};
+                const float ww[4] = {a.w00, a.w01, a.w10, a.w11};
+                i32x4 o; f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool ok = ii[e] >= 0 && !tail;
+                    int off = 0;
+                    if (staged) {                            // float offset of the tap's pixel row in the staged block
+                        const int d = ii[e] - cmin, d2 = d - p.wm;
+                        if (d >= 0 && d < span) off = d * 128;
+                        else if (d2 >= 0 && d2 < span) off = (span + d2) * 128;
+                        else ok = false;                     // cannot happen for a valid tap; keep it harmless
+                    } else off = ii[e] < 0 ? 0 : ii[e] * (p.ldq * 4);      // byte offset into the (problem, frame) logit map
+                    o[e] = off; w[e] = ok ? ww[e] : 0.f;
+                }
+                *reinterpret_cast<i32x4 *>(bqi[buf][l32]) = o;
+                *reinterpret_cast<f32x4 *>(bqw[buf][l32]) = w;
+                if (tid == 0) { bmeta[buf][0] = cmin; bmeta[buf][1] = span; bmeta[buf][2] = staged ? 1 : 0; }
+            }
         } else if (sett) {
             const Bil d = bil_setup(u, v, p.H, p.W);
             const i32x4 o = {max(d.i00, 0), max(d.i01, 0), max(d.i10, 0), max(d.i11, 0)};
@@ -346,6 +349,24 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
                              (d.i10 < 0 || tail) ? 0.f : d.w10, (d.i11 < 0 || tail) ? 0.f : d.w11};
             *reinterpret_cast<i32x4 *>(bti[buf][l32]) = o;
             *reinterpret_cast<f32x4 *>(btw[buf][l32]) = w;
+        }
+    };
+    // staged logit rows of a batch: global -> LDS directly (buffer_load ... lds, 16 B per lane, no registers): one wave
+    // instruction fills two 512-B LDS rows (lanes 0..31 / 32..63; ldq / 4 <= 32 float4s of each are real data)
+    auto rows_dma = [&](int tb, int buf) {
+        const int cmin = bmeta[tb][0], span = bmeta[tb][1];
+        if (!bmeta[tb][2]) return;
+        const int c4 = lane & 31;
+#pragma unroll
+        for (int r = 0; r < SPANMAX / 4; ++r) {
+            const int rp = wv * (SPANMAX / 4) + r;           // row pair 0 .. SPANMAX-1
+            if (2 * rp >= 2 * span) break;                   // wave-uniform
+            const int row = 2 * rp + (lane >> 5);
+            const int pix = cmin + row + (row >= span ? p.wm - span : 0);
+            const bool ok = row < 2 * span && pix < npix && c4 < l4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsM, (__attribute__((address_space(3))) void *)(rowbuf + ((long)buf * 2 * SPANMAX + 2 * rp) * 128), 16,
+                ok ? (pix * p.ldq + c4 * 4) * 4 : (int)0xFFFFFFF0u, 0, 0, 0);
         }
     };
     // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and stores them
@@ -388,8 +409,11 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         __syncthreads();
         unsigned char tv[SPT][4];
         target_gather(0, tv);
+        rows_dma(0, 0);
         target_tile(0, 0, tv);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // rows [0] visible
     int r0 = 0, cur = 0;                                    // r0 = i % 3, cur = i & 1
     for (int base = base0; base < p.P; base += bstep, cur ^= 1, r0 = (r0 == 2 ? 0 : r0 + 1)) {
         const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
@@ -398,51 +422,66 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         load_uv(base + 2 * bstep, un, vn, tailn);
         unsigned char tv[SPT][4];
         target_gather(r1, tv);                              // batch i+1 (all-tail tables past the end: offsets 0)
+        rows_dma(r1, cur ^ 1);                              // batch i+1's logit rows -> rows [cur^1] (last read before the previous barrier)
         // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
-        float m[16][4];
-#pragma unroll
-        for (int s16 = 0; s16 < 16; ++s16) {
-            const int k = 16 * (s16 >> 3) + 8 * h + (s16 & 7);
-            const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][k]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                m[s16][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, (int)((unsigned int)qi[e] + q4), 0, 0));
-        }
+        const bool staged_now = bmeta[r0][2] != 0;
+        const float *rb = rowbuf + (long)cur * 2 * SPANMAX * 128 + qr;
         // softplus(x) = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)): the two sums are kept apart and ln2 is applied once.
         // A tail sample (zero tap weights) has x == 0 exactly; only the one partial batch of a chunk pays for the masks.
         unsigned int xh[2][4], xl[2][4], gh[2][4], gl[2][4];
-        auto query_side = [&](auto masked) {
+        auto query_half = [&](int st, auto masked, auto staged) {
+            float m[8][4];                                   // direct-gather path: this half's 32 taps in flight together
+            if constexpr (!decltype(staged)::value) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][16 * st + 8 * h + s8]);
 #pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    float xv[2], sv[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int s16 = 8 * st + 2 * jp + e, k = 16 * st + 8 * h + 2 * jp + e;
-                        const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
-                        const float x = fmaf(m[s16][3], qw[3], fmaf(m[s16][2], qw[2], fmaf(m[s16][1], qw[1], m[s16][0] * qw[0])));
-                        const float ex = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
-                        const float den = 1.f + ex;
-                        const float inv = __builtin_amdgcn_rcpf(den);
-                        float sgm = x >= 0.f ? inv : ex * inv;
-                        float lg = __builtin_amdgcn_logf(den);
-                        if constexpr (decltype(masked)::value) {
-                            const float liveq = k < nvalid ? 1.f : 0.f;
-                            sgm *= liveq; lg *= liveq;
-                        }
-                        relusum += fmaxf(x, 0.f);
-                        lg2sum += lg;
-                        sgsum += sgm;
-                        xv[e] = x; sv[e] = sgm;
-                    }
-                    split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
-                    split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
+                    for (int e = 0; e < 4; ++e)
+                        m[s8][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, (int)((unsigned int)qi[e] + q4), 0, 0));
                 }
+            }
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                float xv[2], sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int s8 = 2 * jp + e, k = 16 * st + 8 * h + s8;
+                    const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
+                    float m0, m1, m2, m3;
+                    if constexpr (decltype(staged)::value) {
+                        const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][k]);
+                        m0 = rb[qi[0]]; m1 = rb[qi[1]]; m2 = rb[qi[2]]; m3 = rb[qi[3]];
+                    } else { m0 = m[s8][0]; m1 = m[s8][1]; m2 = m[s8][2]; m3 = m[s8][3]; }
+                    const float x = fmaf(m3, qw[3], fmaf(m2, qw[2], fmaf(m1, qw[1], m0 * qw[0])));
+                    const float ex = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
+                    const float den = 1.f + ex;
+                    const float inv = __builtin_amdgcn_rcpf(den);
+                    float sgm = x >= 0.f ? inv : ex * inv;
+                    float lg = __builtin_amdgcn_logf(den);
+                    if constexpr (decltype(masked)::value) {
+                        const float liveq = k < nvalid ? 1.f : 0.f;
+                        sgm *= liveq; lg *= liveq;
+                    }
+                    relusum += fmaxf(x, 0.f);
+                    lg2sum += lg;
+                    sgsum += sgm;
+                    xv[e] = x; sv[e] = sgm;
+                }
+                split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
+                split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
+            }
         };
-        if (nvalid == SB) query_side(std::false_type{}); else query_side(std::true_type{});
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (staged_now) {
+                if (nvalid == SB) query_half(st, std::false_type{}, std::true_type{}); else query_half(st, std::true_type{}, std::true_type{});
+            } else {
+                if (nvalid == SB) query_half(st, std::false_type{}, std::false_type{}); else query_half(st, std::true_type{}, std::false_type{});
+            }
+        }
         setup(r2, un, vn, tailn);
-        __syncthreads();  // target tile [cur] (written last iteration) and taps [r2] complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target gathers) have landed
+        __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1] and taps [r2] complete
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[cur][l32][8 * st + 4 * h]);
@@ -641,8 +680,9 @@ extern "C" {
 
 long s2d_matcher_workspace_floats(int NL, int B, int T, int P)
 {
-    const long nprob = (long)NL * B, ch = (long)T * CHM;
-    return nprob * ch * (2L * QP * NP + 3 * 128) + 6L * nprob * P + nprob * BANDS + 64;
+    const long nprob = (long)NL * B, ch = (long)T * CHM, n = nprob * P;
+    // partial sums + raw / sorted coordinates + 4 key/value arrays + radix-sort scratch (checked against rocPRIM's need at launch)
+    return nprob * ch * (2L * QP * NP + 3 * 128) + 4 * n + 4 * n + (4 * n + (1L << 20)) + 64;
 }
 
 int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
@@ -660,24 +700,37 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     p.wsA = workspace;
     p.wsD = p.wsA + (long)nprob * p.chunks * QP * NP;
     p.wsV = p.wsD + (long)nprob * p.chunks * QP * NP;
+    const long n = (long)nprob * P;
     float *raw = p.wsV + (long)nprob * p.chunks * 3 * 128;
-    float *sorted = raw + 2L * nprob * P;
-    float *raw2 = sorted + 2L * nprob * P;
-    int *counts = (int *)(raw2 + 2L * nprob * P);
+    float *sorted = raw + 2 * n;
+    unsigned int *keys_in = (unsigned int *)(sorted + 2 * n), *keys_out = keys_in + n, *vals_in = keys_out + n, *vals_out = vals_in + n;
+    void *tmp = vals_out + n;
+    const size_t tmp_bytes = (size_t)(4 * n + (1L << 20)) * 4;
     if (!coords) {
         hipLaunchKernelGGL(gen_points_kernel, dim3(cdiv(P, 256), nprob), dim3(256), 0, stream, raw, seed, P);
         coords = raw;
     }
-    if (hm > 256) return S2D_ERR_ARG;
-    // stable LSD radix sort on the row index: low nibble (coords -> sorted), then high nibble (sorted -> raw)
-    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, hm, 0, counts);
-    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, coords, P, hm, 0, counts, sorted);
-    hipLaunchKernelGGL(band_count_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, sorted, P, hm, 4, counts);
-    hipLaunchKernelGGL(band_fill_kernel, dim3(BANDS, nprob), dim3(256), 0, stream, sorted, P, hm, 4, counts, raw2);
-    p.coords = raw2;
+    // Points are i.i.d. and every cost term is a SUM over points, so their order is free: a stable radix sort by logit-map
+    // cell makes each 32-point batch of the cost kernel touch one short run of pixels (see matcher_cost_f16_kernel).
+    const long nkeys = (long)nprob * hm * wm;
+    if (nkeys >= (1L << 32) || n >= (1L << 31)) return S2D_ERR_ARG;
+    int bits = 1;
+    while ((1L << bits) < nkeys) ++bits;
+    hipLaunchKernelGGL(cell_key_kernel, dim3(cdiv(P, 256), nprob), dim3(256), 0, stream, coords, P, hm, wm, keys_in, vals_in);
+    if (int e = s2d_radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, (size_t)n, bits, tmp, tmp_bytes, stream)) return e;
+    hipLaunchKernelGGL(gather_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, coords, vals_out, n, sorted);
+    p.coords = sorted;
     const int npairs = nprob * T;
     const int grid = ((npairs + 7) / 8) * 8 * CHM;
-    hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), 0, stream, p);
+    const size_t lds_rows = sizeof(float) * 2 * 2 * SPANMAX * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_rows) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), lds_rows, stream, p);
     if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
                        class_logits, w_class, w_mask, w_dice, C);
