@@ -36,14 +36,14 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
 {
     __shared__ uint32_t um[QW];
     const int b = blockIdx.y;
-    const long K = (long)T * hl * wl;
+    const int K = T * hl * wl;                 // < 2^31 (checked on the host): 32-bit index decomposition
     if (threadIdx.x < QW) um[threadIdx.x] = 0u;
     __syncthreads();
     const int g = threadIdx.x & 31;
-    const long key = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int key = blockIdx.x * 8 + (threadIdx.x >> 5);
     uint32_t nib = 0u, valid = 0u;
     if (key < K) {
-        const int x = (int)(key % wl), y = (int)((key / wl) % hl), t = (int)(key / ((long)wl * hl));
+        const int x = key % wl, yy = key / wl, y = yy % hl, t = yy / hl;
         // ATen bilinear source index, align_corners=False
         float sy = ((float)hm / hl) * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
         float sx = ((float)wm / wl) * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
@@ -269,6 +269,7 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
     if (Q > 128 || Q <= 0 || ldq < Q) return S2D_ERR_ARG;
     const long K = (long)T * hl * wl;
     if (B == 0 || K == 0) return S2D_OK;
+    if (K >= (1L << 31) - 8) return S2D_ERR_ARG;
     if (s2d_zero_async(unmasked, sizeof(uint32_t) * QW * B, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_mask_kernel<false>, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl,
                        wl, bits, unmasked);

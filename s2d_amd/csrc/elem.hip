@@ -8,15 +8,19 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // (x - mean) / std, zero-pad to (Hp, Wp), NCHW uint8 -> NHWC float with C padded 3 -> 4
 // kd_video_maskformer_model.py:263-269 (+ detectron2 ImageList.from_tensors zero padding)
+// (the element index is decomposed in the index type I: unsigned 32-bit whenever the tensor allows -- a 64-bit division
+// chain per element costs more than the element's memory traffic)
+template <typename I>
 __global__ void normalize_pad_kernel(const uint8_t *__restrict__ in, int F, int H0, int W0, int Hp, int Wp, f32x4 mean,
                                      f32x4 stdv, float *__restrict__ out)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)F * Hp * Wp;
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const I total = (I)F * Hp * Wp;
     if (i >= total) return;
-    const int x = (int)(i % Wp);
-    const int y = (int)((i / Wp) % Hp);
-    const int f = (int)(i / ((long)Wp * Hp));
+    const int x = (int)(i % (I)Wp);
+    const I r = i / (I)Wp;
+    const int y = (int)(r % (I)Hp);
+    const int f = (int)(r / (I)Hp);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (y < H0 && x < W0) {
         const uint8_t *p = in + ((long)f * 3 * H0 + y) * W0 + x;
@@ -25,22 +29,23 @@ __global__ void normalize_pad_kernel(const uint8_t *__restrict__ in, int F, int 
         v[1] = ((float)p[cs] - mean[1]) / stdv[1];
         v[2] = ((float)p[2 * cs] - mean[2]) / stdv[2];
     }
-    *reinterpret_cast<f32x4 *>(out + i * 4) = v;
+    *reinterpret_cast<f32x4 *>(out + (long)i * 4) = v;
 }
 
 // 3x3 / stride 2 / pad 1 max pool, NHWC, C % 4 == 0 (detectron2 BasicStem)
+template <typename I>
 __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
                                float *__restrict__ out)
 {
     const int c4n = C / 4;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * Ho * Wo * c4n;
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const I total = (I)N * Ho * Wo * c4n;
     if (i >= total) return;
-    const int c = (int)(i % c4n);
-    long t = i / c4n;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+    const int c = (int)(i % (I)c4n);
+    I t = i / (I)c4n;
+    const int ox = (int)(t % (I)Wo); t /= (I)Wo;
+    const int oy = (int)(t % (I)Ho);
+    const int n = (int)(t / (I)Ho);
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -54,7 +59,7 @@ __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W
             m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
     }
-    *reinterpret_cast<f32x4 *>(out + i * 4) = m;
+    *reinterpret_cast<f32x4 *>(out + (long)i * 4) = m;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -103,30 +108,31 @@ __global__ void gn_reduce_kernel(const double *__restrict__ part, int nblk, int 
 }
 
 // y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
+template <typename I>
 __global__ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, int N, int H, int W, int C, int G, float eps,
                                 const float *__restrict__ up, int hu, int wu, int relu, float *__restrict__ y)
 {
     const int q = C / 4;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * H * W * q;
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const I total = (I)N * H * W * q;
     if (i >= total) return;
-    const int c4 = (int)(i % q);
-    const long pix = i / q;
-    const int n = (int)(pix / ((long)H * W));
+    const int c4 = (int)(i % (I)q);
+    const I pix = i / (I)q;
+    const int n = (int)(pix / ((I)H * W));
     const int g = (c4 * 4) / (C / G);
     const double cnt = (double)H * W * (C / G);
     const double mu = stats[((long)n * G + g) * 2] / cnt;
     const double var = stats[((long)n * G + g) * 2 + 1] / cnt - mu * mu;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mean = (float)mu;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(x + i * 4);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + (long)i * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
     const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4 * 4);
     v = (v - mean) * rstd * ga + be;
     if (up) {
         // F.interpolate(bilinear, align_corners=False) source index rule (msdeformattn.py:349)
-        const int px = (int)(pix % W), py = (int)((pix / W) % H);
+        const int px = (int)(pix % (I)W), py = (int)((pix / (I)W) % (I)H);
         float sy = ((float)hu / H) * (py + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
         float sx = ((float)wu / W) * (px + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
         const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hu - 1 ? 1 : 0), x1 = x0 + (x0 < wu - 1 ? 1 : 0);
@@ -139,7 +145,7 @@ __global__ void gn_apply_kernel(const float *__restrict__ x, const double *__res
         v += hy * (hx * a + lx * b) + ly * (hx * c + lx * d);
     }
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    *reinterpret_cast<f32x4 *>(y + i * 4) = v;
+    *reinterpret_cast<f32x4 *>(y + (long)i * 4) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -187,13 +193,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // y[n][r][:] = x[n][r][:] + b[r % brows][:]   (broadcast add of a [brows, C] table over the batch)
+template <typename I>
 __global__ void add_bcast_kernel(const float *__restrict__ x, const float *__restrict__ b, long n4, long b4,
                                  float *__restrict__ y)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    *reinterpret_cast<f32x4 *>(y + i * 4) =
-        *reinterpret_cast<const f32x4 *>(x + i * 4) + *reinterpret_cast<const f32x4 *>(b + (i % b4) * 4);
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (I)n4) return;
+    *reinterpret_cast<f32x4 *>(y + (long)i * 4) =
+        *reinterpret_cast<const f32x4 *>(x + (long)i * 4) + *reinterpret_cast<const f32x4 *>(b + (long)(i % (I)b4) * 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -269,8 +276,12 @@ int s2d_normalize_pad_nhwc4_f32(const uint8_t *frames, int F, int H0, int W0, in
     const long total = (long)F * Hp * Wp;
     if (total == 0) return S2D_OK;
     f32x4 m = {mean3_host[0], mean3_host[1], mean3_host[2], 0.f}, s = {std3_host[0], std3_host[1], std3_host[2], 1.f};
-    hipLaunchKernelGGL(normalize_pad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, frames, F, H0, W0, Hp, Wp, m,
-                       s, out);
+    if (total < (1L << 31))
+        hipLaunchKernelGGL(normalize_pad_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, frames, F, H0, W0, Hp, Wp,
+                           m, s, out);
+    else
+        hipLaunchKernelGGL(normalize_pad_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, frames, F, H0, W0, Hp, Wp, m, s,
+                           out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -281,7 +292,10 @@ int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float 
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * Ho * Wo * (C / 4);
     if (total == 0) return S2D_OK;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
+    if (total < (1L << 31))
+        hipLaunchKernelGGL(maxpool_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -308,8 +322,12 @@ int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, co
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, (int)HW, C, G, rows_per_blk, part);
     hipLaunchKernelGGL(gn_reduce_kernel, dim3(N), dim3(256), 0, stream, part, nblk, G, stats_ws);
     const long total = (long)N * HW * (C / 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W, C,
-                       G, eps, up, hu, wu, relu, y);
+    if (total < (1L << 31))
+        hipLaunchKernelGGL(gn_apply_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W,
+                           C, G, eps, up, hu, wu, relu, y);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W, C, G,
+                           eps, up, hu, wu, relu, y);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -328,7 +346,10 @@ int s2d_add_bcast_f32(const float *x, const float *b, long n, long bn, float *y,
 {
     if ((n & 3) || (bn & 3) || bn == 0 || n % bn) return S2D_ERR_ARG;
     if (n == 0) return S2D_OK;
-    hipLaunchKernelGGL(add_bcast_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, x, b, n / 4, bn / 4, y);
+    if (n / 4 < (1L << 31))
+        hipLaunchKernelGGL(add_bcast_kernel<unsigned int>, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, x, b, n / 4, bn / 4, y);
+    else
+        hipLaunchKernelGGL(add_bcast_kernel<long>, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, x, b, n / 4, bn / 4, y);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
