@@ -131,8 +131,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("S2D_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N > 1 control flow on one GPU
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    cdev = torch.device("cpu") if world > 1 and os.environ.get("S2D_BENCH_BACKEND", "nccl") != "nccl" else None
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -193,7 +199,7 @@ def main():
         same = torch.equal(a, b)
         if world > 1:                       # all ranks take the same branch (the fallback re-times with barriers)
             import torch.distributed as dist
-            flag = torch.tensor([1 if same else 0], device=dev)
+            flag = torch.tensor([1 if same else 0], device=cdev or dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             same = bool(flag.item())
         if same:
@@ -221,7 +227,7 @@ def main():
                        "(the timed region runs the two networks on two HIP streams; --no-overlap times them live)")
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev or dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     assert bool(torch.isfinite(total)), "non-finite loss"
