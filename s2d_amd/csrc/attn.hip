@@ -96,7 +96,13 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
         if (open) atomicOr(&um[g >> 3], open);
     }
     __syncthreads();
-    if (threadIdx.x < QW && um[threadIdx.x]) atomicOr(&unmasked[b * QW + threadIdx.x], um[threadIdx.x]);
+    // every workgroup of a clip ORs into the same four words: test first, so that once the bits are set (after the first
+    // few workgroups) nobody queues on the L2 atomic unit any more -- a stale read only costs a redundant atomic
+    if (threadIdx.x < QW && um[threadIdx.x]) {
+        const uint32_t want = um[threadIdx.x];
+        const uint32_t have = __hip_atomic_load(&unmasked[b * QW + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((have & want) != want) atomicOr(&unmasked[b * QW + threadIdx.x], want);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
