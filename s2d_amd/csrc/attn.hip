@@ -196,24 +196,27 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qr[4 * g + j], s, 0, 0, 0);
         }
-        // mask + tail, tile max
+        // mask + tail, tile max  (only the last tile of the key range can have a tail: uniform branch)
         float tmax = -INFINITY;
+        const int kleft = p.K - tile * KT;                   // keys of this tile that exist (>= KT except on the last tile)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            bool dead = (long)tile * KT + kr >= p.K;
+            bool dead = kr >= kleft;
             if (use_mask) dead = dead || ((Ms[cur][kr][wv] >> l32) & 1u);
             s[r] = dead ? -INFINITY : s[r];
             tmax = fmaxf(tmax, s[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        // raw v_exp_f32: arguments are <= 0 (or -inf -> 0); results below the normal range flush to zero, which is what a
+        // softmax weight of 2^-126 is worth
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(s[r] - mn);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
             ps += s[r];
         }
         l = l * alpha + ps;
