@@ -106,6 +106,22 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-fp16 helpers (the scheme of gemm_bf16.hip: x = h + l * 2^-11, h = fp16_rtz(x), l = fp16_rtz((x - h) * 2^11))
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_h(const f32x4 v, u32x2 &hi, u32x2 &lo)
+{
+    const h16x2 ha = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), hb = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2 ra = (a - __builtin_convertvector(ha, f32x2)) * 2048.f, rb = (b - __builtin_convertvector(hb, f32x2)) * 2048.f;
+    const h16x2 la = __builtin_amdgcn_cvt_pkrtz(ra[0], ra[1]), lb = __builtin_amdgcn_cvt_pkrtz(rb[0], rb[1]);
+    hi[0] = __builtin_bit_cast(unsigned int, ha); hi[1] = __builtin_bit_cast(unsigned int, hb);
+    lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
+}
+
 struct AttnParams {
     const float *q, *k, *v;      // q [B][Q][C] (projected, unscaled); k, v [B][K][C]
     const uint32_t *bits;        // [B][K][QW] or null
@@ -117,8 +133,13 @@ struct AttnParams {
 
 __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
 {
-    __shared__ __attribute__((aligned(16))) float Ks[2][KT][LSTR];
-    __shared__ __attribute__((aligned(16))) float Vs[2][KT][LSTR];
+    // K tile as split fp16 (row = 16 words hi | 16 words lo | pad): Q.K^T runs on the f16 matrix cores at fp32-class
+    // accuracy (3 x 32 cycles per 16 dims instead of 8 x 64 for the fp32-input MFMA); V stays fp32 for the P.V product
+    __shared__ __attribute__((aligned(16))) unsigned int Ks[2][KT][LSTR];
+    // V tile transposed and split: Vth / Vtl [d][key slot] in fp16, key slots permuted so that the 8 keys a lane holds of P
+    // in the MFMA C layout (16 st + 8 (j >> 2) + 4 h + (j & 3), j = 0..7) are 8 consecutive halves of row d
+    constexpr int VROW = 40;
+    __shared__ __attribute__((aligned(16))) unsigned short Vth[2][32][VROW], Vtl[2][32][VROW];
     __shared__ uint32_t Ms[2][KT][QW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
@@ -126,15 +147,21 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
     const int q = wv * 32 + l32;
     const bool qok = q < p.Q;
 
-    // Q fragment in registers, k-order matched to the K tile reads: element j of group g is dim 8g+4h+j
-    float qr[16];
+    // Q fragment in registers, split: MFMA step st covers dims 16 st .. 16 st + 15, lane half h owns 8 h .. 8 h + 7 of them
+    f16x8 qh[2], ql[2];
     {
-        const float *qp = p.q + ((long)b * p.Q + (qok ? q : 0)) * p.C + hd * 32 + 4 * h;
+        const float *qp = p.q + ((long)b * p.Q + (qok ? q : 0)) * p.C + hd * 32 + 8 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 t = qok ? *reinterpret_cast<const f32x4 *>(qp + 8 * g) : f32x4(0.f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qr[4 * g + j] = t[j] * p.qscale;
+        for (int st = 0; st < 2; ++st) {
+            f32x4 t0 = qok ? *reinterpret_cast<const f32x4 *>(qp + 16 * st) : f32x4(0.f);
+            f32x4 t1 = qok ? *reinterpret_cast<const f32x4 *>(qp + 16 * st + 4) : f32x4(0.f);
+            t0 *= p.qscale; t1 *= p.qscale;
+            u32x2 h0, l0, h1, l1;
+            split4_h(t0, h0, l0);
+            split4_h(t1, h1, l1);
+            const u32x4 hv = {h0[0], h0[1], h1[0], h1[1]}, lv = {l0[0], l0[1], l1[0], l1[1]};
+            qh[st] = __builtin_bit_cast(f16x8, hv);
+            ql[st] = __builtin_bit_cast(f16x8, lv);
         }
     }
     bool use_mask = p.bits != nullptr;
@@ -167,14 +194,25 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
         }
     };
     auto store_tile = [&](int buf) {
-        *reinterpret_cast<f32x4 *>(&Ks[buf][srow][sc4 * 4]) = rk;
-        *reinterpret_cast<f32x4 *>(&Vs[buf][srow][sc4 * 4]) = rv;
+        u32x2 kh, kl;
+        split4_h(rk, kh, kl);
+        *reinterpret_cast<u32x2 *>(&Ks[buf][srow][sc4 * 2]) = kh;
+        *reinterpret_cast<u32x2 *>(&Ks[buf][srow][16 + sc4 * 2]) = kl;
+        u32x2 vh, vl;
+        split4_h(rv, vh, vl);
+        const int k16 = srow & 15;
+        const int pos = (srow >> 4) * 16 + ((k16 >> 2) & 1) * 8 + (((k16 >> 3) << 2) | (k16 & 3));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vth[buf][sc4 * 4 + e][pos] = (unsigned short)(vh[e >> 1] >> (16 * (e & 1)));
+            Vtl[buf][sc4 * 4 + e][pos] = (unsigned short)(vl[e >> 1] >> (16 * (e & 1)));
+        }
         if (p.bits && tid < KT * QW) Ms[buf][tid >> 2][tid & 3] = rm;
     };
 
-    f32x16 o;
+    f32x16 o, ox;                                    // main / cross accumulators of O^T
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { o[r] = 0.f; ox[r] = 0.f; }
     float m = -1e30f, l = 0.f;
 
     if (tile0 < tile1) {
@@ -186,16 +224,20 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
         const int cur = (tile - tile0) & 1;
         if (tile + 1 < tile1) load_tile(tile + 1);
 
-        // S^T[key][q] = sum_d K[key][d] * Q[q][d]
-        f32x16 s;
+        // S^T[key][q] = sum_d K[key][d] * Q[q][d]   (split-fp16 x3: main + cross / 2^11)
+        f32x16 s, sx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; sx[r] = 0.f; }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 kf = *reinterpret_cast<const f32x4 *>(&Ks[cur][l32][8 * g + 4 * h]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qr[4 * g + j], s, 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+            const f16x8 kh = *reinterpret_cast<const f16x8 *>(&Ks[cur][l32][8 * st + 4 * h]);
+            const f16x8 kl = *reinterpret_cast<const f16x8 *>(&Ks[cur][l32][16 + 8 * st + 4 * h]);
+            sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], sx, 0, 0, 0);
+            sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], sx, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += sx[r] * (1.0f / 2048.0f);
         // mask + tail, tile max  (only the last tile of the key range can have a tail: uniform branch)
         float tmax = -INFINITY;
         const int kleft = p.K - tile * KT;                   // keys of this tile that exist (>= KT except on the last tile)
@@ -221,12 +263,25 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
         }
         l = l * alpha + ps;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        // O^T[d][q] += sum_key V[key][d] * P[q][key];   lane half h owns keys (r&3)+8(r>>2)+4h
+        for (int r = 0; r < 16; ++r) { o[r] *= alpha; ox[r] *= alpha; }
+        // O^T[d][q] += sum_key V[key][d] * P[q][key]: the lane's own 8 probabilities of step st are the B fragment
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][kr][l32], s[r], o, 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+            u32x4 phv, plv;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                const float a = s[8 * st + 2 * jp], bq = s[8 * st + 2 * jp + 1];
+                const h16x2 hh = __builtin_amdgcn_cvt_pkrtz(a, bq);
+                const h16x2 ll = __builtin_amdgcn_cvt_pkrtz((a - (float)hh[0]) * 2048.f, (bq - (float)hh[1]) * 2048.f);
+                phv[jp] = __builtin_bit_cast(unsigned int, hh);
+                plv[jp] = __builtin_bit_cast(unsigned int, ll);
+            }
+            const f16x8 ph = __builtin_bit_cast(f16x8, phv), pl = __builtin_bit_cast(f16x8, plv);
+            const f16x8 vth = *reinterpret_cast<const f16x8 *>(&Vth[cur][l32][16 * st + 8 * h]);
+            const f16x8 vtl = *reinterpret_cast<const f16x8 *>(&Vtl[cur][l32][16 * st + 8 * h]);
+            ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vtl, ph, ox, 0, 0, 0);
+            ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vth, pl, ox, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vth, ph, o, 0, 0, 0);
         }
         if (tile + 1 < tile1) store_tile(cur ^ 1);
         __syncthreads();
@@ -240,7 +295,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
-        p.wo[(pidx * 32 + d) * 128 + q] = o[r];
+        p.wo[(pidx * 32 + d) * 128 + q] = o[r] + ox[r] * (1.0f / 2048.0f);
     }
 }
 
@@ -289,7 +344,7 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
 long s2d_attn_workspace_floats(int B, int H, int K)
 {
     const int tiles = (K + KT - 1) / KT;
-    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;
+    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;   // 64 / 128 splits measured slower (merge + per-workgroup fixed cost)
     return (long)B * H * S * (32 * 128 + 2 * 128);
 }
 
@@ -299,7 +354,7 @@ int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const ui
     if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0) return S2D_ERR_ARG;
     if (B == 0) return S2D_OK;
     const int tiles = (K + KT - 1) / KT;
-    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;
+    int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;   // 64 / 128 splits measured slower (merge + per-workgroup fixed cost)
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.bits = bits; p.unmasked = unmasked;
     p.Q = Q; p.K = K; p.C = C; p.H = H; p.S = S; p.tiles_per_split = (tiles + S - 1) / S;
