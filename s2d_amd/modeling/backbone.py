@@ -49,7 +49,10 @@ class ConvBN(nn.Module):
             if w.shape[-1] % 4:
                 w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1] % 4))  # stem: Cin 3 -> 4 (input is NHWC4)
             scale, shift = self.norm.fold()
-            self._packed = (key, ops.mark_static(w.contiguous().float()), scale.float(), shift.float())
+            w = w.contiguous().float()
+            if w._base is not None:          # 1x1 kernels: permute + contiguous is still a view of the parameter; own the
+                w = w.clone()                # storage so that views of the packed weight resolve to this (marked) tensor
+            self._packed = (key, ops.mark_static(w), scale.float(), shift.float())
         return self._packed[1:]
 
     def forward(self, x, res=None, relu=True):

@@ -153,7 +153,8 @@ class _ConvGN(nn.Module):
     def packed(self):
         key = (self.weight._version, self.weight.device)
         if self._packed is None or self._packed[0] != key:
-            self._packed = (key, ops.mark_static(self.weight.detach().permute(0, 2, 3, 1).contiguous()))
+            w = self.weight.detach().permute(0, 2, 3, 1).contiguous()
+            self._packed = (key, ops.mark_static(w.clone() if w._base is not None else w))
         return self._packed[1]
 
 
