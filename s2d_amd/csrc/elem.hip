@@ -97,14 +97,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     }
 }
 
-__global__ void gn_reduce_kernel(const double *__restrict__ part, int nblk, int G, double *__restrict__ stats)
+// one wavefront per (n, g): lane l sums partials l, l + 64, ... in that order, then a fixed butterfly -- deterministic
+__global__ __launch_bounds__(64) void gn_reduce_kernel(const double *__restrict__ part, int nblk, int G, double *__restrict__ stats)
 {
-    const int n = blockIdx.x, g = threadIdx.x;
-    if (g >= G) return;
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
     double a = 0., b = 0.;
-    for (int k = 0; k < nblk; ++k) { a += part[(((long)n * nblk + k) * G + g) * 2]; b += part[(((long)n * nblk + k) * G + g) * 2 + 1]; }
-    stats[((long)n * G + g) * 2] = a;
-    stats[((long)n * G + g) * 2 + 1] = b;
+    for (int k = threadIdx.x; k < nblk; k += 64) {
+        a += part[(((long)n * nblk + k) * G + g) * 2];
+        b += part[(((long)n * nblk + k) * G + g) * 2 + 1];
+    }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (threadIdx.x == 0) {
+        stats[((long)n * G + g) * 2] = a;
+        stats[((long)n * G + g) * 2 + 1] = b;
+    }
 }
 
 // y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
@@ -320,7 +326,7 @@ int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, co
     const int nblk = (int)cdiv(HW, (long)rows_per_blk);
     double *part = stats_ws + 2L * N * G;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, (int)HW, C, G, rows_per_blk, part);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(N), dim3(256), 0, stream, part, nblk, G, stats_ws);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(N * G), dim3(64), 0, stream, part, nblk, G, stats_ws);
     const long total = (long)N * HW * (C / 4);
     if (total < (1L << 31))
         hipLaunchKernelGGL(gn_apply_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W,
