@@ -338,6 +338,8 @@ template <int LEVEL>
 __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int hq_idx[LTHREADS / 64][128];
+    __shared__ float hq_y[LTHREADS / 64][128];
     constexpr int nb = LEVEL == 0 ? 2048 : 1024;
     const PartGeom g = part_geom(p.hm, p.wm);
     unsigned int *h = reinterpret_cast<unsigned int *>(smem);
@@ -356,35 +358,53 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
         // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
-        // branch-free and 4-way unrolled: four independent hash -> tap -> key chains per thread hide the LDS latency
-        for (int i0 = threadIdx.x; i0 < p.n_over; i0 += 4 * LTHREADS) {
-            unsigned int key[4];
-            bool own[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = i0 + j * LTHREADS;
-                const int ic = min(i, p.n_over - 1);
-                float u, v;
-                if (cr) { u = cr[2 * ic]; v = cr[2 * ic + 1]; }
-                else {
-                    u = (float)(hash32(key0 + 2u * (uint32_t)ic) >> 8) * (1.0f / 16777216.0f);
-                    v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
-                }
-                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+        // A part owns about half of the row's points (those whose upper tap row falls in it).  Every point is tested with
+        // one hash (its v coordinate); the owned ones are compacted per wave (ballot + LDS queue) and only full waves of
+        // owned points pay for the second hash, the four LDS taps and the histogram update.
+        {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            int *qi = hq_idx[wv];
+            float *qy = hq_y[wv];
+            int qn = 0;                                   // wave-uniform
+            auto heavy = [&](int i, float y) {
+                float u;
+                if (cr) u = cr[2 * i];
+                else u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                const float xv = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), (int)floorf(y));
+                const unsigned int key = __float_as_uint(fabsf(xv));
+                if (LEVEL == 0 && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
+                if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
+                else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
+                else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+            };
+            const int iters = (p.n_over + LTHREADS - 1) / LTHREADS;      // uniform: the ballots need whole waves
+            for (int k = 0; k < iters; ++k) {
+                const int i = k * LTHREADS + threadIdx.x;
+                const bool live = i < p.n_over;
+                const int ic = live ? i : p.n_over - 1;
+                float v;
+                if (cr) v = cr[2 * ic + 1];
+                else v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const int y0 = (int)floorf(y);
-                own[j] = i < p.n_over && y0 >= ylo && y0 < yhi;
-                const float xv = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
-                key[j] = __float_as_uint(fabsf(xv));
-                if (LEVEL == 0 && own[j] && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
+                const bool own = live && y0 >= ylo && y0 < yhi;
+                const unsigned long long m = __ballot(own);
+                if (own) {
+                    const int pos = qn + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    qi[pos] = i; qy[pos] = y;
+                }
+                qn += (int)__popcll(m);
+                if (qn >= 64) {
+                    heavy(qi[lane], qy[lane]);
+                    const int rest = qn - 64;
+                    int ti = 0; float ty = 0.f;
+                    if (lane < rest) { ti = qi[64 + lane]; ty = qy[64 + lane]; }
+                    if (lane < rest) { qi[lane] = ti; qy[lane] = ty; }
+                    qn = rest;
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!own[j]) continue;
-                if (LEVEL == 0) atomicAdd(&h[key[j] >> 20], 1u);
-                else if (LEVEL == 1) { if ((key[j] >> 20) == (pre >> 20)) atomicAdd(&h[(key[j] >> 10) & 1023u], 1u); }
-                else { if ((key[j] >> 10) == (pre >> 10)) atomicAdd(&h[key[j] & 1023u], 1u); }
-            }
+            if (lane < qn) heavy(qi[lane], qy[lane]);
         }
         if (LEVEL == 0 && li < p.xcap) {
             // the extra uniform points (point_features.py:112): sample their logits now too, so that the later passes
