@@ -156,8 +156,11 @@ def main():
     mean, std = model.pixel_mean.flatten().cpu().numpy(), model.pixel_std.flatten().cpu().numpy()
 
     def step():
+        # everything KDVideoMaskFormer.forward does per batch on the device: normalise + pad the frames, paste the GT masks
+        # into padded target planes (prepare_targets), both forwards, both criteria, the weighted sum the trainer takes
         images = ops.normalize_pad(frames, 32, mean, std)
-        losses = model.forward_losses(images, gt)
+        targets = TargetSet.from_list(masks, device=dev)
+        losses = model.forward_losses(images, targets)
         return sum(losses.values())
 
     def seeded_step(two_streams):

@@ -15,6 +15,9 @@ from .. import ops
 from .video_decoder import MaskOutputs
 
 
+_COUNT_CACHE = {}
+
+
 class TargetSet:
     """Device-resident targets of one criterion pass: masks u8 [B,Nmax,T,H,W], count i32 [B] (device),
     nonempty i32 [B,Nmax,T].  `host_counts` is set when the counts are known on the host (ground truth)."""
@@ -30,11 +33,22 @@ class TargetSet:
         ns = [int(m.shape[0]) for m in mask_list]
         T, H, W = mask_list[0].shape[1:]
         Nmax = Nmax or max(max(ns), 1)
-        masks = torch.zeros((B, Nmax, T, H, W), device=device, dtype=torch.uint8)
+        masks = torch.empty((B, Nmax, T, H, W), device=device, dtype=torch.uint8)
         for b, m in enumerate(mask_list):
             if ns[b]:
-                masks[b, :ns[b]] = (m != 0).to(device=device, dtype=torch.uint8)
-        count = torch.tensor(ns, dtype=torch.int32, device=device)
+                mb = m.to(device=device, non_blocking=True)
+                if mb.dtype == torch.uint8:
+                    torch.ne(mb, 0, out=masks[b, :ns[b]].view(torch.bool))    # one pass, no temporary
+                else:
+                    masks[b, :ns[b]] = (mb != 0).to(torch.uint8)
+            if ns[b] < Nmax:
+                masks[b, ns[b]:].zero_()
+        key = (tuple(ns), str(device))
+        count = _COUNT_CACHE.get(key)                       # instance counts repeat: no H2D copy / host sync on the hot path
+        if count is None:
+            if len(_COUNT_CACHE) > 4096:
+                _COUNT_CACHE.clear()
+            count = _COUNT_CACHE[key] = torch.tensor(ns, dtype=torch.int32, device=device)
         return TargetSet(masks, count, ops.target_nonempty(masks, count), ns)
 
 
