@@ -245,6 +245,8 @@ def main():
                                       f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
                           "streams": 2 if overlap else 1, "schedule": schedule_note,
+                          "teacher_intermediate_masks": "full maps" if model.teacher_aux_masks else
+                          "only at the pixels its own attention masks read (no loss reads them; final prediction bit-identical)",
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)

@@ -130,8 +130,11 @@ int s2d_pe_sine_f32(int T, int H, int W, int num_pos_feats, const float *add_c, 
 /* Attention-mask builder: bilinear-resize the pixel-major mask logits [B][T*hm*wm][ldq] to the level size
  * (hl,wl), threshold sigmoid<0.5 (== logit<0) and pack to bits [B][K=T*hl*wl][4] (bit q set = query q must NOT
  * attend key); unmasked [B][4] gets bit q set iff query q has at least one attendable key.
- * video_mask2former_transformer_decoder.py:460-465 (the x8 head repeat is implicit: heads share the bits). */
-int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl,
+ * video_mask2former_transformer_decoder.py:460-465 (the x8 head repeat is implicit: heads share the bits).
+ * compact != 0: mask_logits holds only the four bilinear source pixels of every key, [B][K][4][ldq] in the order
+ * (y0,x0) (y0,x1) (y1,x0) (y1,x1) of the ATen align_corners=False source rule -- for a network whose intermediate mask
+ * predictions feed nothing but the next layer's attention mask (the frozen teacher). */
+int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl, int compact,
                        uint32_t *bits, uint32_t *unmasked, hipStream_t stream);
 
 /* floats of workspace s2d_masked_attn_f32 needs */

@@ -32,7 +32,7 @@ constexpr int LSTR = 36;         // LDS row stride (floats)
 template <bool COHERENT>
 __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
                                                         int hl, int wl, uint32_t *__restrict__ bits,
-                                                        uint32_t *__restrict__ unmasked)
+                                                        uint32_t *__restrict__ unmasked, int compact)
 {
     __shared__ uint32_t um[QW];
     const int b = blockIdx.y;
@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
         if (q0 < Q) {
             const float *p00 = base + ((long)y0 * wm + x0) * ldq + q0, *p01 = base + ((long)y0 * wm + x1) * ldq + q0;
             const float *p10 = base + ((long)y1 * wm + x0) * ldq + q0, *p11 = base + ((long)y1 * wm + x1) * ldq + q0;
+            if (compact) {       // logits were computed only at the four source pixels of each key: rows [b][key][4]
+                const float *cb = ml + (((long)b * K + key) * 4) * ldq + q0;
+                p00 = cb; p01 = cb + ldq; p10 = cb + 2 * ldq; p11 = cb + 3 * ldq;
+            }
             f32x4 a00, a01, a10, a11;
             if (q0 + 3 < Q && !COHERENT && (ldq & 3) == 0) {      // rows are 16-B aligned: one 16-B load per tap
                 a00 = *reinterpret_cast<const f32x4 *>(p00); a01 = *reinterpret_cast<const f32x4 *>(p01);
@@ -327,7 +331,7 @@ __global__ void attn_merge_kernel(const float *__restrict__ wo, const float *__r
 
 extern "C" {
 
-int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl,
+int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, int hm, int wm, int hl, int wl, int compact,
                        uint32_t *bits, uint32_t *unmasked, hipStream_t stream)
 {
     if (Q > 128 || Q <= 0 || ldq < Q) return S2D_ERR_ARG;
@@ -336,7 +340,7 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
     if (K >= (1L << 31) - 8) return S2D_ERR_ARG;
     if (s2d_zero_async(unmasked, sizeof(uint32_t) * QW * B, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_mask_kernel<false>, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl,
-                       wl, bits, unmasked);
+                       wl, bits, unmasked, compact);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -44,16 +44,16 @@ class MaskFormerHead(nn.Module):
         return cls(MSDeformAttnPixelDecoder.from_config(cfg), VideoMultiScaleMaskedTransformerDecoder.from_config(
             cfg, cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM, True), cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES)
 
-    def forward(self, features, training=True):  # layers(), mask_former_head.py:118-132 ("multi_scale_pixel_decoder")
+    def forward(self, features, training=True, aux_masks=True):  # layers(), mask_former_head.py:118-132 ("multi_scale_pixel_decoder")
         mask_features, multi_scale = self.pixel_decoder.forward_features(features)
-        return self.predictor(multi_scale, mask_features, training)
+        return self.predictor(multi_scale, mask_features, training, aux_masks)
 
 
 class _Net(nn.Sequential):
     """nn.Sequential(backbone, head): keeps the reference's state_dict keys (kd_video_maskformer_model.py:94-95)."""
 
-    def forward(self, x, training=True):
-        return self[1](self[0](x), training)
+    def forward(self, x, training=True, aux_masks=True):
+        return self[1](self[0](x), training, aux_masks)
 
 
 def _frames_to_device(batched_inputs, device):
@@ -105,6 +105,9 @@ class KDVideoMaskFormer(nn.Module):
         # and bitwise identical to the one-stream schedule (bench.py re-checks that on every run; DESIGN.md section 5,
         # "Streams", has the history of why the default here stays one stream).
         self.overlap_criteria = False
+        # The teacher's intermediate mask predictions feed only its own attention masks (no loss reads them): by default
+        # they are evaluated at the attention masks' source pixels only; True computes the full maps like the reference.
+        self.teacher_aux_masks = False
         self.overlap_teacher, self._side = False, None
 
     @classmethod
@@ -160,7 +163,7 @@ class KDVideoMaskFormer(nn.Module):
         else:
             side = main
         with torch.cuda.stream(side):
-            teacher = self.teacher(images, True)
+            teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
             tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
                                                 self.score_threshold_distillation, self.num_predictions_distillation)
         student = self.student(images, True)

@@ -138,6 +138,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self._pos_cache = {}
+        self._tap_cache = {}
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification=True):  # :344-372
@@ -157,23 +158,31 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
                 for i, (h, w) in enumerate(sizes)]}
         return self._pos_cache["posl"]
 
-    def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm):
-        """forward_prediction_heads :448-467 for all clips; writes slot `layer_slot` of the output buffers and
-        returns the attention-mask bits for the next layer."""
+    def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm, ml_slot=None, mf_taps=None):
+        """forward_prediction_heads :448-467 for all clips; writes slot `layer_slot` of the class buffer and slot `ml_slot`
+        of the mask-logit buffer, and returns the attention-mask bits for the next layer.  With `mf_taps` (the mask
+        features gathered at the four bilinear source pixels of every key of the next level) only those logits are
+        computed: enough for the attention mask, which is all an intermediate prediction of a frozen network feeds."""
         Q, C = self.num_queries, self.hidden_dim
         d = ops.layernorm(output, self.decoder_norm.weight, self.decoder_norm.bias).view(-1, C)
         ops.gemm_nt(d, self.class_embed.weight, bias=self.class_embed.bias, out=out_cls[layer_slot].view(B * Q, -1))
         e = self.mask_embed(d).view(B, Q, -1)
+        if mf_taps is not None:
+            sub = ops.gemm_nt(mf_taps, e)                                  # [B, K*4, Q]
+            return ops.attn_mask_bits(sub, B, Q, T, hm, wm, target_hw[0], target_hw[1], compact=True)
         # einsum "bqc,btchw->bqthw" as a pixel-major GEMM: [T*hm*wm, C] x [Q, C]^T per clip
-        ops.gemm_nt(mf, e, out=out_ml[layer_slot])
+        ops.gemm_nt(mf, e, out=out_ml[layer_slot if ml_slot is None else ml_slot])
         if target_hw is None:
             return None, None
-        return ops.attn_mask_bits(out_ml[layer_slot], B, Q, T, hm, wm, target_hw[0], target_hw[1])
+        return ops.attn_mask_bits(out_ml[layer_slot if ml_slot is None else ml_slot], B, Q, T, hm, wm, target_hw[0], target_hw[1])
 
     @torch.no_grad()
-    def forward(self, multi_scale, mask_features, training=True):
+    def forward(self, multi_scale, mask_features, training=True, aux_masks=True):
         """multi_scale: 3 x (tokens [BT,h*w,C], (h,w)) from the pixel decoder (res5, res4, res3 scale);
-        mask_features [BT,hm,wm,C] NHWC.  Returns MaskOutputs."""
+        mask_features [BT,hm,wm,C] NHWC.  Returns MaskOutputs.
+        aux_masks=False (a frozen network whose intermediate predictions are not supervised: the teacher): the mask logits
+        of layers 0..L-2 are evaluated only where the next layer's attention mask reads them; `mask_logits` then holds the
+        full-map slots only (the last one is the final prediction, as always)."""
         BT, hm, wm, C = mask_features.shape
         B = BT // self.num_frames if training else 1   # :376
         T = BT // B
@@ -188,18 +197,42 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             v_in.append(ops.add_bcast(x, self.level_embed.weight[i].detach().contiguous()))  # src + level_embed
         mf = mask_features.view(B, T * hm * wm, C)
         ldq = (Q + 3) // 4 * 4
+        # slot s (the prediction after layer s-1) feeds the attention mask of layer s at level s % 3; a level whose keys
+        # read every pixel of the map (scale <= 2) gains nothing from the tap-gathered form
+        def target(s):
+            return sizes[s % 3] if s < self.num_layers else None
+        def sparse(s):
+            t = target(s)
+            return (not aux_masks) and t is not None and 4 * t[0] * t[1] < hm * wm
+        full = [s for s in range(NL) if not sparse(s)]
+        taps = {}
+        if not aux_masks:
+            for lvl in {s % 3 for s in range(NL) if sparse(s)}:
+                idx = self._tap_index(T, hm, wm, sizes[lvl], dev)
+                taps[lvl] = mf.index_select(1, idx)                                        # [B, K*4, C]
         out_cls = torch.empty((NL, B, Q, self.class_embed.out_features), device=dev, dtype=torch.float32)
-        out_ml = torch.empty((NL, B, T * hm * wm, ldq), device=dev, dtype=torch.float32)
+        out_ml = torch.empty((len(full), B, T * hm * wm, ldq), device=dev, dtype=torch.float32)
         if ldq != Q:
             out_ml.zero_()
         qe = self.query_embed.weight.detach()
         output = self.query_feat.weight.detach().unsqueeze(0).repeat(B, 1, 1).contiguous()
-        bits, unm = self._heads(0, output, mf, out_cls, out_ml, sizes[0], B, T, hm, wm)
+
+        def heads(s, out):
+            if sparse(s):
+                return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, mf_taps=taps[s % 3])
+            return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, ml_slot=full.index(s))
+
+        bits, unm = heads(0, output)
         for i in range(self.num_layers):
             lvl = i % 3
             output = self.transformer_cross_attention_layers[i](output, k_in[lvl], v_in[lvl], bits, unm, qe)
             output = self.transformer_self_attention_layers[i](output, qe)
             output = self.transformer_ffn_layers[i](output)
-            nxt = sizes[(i + 1) % 3] if i + 1 < self.num_layers else None
-            bits, unm = self._heads(i + 1, output, mf, out_cls, out_ml, nxt, B, T, hm, wm)
+            bits, unm = heads(i + 1, output)
         return MaskOutputs(out_cls, out_ml, Q, T, hm, wm)
+
+    def _tap_index(self, T, hm, wm, size, device):
+        key = (T, hm, wm, tuple(size), device)
+        if key not in self._tap_cache:
+            self._tap_cache[key] = ops.attn_mask_tap_index(T, hm, wm, size[0], size[1], device)
+        return self._tap_cache[key]

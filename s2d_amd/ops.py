@@ -254,14 +254,33 @@ def pe_sine(T, H, W, num_pos_feats=128, add_c=None, device="cuda"):
 
 
 # ----------------------------------------------------------------------------- masked attention
-def attn_mask_bits(mask_logits, B, Q, T, hm, wm, hl, wl):
-    """mask_logits pixel-major [B, T*hm*wm, ldq] -> (bits int32 [B,K,4], unmasked int32 [B,4])."""
+def attn_mask_bits(mask_logits, B, Q, T, hm, wm, hl, wl, compact=False):
+    """mask_logits pixel-major [B, T*hm*wm, ldq] (or, compact, [B, K*4, ldq]: the four source pixels of every key, see
+    attn_mask_tap_index) -> (bits int32 [B,K,4], unmasked int32 [B,4])."""
     _chk(mask_logits)
     K = T * hl * wl
+    assert mask_logits.shape[1] == (K * 4 if compact else T * hm * wm)
     bits = torch.empty((B, K, 4), device=mask_logits.device, dtype=torch.int32)
     unm = torch.empty((B, 4), device=mask_logits.device, dtype=torch.int32)
-    lib().call("s2d_attn_mask_bits", mask_logits, mask_logits.shape[-1], B, Q, T, hm, wm, hl, wl, bits, unm, _stream())
+    lib().call("s2d_attn_mask_bits", mask_logits, mask_logits.shape[-1], B, Q, T, hm, wm, hl, wl, int(compact), bits, unm, _stream())
     return bits, unm
+
+
+def attn_mask_tap_index(T, hm, wm, hl, wl, device):
+    """int64 [T*hl*wl*4]: for every key of a (hl, wl) level the four pixels of the (hm, wm) map that
+    F.interpolate(bilinear, align_corners=False) reads for it, in the order (y0,x0) (y0,x1) (y1,x0) (y1,x1) -- the same
+    float32 arithmetic as attn_mask_kernel, so a GEMM restricted to these rows feeds attn_mask_bits(compact=True)."""
+    f32 = torch.float32
+    ys = torch.arange(hl, dtype=f32, device=device); xs = torch.arange(wl, dtype=f32, device=device)
+    sy = torch.clamp((torch.tensor(float(hm), dtype=f32, device=device) / hl) * (ys + 0.5) - 0.5, min=0.0)
+    sx = torch.clamp((torch.tensor(float(wm), dtype=f32, device=device) / wl) * (xs + 0.5) - 0.5, min=0.0)
+    y0 = sy.to(torch.int64); x0 = sx.to(torch.int64)
+    y1 = y0 + (y0 < hm - 1).to(torch.int64); x1 = x0 + (x0 < wm - 1).to(torch.int64)
+    rows = torch.stack([y0, y0, y1, y1], -1)                      # [hl, 4]
+    cols = torch.stack([x0, x1, x0, x1], -1)                      # [wl, 4]
+    pix = rows[:, None, :] * wm + cols[None, :, :]                # [hl, wl, 4]
+    t = torch.arange(T, dtype=torch.int64, device=device)[:, None, None, None] * (hm * wm)
+    return (t + pix[None]).reshape(-1).contiguous()
 
 
 def masked_attn(q, k, v, bits=None, unmasked=None, H=8):

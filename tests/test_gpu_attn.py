@@ -82,3 +82,15 @@ def test_cross_attention_long_keys(oracle):
     ref = _ref_attn(oracle, q, k, v, None)
     out = ops.masked_attn(_dev(q), _dev(k), _dev(v)).cpu().numpy()
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_attn_mask_bits_compact_matches_full():
+    """the tap-index table reproduces the kernel's bilinear source rule: logits gathered at those pixels give the same bits"""
+    from s2d_amd import ops
+    B, Q, T, hm, wm = 2, 100, 3, 46, 80
+    ml = torch.randn((B, T * hm * wm, Q), device="cuda")
+    for (hl, wl) in [(6, 10), (12, 20), (23, 40), (7, 13)]:
+        idx = ops.attn_mask_tap_index(T, hm, wm, hl, wl, "cuda")
+        b0, u0 = ops.attn_mask_bits(ml, B, Q, T, hm, wm, hl, wl)
+        b1, u1 = ops.attn_mask_bits(ml.index_select(1, idx).contiguous(), B, Q, T, hm, wm, hl, wl, compact=True)
+        assert torch.equal(b0, b1) and torch.equal(u0, u1)

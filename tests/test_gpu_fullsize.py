@@ -66,3 +66,17 @@ def test_two_stream_schedule_bitwise(setup):
             assert all((a == b).all() for a, b in zip(cur[1], ref[1])) and (cur[2] == ref[2]).all()
     finally:
         model.overlap_teacher = model.overlap_criteria = False
+
+
+def test_teacher_tap_gathered_masks_bitwise(setup):
+    """evaluating the teacher's intermediate mask logits only at the attention masks' source pixels (aux_masks=False)
+    leaves its final prediction -- all the KD pass reads -- bit-identical"""
+    from s2d_amd import ops
+    model, frames, _, _ = setup
+    images = ops.normalize_pad(frames)
+    full = model.teacher(images, True, aux_masks=True)
+    thin = model.teacher(images, True, aux_masks=False)
+    torch.cuda.synchronize()
+    assert thin.mask_logits.shape[0] < full.mask_logits.shape[0]
+    assert torch.equal(thin.mask_logits[-1], full.mask_logits[-1])
+    assert torch.equal(thin.class_logits, full.class_logits)
