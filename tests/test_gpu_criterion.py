@@ -218,3 +218,29 @@ def test_loss_golden_and_droploss_empty():
     # device RNG mode: finite, and close to the injected-coordinate value (same estimator, other points)
     Lr = ops.point_loss(ml, tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P, seed=7).cpu().numpy()
     assert np.isfinite(Lr).all() and abs(Lr[0, 1] - L[0, 1]) < 0.2 * abs(L[0, 1]) + 0.05
+
+
+@pytest.mark.parametrize("B,Q,T,h,w,P,ns,dense", [
+    (1, 37, 1, 13, 21, 77, [3], False),            # odd sizes, sparse points: every batch takes the direct-gather path
+    (2, 128, 2, 24, 40, 4096, [5, 33], True),      # Q = 128, one clip on the N > 32 kernel, dense points: LDS-staged rows
+    (2, 100, 3, 16, 28, 1500, [1, 17], True),      # tail batch (P % 32 != 0)
+])
+def test_matcher_cost_vs_oracle_odd_shapes(oracle, B, Q, T, h, w, P, ns, dense):
+    """device cost matrix vs the CPU restatement on shapes the goldens do not cover, including points on the image border"""
+    from s2d_amd import ops
+    H, W = 4 * h, 4 * w
+    seed = 40 + Q
+    logits = synth.randn(seed, 1, (B, Q, 2))
+    masks = synth.smooth_logits(seed, 2, (B, Q, T), (h, w))
+    tg = make_targets(seed, 7, ns, T, H, W)
+    Nmax = max(ns)
+    tgt, cnt = pad_targets(tg, Nmax, T, H, W)
+    rng = np.random.default_rng(seed)
+    coords = rng.random((1, B, P, 2), dtype=np.float32)
+    coords[0, :, :8] = np.array([[0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0], [0, 0.5], [1, 0.5], [0.5, 1]], np.float32)
+    wts = (2.0, 5.0, 5.0)
+    C = ops.matcher_cost(_dev(pixel_major(masks)[None]), _dev(logits[None]), _dev(tgt), _dev(cnt), (Q, T, h, w), P, wts,
+                         coords=_dev(coords)).cpu().numpy()
+    for b in range(B):
+        ref = oracle.matcher_cost(logits[b], masks[b], tg[b], coords[0, b][None], *wts)
+        np.testing.assert_allclose(C[b][:, :ns[b]], ref, rtol=3e-5, atol=3e-5 * np.abs(ref).max())
