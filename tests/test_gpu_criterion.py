@@ -244,3 +244,57 @@ def test_matcher_cost_vs_oracle_odd_shapes(oracle, B, Q, T, h, w, P, ns, dense):
     for b in range(B):
         ref = oracle.matcher_cost(logits[b], masks[b], tg[b], coords[0, b][None], *wts)
         np.testing.assert_allclose(C[b][:, :ns[b]], ref, rtol=3e-5, atol=3e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("P,H,W", [(250, 64, 96), (256, 64, 96), (1000, 32, 128)])
+def test_point_loss_vs_oracle_both_paths(oracle, P, H, W):
+    """point loss vs the CPU restatement where the sampled logits cannot be kept (3P or P/4 not a multiple of 4: the
+    recompute kernels) and where they can (the streamed kernels), same call"""
+    from s2d_amd import ops
+    B, Q, T, h, w = 2, 16, 2, H // 4, W // 4
+    ns = [3, 2]
+    seed = 90 + P
+    masks = synth.smooth_logits(seed, 2, (B, Q, T), (h, w))
+    tg = make_targets(seed, 100, ns, T, H, W)
+    Nmax = max(ns)
+    tgt, cnt = pad_targets(tg, Nmax, T, H, W)
+    maxm = min(Q, Nmax)
+    rng = np.random.default_rng(seed)
+    iq = np.zeros((B, maxm), np.int32); it = np.zeros((B, maxm), np.int32); nm = np.array(ns, np.int32)
+    indices = []
+    for b in range(B):
+        qi = np.sort(rng.choice(Q, ns[b], replace=False)); tj = rng.permutation(ns[b])
+        iq[b, :ns[b]], it[b, :ns[b]] = qi, tj
+        indices.append((qi, tj))
+    # kept rows in the reference's order: clip-major, pair-major, frame-minor, empty (pair, frame) planes dropped
+    rows = [(b, s, t) for b in range(B) for s in range(ns[b]) for t in range(T)]
+    kept = [r for r in rows if tg[r[0]][indices[r[0]][1][r[1]], r[2]].any()]
+    R = len(kept)
+    n_rand = P - int(0.75 * P)
+    cov = rng.random((R, 3 * P, 2), dtype=np.float32); crd = rng.random((R, n_rand, 2), dtype=np.float32)
+    rows_l = B * maxm * T
+    cover = np.zeros((1, rows_l, 3 * P, 2), np.float32); cover[0, :R] = cov
+    crand = np.zeros((1, rows_l, n_rand, 2), np.float32); crand[0, :R] = crd
+    tgt_d, cnt_d = _dev(tgt), _dev(cnt)
+    ne = ops.target_nonempty(tgt_d, cnt_d)
+    L = ops.point_loss(_dev(pixel_major(masks)[None]), tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P,
+                       coords_over=_dev(cover), coords_rand=_dev(crand)).cpu().numpy()
+    # the reference flattens (pair, frame) into rows: [R,1,h,w] maps and [R,1,H,W] planes
+    m_rows = [masks[b][None, indices[b][0]].transpose(1, 2, 0, 3, 4).reshape(-1, 1, 1, h, w)[:, 0] for b in range(B)]
+    t_rows = [tg[b][indices[b][1]].reshape(-1, 1, H, W) for b in range(B)]
+    src = np.concatenate(m_rows, 0); tt = np.concatenate(t_rows, 0)
+    keep = np.array([i for i in range(tt.shape[0]) if tt[i].any()])
+    assert len(keep) == R
+    num_masks = max(float(sum(ns)), 1.0)
+    # criterion.py:292-356 evaluated with the oracle's primitives on the flattened rows
+    pl = oracle.point_sample(src[keep], cov)[:, 0]
+    idx = np.argsort(np.abs(pl), axis=1, kind="stable")[:, :int(0.75 * P)]
+    coords = np.concatenate([np.take_along_axis(cov, idx[..., None], 1), crd], 1)
+    labels = oracle.point_sample(tt[keep], coords)[:, 0]
+    lg = oracle.point_sample(src[keep], coords)[:, 0]
+    bce = np.maximum(lg, 0) - lg * labels + np.log1p(np.exp(-np.abs(lg)))
+    ref_mask = bce.mean(1).sum() / num_masks
+    sg = oracle.sigmoid(lg)
+    ref_dice = (1 - (2 * (sg * labels).sum(-1) + 1) / (sg.sum(-1) + labels.sum(-1) + 1)).sum() / num_masks
+    np.testing.assert_allclose(L[0, 0], ref_mask, rtol=1e-3)
+    np.testing.assert_allclose(L[0, 1], ref_dice, rtol=1e-3)
