@@ -203,6 +203,33 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
 int s2d_class_loss_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,
                        float eos_coef, float *loss_ce, hipStream_t stream);
 
+/* ---- eval-side step after the path: inference_video -------------------------------- */
+
+/* kd_video_maskformer_model.py:532-538 (= video_maskformer_model.py:300-306): scores = softmax(class_logits
+ * [Q][C+1])[:, :-1] flattened to [Q*C]; sorted top-K (descending; ties -> lower flat index); scores[K], query[K] =
+ * flat // C, label[K] = flat % C on the device.  Q*C <= 16384, 1 <= K <= Q*C. */
+int s2d_infer_select_f32(const float *class_logits, int Q, int C, int K, float *scores, int *query, int *label,
+                         hipStream_t stream);
+
+/* floats of workspace s2d_infer_masks_u8 needs (the K gathered low-resolution planes) */
+long s2d_infer_workspace_floats(int K, int T, int hm, int wm);
+
+/* 32-bit words of one bit-packed mask [T][oh][ow] (flat index i -> word i/32, bit i%32; tail bits zero) */
+long s2d_mask_bit_words(int T, int oh, int ow);
+
+/* masks[k] = bilinear( bilinear(mask_logits[query[k]] -> (Hp,Wp)) [:, :ih, :iw] -> (oh,ow) ) > 0, both resizes
+ * align_corners=False, fp32, the expression tree of two F.interpolate calls (kd_video_maskformer_model.py:341-346,
+ * :545-550).  mask_logits pixel-major [T*hm*wm][ldq]; masks u8 [K][T][oh][ow]; bits (may be NULL) [K][words] with
+ * words = s2d_mask_bit_words(T,oh,ow).  Nothing of size [Q][T][Hp][Wp] is materialised. */
+int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm, int Hp, int Wp, int ih, int iw, int oh,
+                       int ow, const int *query, int K, float *workspace, uint8_t *masks, uint32_t *bits,
+                       hipStream_t stream);
+
+/* inter[i][j] = sum(mask_i & mask_j) for all pairs of K bit-packed masks (diagonal = areas; sum(mask_i | mask_j) =
+ * inter[i][i] + inter[j][j] - inter[i][j]): everything the greedy mask-NMS of :552-583 reads, in one launch instead
+ * of two full-tensor reductions and a host sync per pair.  inter [K][K] (zeroed here). */
+int s2d_mask_pair_counts_u64(const uint32_t *bits, int K, long words, unsigned long long *inter, hipStream_t stream);
+
 /* ---- keymask discovery (paths relative to /root/reference/keymask_ident) ------------------------------- */
 
 /* pred_tracks_to_binary_masks(return_mask=False), cotracker_matching.py:453-503: tracks [T][Np][2] (x,y px) ->

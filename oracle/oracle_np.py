@@ -455,6 +455,47 @@ def kd_targets(t_logits, t_masks, Hp, Wp, K=100, thr=0.75):
     return (up > 0).astype(np.uint8), kept
 
 
+def mask_nms(masks, labels, thr):
+    """greedy same-label mask-NMS in score order, kd_video_maskformer_model.py:552-583.  masks [K,...] bool sorted by
+    score; IoU is formed in float32 from integer counts as the reference does (.float() / .float()), union 0 -> IoU 0."""
+    flat = masks.reshape(masks.shape[0], -1)
+    idx = list(range(flat.shape[0]))
+    keep = []
+    while idx:
+        cur = idx.pop(0)
+        keep.append(cur)
+        rem = []
+        for o in idx:
+            if labels[o] != labels[cur]:
+                rem.append(o)
+                continue
+            inter = np.float32(np.count_nonzero(flat[cur] & flat[o]))
+            union = np.float32(np.count_nonzero(flat[cur] | flat[o]))
+            iou = inter / union if union > 0 else np.float32(0.0)
+            if iou <= np.float32(thr):
+                rem.append(o)
+        idx = rem
+    return keep
+
+
+def inference_video(cls_logits, masks_lowres, Hp, Wp, ih, iw, oh, ow, K, use_nms=False, thr=0.75):
+    """eval branch of KDVideoMaskFormer.forward (kd_video_maskformer_model.py:340-356) + inference_video (:530-610).
+    cls_logits [Q,C+1], masks_lowres [Q,T,h,w] -> dict(scores [n] f32, labels [n] i64, masks [n,T,oh,ow] bool,
+    query [n] i64 (the query each prediction came from), logits [K,T,oh,ow] f32 before NMS, keep list).
+    Ties in the sorted top-k resolve to the lower flat index."""
+    Q, C1 = cls_logits.shape
+    C = C1 - 1
+    sc = softmax(cls_logits.astype(np.float32), -1)[:, :-1].reshape(-1)
+    order = np.argsort(-sc, kind="stable")[:K]
+    scores, labels, qidx = sc[order], (order % C).astype(np.int64), order // C
+    up = resize_bilinear(masks_lowres[qidx].astype(np.float32), Hp, Wp)[:, :, :ih, :iw]       # :341-346, :545
+    lg = resize_bilinear(np.ascontiguousarray(up), oh, ow)                                    # :546-548
+    m = lg > 0
+    keep = mask_nms(m, labels, thr) if use_nms else list(range(len(order)))
+    return dict(scores=scores[keep], labels=labels[keep], masks=m[keep], query=qidx[keep], logits=lg, keep=keep,
+                all_scores=scores, all_labels=labels, all_query=qidx)
+
+
 # --------------------------------------------------------------------------- matcher
 def softplus(x):
     return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))

@@ -13,6 +13,7 @@ from .. import ops
 from .backbone import ResNet50
 from .criterion import TargetSet, VideoHungarianMatcher, VideoSetCriterion
 from .pixel_decoder import MSDeformAttnPixelDecoder
+from .postprocess import inference_video
 from .video_decoder import VideoMultiScaleMaskedTransformerDecoder
 
 try:  # plug into detectron2's registries when it is installed (the drop-in boundary)
@@ -56,6 +57,18 @@ class _Net(nn.Sequential):
         return self[1](self[0](x), training, aux_masks)
 
 
+def _test_kwargs(mf, npred_name, eval_student=False):
+    """MODEL.MASK_FORMER.TEST.* keys of the eval branch (kd_video_maskformer_model.py:153, 224-230;
+    video_maskformer_model.py:112, 179-181); absent TEST node -> the constructors' defaults."""
+    t = getattr(mf, "TEST", None)
+    if t is None:
+        return {}
+    kw = {"use_nms": t.USE_NMS, "nms_threshold": t.NMS_THRESH, npred_name: t.NUM_PREDICTIONS}
+    if eval_student:
+        kw["eval_student"] = t.EVAL_STUDENT
+    return kw
+
+
 def _frames_to_device(batched_inputs, device):
     frames = [f for video in batched_inputs for f in video["image"]]
     x = torch.stack([f if isinstance(f, torch.Tensor) else torch.as_tensor(f) for f in frames])
@@ -88,7 +101,8 @@ def _gt_target_list(batched_inputs, num_frames, Hp, Wp, device):
 class KDVideoMaskFormer(nn.Module):
     def __init__(self, *, student_backbone, student_sem_seg_head, teacher_backbone, teacher_sem_seg_head, criterion,
                  num_queries, num_frames, size_divisibility=32, pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD,
-                 num_predictions_distillation=100, score_threshold_distillation=0.75, accum_iter=1, eval_student=False):
+                 num_predictions_distillation=100, score_threshold_distillation=0.75, accum_iter=1, eval_student=False,
+                 use_nms=False, nms_threshold=0.75, num_predictions_inference=10):
         super().__init__()
         self.student = _Net(student_backbone, student_sem_seg_head)
         self.teacher = _Net(teacher_backbone, teacher_sem_seg_head)
@@ -101,6 +115,7 @@ class KDVideoMaskFormer(nn.Module):
         self.num_predictions_distillation = num_predictions_distillation
         self.score_threshold_distillation = score_threshold_distillation
         self.accum_iter, self.eval_student = accum_iter, eval_student
+        self.use_nms, self.nms_threshold, self.num_predictions_inference = use_nms, nms_threshold, num_predictions_inference
         # Optional two-stream schedule of forward_losses (teacher forward / GT criterion on a second HIP stream): ~8 % faster
         # and bitwise identical to the one-stream schedule (bench.py re-checks that on every run; DESIGN.md section 5,
         # "Streams", has the history of why the default here stays one stream).
@@ -135,7 +150,8 @@ class KDVideoMaskFormer(nn.Module):
                    criterion=crit, num_queries=mf.NUM_OBJECT_QUERIES, num_frames=cfg.INPUT.SAMPLING_FRAME_NUM,
                    size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
                    num_predictions_distillation=mf.NUM_PREDICTIONS_DISTILLATION,
-                   score_threshold_distillation=mf.SCORE_THRESHOLD_DISTILLATION, accum_iter=cfg.SOLVER.ACCUM_ITER)
+                   score_threshold_distillation=mf.SCORE_THRESHOLD_DISTILLATION, accum_iter=cfg.SOLVER.ACCUM_ITER,
+                   **_test_kwargs(mf, "num_predictions_inference", eval_student=True))
 
     @property
     def device(self):
@@ -195,14 +211,21 @@ class KDVideoMaskFormer(nn.Module):
 
     @torch.no_grad()
     def inference(self, images, batched_inputs):
-        """eval branch (kd_video_maskformer_model.py:327-356): whole video as one clip; returns the teacher's (or
-        student's) class logits and mask logits upsampled to the padded frame size.  The python mask-NMS /
-        top-k post-processing (inference_video, :530-610) is a 'next' row of SURVEY.md 8f, not on the metric path."""
+        """eval branch (kd_video_maskformer_model.py:327-356): the whole video as one clip through the teacher (or the
+        student, TEST.EVAL_STUDENT), then inference_video (:530-610) on the device -> {image_size, pred_scores,
+        pred_labels, pred_masks}."""
         net = self.student if self.eval_student else self.teacher
-        out = net(images, False)
-        masks = out.pred_masks(-1)[0]
-        masks = torch.nn.functional.interpolate(masks, size=images.shape[1:3], mode="bilinear", align_corners=False)
-        return {"pred_logits": out.class_logits[-1][0], "pred_masks": masks}
+        return _inference(net, images, batched_inputs, self.num_predictions_inference, self.use_nms, self.nms_threshold)
+
+
+def _inference(net, images, batched_inputs, num_predictions, use_nms, nms_threshold):
+    out = net(images, False)
+    video = batched_inputs[0]
+    first = video["image"][0]
+    image_size = tuple(int(v) for v in first.shape[-2:])            # size without padding (images.image_sizes[0], :349)
+    height, width = video.get("height", image_size[0]), video.get("width", image_size[1])   # :351-352
+    return inference_video(out.class_logits[-1][0], out.mask_logits[-1][0], (out.T, out.hm, out.wm), tuple(images.shape[1:3]),
+                           image_size, (int(height), int(width)), num_predictions, use_nms, nms_threshold)
 
 
 @META_ARCH_REGISTRY.register()
@@ -210,10 +233,11 @@ class VideoMaskFormer(nn.Module):
     """Non-KD variant (video_maskformer_model.py:189-265): one network, one criterion pass."""
 
     def __init__(self, *, backbone, sem_seg_head, criterion, num_queries, num_frames, size_divisibility=32,
-                 pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD):
+                 pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD, use_nms=False, nms_threshold=0.75, num_predictions=10):
         super().__init__()
         self.backbone, self.sem_seg_head, self.criterion = backbone, sem_seg_head, criterion
         self.num_queries, self.num_frames, self.size_divisibility = num_queries, num_frames, size_divisibility
+        self.use_nms, self.nms_threshold, self.num_predictions = use_nms, nms_threshold, num_predictions
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
 
@@ -233,6 +257,10 @@ class VideoMaskFormer(nn.Module):
         frames = _frames_to_device(batched_inputs, self.device)
         images = ops.normalize_pad(frames, self.size_divisibility, self.pixel_mean.flatten().cpu().numpy(),
                                    self.pixel_std.flatten().cpu().numpy())
+        if not self.training:                                           # video_maskformer_model.py:241-264
+            net = lambda x, training: self.sem_seg_head(self.backbone(x), training)   # noqa: E731
+            with torch.no_grad():
+                return _inference(net, images, batched_inputs, self.num_predictions, self.use_nms, self.nms_threshold)
         Hp, Wp = images.shape[1:3]
         gt = TargetSet.from_list(_gt_target_list(batched_inputs, self.num_frames, Hp, Wp, self.device), device=self.device)
         return self.forward_losses(images, gt)

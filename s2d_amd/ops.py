@@ -373,3 +373,40 @@ def class_loss(class_logits, idx_q, n_match, eos_coef=0.1):
     out = torch.zeros((1,), device=class_logits.device, dtype=torch.float32)
     lib().call("s2d_class_loss_f32", class_logits, idx_q, n_match, B, Q, idx_q.shape[-1], float(eos_coef), out, _stream())
     return out[0]
+
+
+# --------------------------------------------------------------------------- eval-side post-processing (infer.hip)
+def infer_select(class_logits, K):
+    """class_logits [Q,C+1] -> (scores [K] f32, query [K] i32, label [K] i32): softmax[:, :-1], sorted top-K"""
+    _chk(class_logits)
+    Q, C1 = class_logits.shape
+    dev = class_logits.device
+    scores = torch.empty((K,), device=dev, dtype=torch.float32)
+    query = torch.empty((K,), device=dev, dtype=torch.int32)
+    label = torch.empty((K,), device=dev, dtype=torch.int32)
+    lib().call("s2d_infer_select_f32", class_logits, Q, C1 - 1, K, scores, query, label, _stream())
+    return scores, query, label
+
+
+def infer_masks(mask_logits, dims, padded, img_size, out_size, query, want_bits=False):
+    """mask_logits pixel-major [T*hm*wm, ldq]; dims = (T, hm, wm); -> masks u8 [K,T,oh,ow] (and bit words [K,words])"""
+    _chk(mask_logits); _chk(query, torch.int32)
+    T, hm, wm = dims
+    K = query.shape[0]
+    (Hp, Wp), (ih, iw), (oh, ow) = padded, img_size, out_size
+    dev = mask_logits.device
+    ws = torch.empty((lib().call("s2d_infer_workspace_floats", K, T, hm, wm),), device=dev, dtype=torch.float32)
+    masks = torch.empty((K, T, oh, ow), device=dev, dtype=torch.uint8)
+    bits = torch.empty((K, lib().call("s2d_mask_bit_words", T, oh, ow)), device=dev, dtype=torch.int32) if want_bits else None
+    lib().call("s2d_infer_masks_u8", mask_logits, mask_logits.shape[-1], T, hm, wm, Hp, Wp, ih, iw, oh, ow, query, K, ws, masks,
+               bits, _stream())
+    return masks, bits
+
+
+def mask_pair_counts(bits):
+    """bit-packed masks [K,words] -> int64 [K,K] intersection counts (diagonal = areas)"""
+    _chk(bits, torch.int32)
+    K, words = bits.shape
+    inter = torch.empty((K, K), device=bits.device, dtype=torch.int64)
+    lib().call("s2d_mask_pair_counts_u64", bits, K, words, inter, _stream())
+    return inter

@@ -3,7 +3,7 @@
 the reference's own Python (loaded unmodified from /root/reference through
 _ref_shim.py) on seeded synthetic inputs.  Container-only; re-run with
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [g_name ...]
 
 Fixtures hold data only: seeds, the inputs that cannot be regenerated from a
 seed (recorded torch.rand draws), and the reference's outputs.  Network weights
@@ -523,11 +523,77 @@ def g_grouping():
          groups_json=np.frombuffer(json.dumps({str(k): v for k, v in vt[0]["overall_mask_ids_per_label"].items()}).encode(), np.uint8))
 
 
+def _infer_inputs(seed, Q, C, T, h, w, dup):
+    """class logits [Q,C+1] and low-resolution mask logits [Q,T,h,w]: soft ellipses (logit = margin in px); the queries
+    listed in `dup` repeat another query's mask with a small shift so that mask-NMS has something to suppress."""
+    rng = synth.rng_for(seed, 7)
+    cls = rng.normal(0, 2.0, (Q, C + 1)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    masks = np.empty((Q, T, h, w), np.float32)
+    par = []
+    for q in range(Q):
+        par.append((rng.uniform(0.25 * h, 0.75 * h), rng.uniform(0.25 * w, 0.75 * w), rng.uniform(0.12 * h, 0.3 * h),
+                    rng.uniform(0.12 * w, 0.3 * w), rng.uniform(-0.6, 0.6, (T, 2))))
+    for q, src, sh in dup:
+        cy, cx, ry, rx, dr = par[src]
+        par[q] = (cy + sh, cx - sh, ry, rx, dr)
+    for q in range(Q):
+        cy, cx, ry, rx, dr = par[q]
+        for t in range(T):
+            d = np.sqrt(((yy - cy - dr[:t + 1, 0].sum()) / ry) ** 2 + ((xx - cx - dr[:t + 1, 1].sum()) / rx) ** 2)
+            masks[q, t] = (1.0 - d) * 4.0 + rng.normal(0, 0.05, (h, w))
+    return cls, masks
+
+
+def g_inference():
+    """Eval branch: the upsample of kd_video_maskformer_model.py:340-346 followed by inference_video (:530-610):
+    softmax scores, sorted top-k over Q x classes, crop to the unpadded size, bilinear resize to the output size,
+    > 0, optional greedy same-label mask-NMS."""
+    kd = R.ref("mask2former_video.kd_video_maskformer_model")
+    cases = {
+        # name: (seed, Q, C, K, T, h, w, Hp, Wp, ih, iw, oh, ow, use_nms, thr, dup)
+        "agn_nms": (91, 12, 1, 6, 3, 16, 24, 64, 96, 60, 90, 90, 135, True, 0.75, [(1, 0, 0.4), (5, 4, 0.3), (7, 4, 0.5)]),
+        "agn_plain": (92, 12, 1, 6, 3, 16, 24, 64, 96, 60, 90, 60, 90, False, 0.75, []),
+        "multi_nms": (93, 10, 3, 8, 2, 16, 24, 64, 96, 64, 96, 48, 70, True, 0.5, [(2, 0, 0.3), (3, 0, 0.6), (9, 8, 0.2)]),
+        "down_nms": (94, 16, 1, 10, 4, 24, 40, 96, 160, 90, 157, 45, 80, True, 0.75, [(3, 2, 0.2), (11, 10, 0.4)]),
+    }
+    arrs = {}
+    for name, (seed, Q, C, K, T, h, w, Hp, Wp, ih, iw, oh, ow, use_nms, thr, dup) in cases.items():
+        cls, masks = _infer_inputs(seed, Q, C, T, h, w, dup)
+        if name == "multi_nms":            # duplicated masks must also share their best label, or label-aware NMS never fires
+            for q, src, _ in dup:
+                cls[q] = cls[src]
+                cls[q, -1] += np.float32(0.05) * (q + 1)          # same best label, strictly lower score (no ties)
+        fs = _FakeSelf()
+        fs.teacher = [None, _FakeSelf()]
+        fs.teacher[1].num_classes = C
+        fs.device = torch.device("cpu")
+        fs.num_queries = Q
+        fs.num_predictions_inference = K
+        fs.use_nms, fs.nms_threshold = use_nms, thr
+        up = F.interpolate(torch.from_numpy(masks), size=(Hp, Wp), mode="bilinear", align_corners=False)   # :341-346
+        out = kd.KDVideoMaskFormer.inference_video(fs, torch.from_numpy(cls), up, (ih, iw), oh, ow)
+        assert out["image_size"] == (oh, ow)
+        n = len(out["pred_scores"])
+        arrs[f"{name}_dims"] = np.array([seed, Q, C, K, T, h, w, Hp, Wp, ih, iw, oh, ow, int(use_nms)])
+        arrs[f"{name}_thr"] = np.float32(thr)
+        arrs[f"{name}_cls"] = cls
+        arrs[f"{name}_masks"] = masks
+        arrs[f"{name}_scores"] = np.array(out["pred_scores"], np.float32)
+        arrs[f"{name}_labels"] = np.array(out["pred_labels"], np.int64)
+        arrs[f"{name}_out"] = np.packbits(torch.stack(out["pred_masks"]).numpy().astype(np.uint8), axis=-1) if n else np.zeros((0,), np.uint8)
+        print(f"    {name}: kept {n} of {K}")
+    save("inference", **arrs)
+
+
 def main():
     assert R.available(), "/root/reference not present: goldens can only be generated in the build container"
     R.install()
+    only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping):
+               g_prepare_targets, g_keymask, g_grouping, g_inference):
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn()
 

@@ -24,13 +24,14 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(dll, name), f"{name} declared in include/s2d_hip.h but not exported"
     # the drop-in entry points SURVEY.md 8b names
     for name in ("s2d_msda_forward_f32", "s2d_msda_backward_f32", "s2d_gemm_nt_f32", "s2d_matcher_cost_f32", "s2d_lsap_f32",
-                 "s2d_point_loss_f32", "s2d_masked_attn_f32", "s2d_kd_targets_u8"):
+                 "s2d_point_loss_f32", "s2d_masked_attn_f32", "s2d_kd_targets_u8", "s2d_infer_select_f32", "s2d_infer_masks_u8",
+                 "s2d_mask_pair_counts_u64"):
         assert name in protos
 
 
 def test_abi_version_and_workspace_queries(built):
     dll = ctypes.CDLL(built)
-    assert dll.s2d_abi_version() == 4
+    assert dll.s2d_abi_version() == 5
     dll.s2d_attn_workspace_floats.restype = ctypes.c_long
     assert dll.s2d_attn_workspace_floats(2, 8, 117760) == 2 * 8 * 32 * (32 * 128 + 256)
 

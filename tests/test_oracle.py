@@ -309,3 +309,43 @@ def test_r50_self_check(oracle):
             z = bn(F.conv2d(z, tp[bp + "conv3.weight"]), bp + "conv3.norm.")
             y = F.relu(z + sc)
         close(outs[name], y.numpy(), 1e-3)
+
+
+# ------------------------------------------------------------------ eval branch: inference_video
+INFER_CASES = ("agn_nms", "agn_plain", "multi_nms", "down_nms")
+
+
+def infer_case(g, name):
+    seed, Q, C, K, T, h, w, Hp, Wp, ih, iw, oh, ow, nms = (int(v) for v in g[name + "_dims"])
+    exp = np.unpackbits(g[name + "_out"], axis=-1)[..., :ow].astype(bool) if g[name + "_scores"].size else np.zeros((0, T, oh, ow), bool)
+    return dict(Q=Q, C=C, K=K, T=T, h=h, w=w, Hp=Hp, Wp=Wp, ih=ih, iw=iw, oh=oh, ow=ow, nms=bool(nms), thr=float(g[name + "_thr"]),
+                cls=g[name + "_cls"], masks=g[name + "_masks"], scores=g[name + "_scores"], labels=g[name + "_labels"], out=exp)
+
+
+@pytest.mark.parametrize("name", INFER_CASES)
+def test_inference_video(oracle, name):
+    """kd_video_maskformer_model.py:340-356 + :530-610 (upsample, sorted top-k, crop, resize, > 0, same-label mask-NMS)"""
+    c = infer_case(golden("inference"), name)
+    r = oracle.inference_video(c["cls"], c["masks"], c["Hp"], c["Wp"], c["ih"], c["iw"], c["oh"], c["ow"], c["K"], c["nms"], c["thr"])
+    np.testing.assert_allclose(r["scores"], c["scores"], rtol=1e-6)
+    np.testing.assert_array_equal(r["labels"], c["labels"])
+    assert r["masks"].shape == c["out"].shape
+    np.testing.assert_array_equal(r["masks"], c["out"])          # boolean masks bit-exact
+    if c["nms"]:
+        assert len(r["keep"]) < c["K"]                           # the case does suppress something
+
+
+def test_greedy_nms_on_counts_equals_nms_on_masks(oracle):
+    """host logic of the product (greedy loop on the K x K intersection counts) vs the oracle's loop on the masks"""
+    from s2d_amd.modeling.postprocess import greedy_mask_nms
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        K, n = int(rng.integers(1, 14)), 600
+        base = rng.random((4, n)) < 0.3
+        m = np.stack([base[rng.integers(4)] ^ (rng.random(n) < rng.choice([0.01, 0.1, 0.4])) for _ in range(K)])
+        if trial % 5 == 0:
+            m[rng.integers(K)] = False                           # an empty mask: union 0 -> IoU 0 (:577)
+        labels = rng.integers(0, 2, K)
+        inter = (m[:, None, :] & m[None, :, :]).sum(-1).astype(np.int64)
+        for thr in (0.3, 0.5, 0.75):
+            assert greedy_mask_nms(inter, labels, thr) == oracle.mask_nms(m, labels, thr)
