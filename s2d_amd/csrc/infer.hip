@@ -96,27 +96,16 @@ __device__ __forceinline__ void src_tap(float scale, int dst, int in_size, int &
     l0 = 1.f - l1;
 }
 
-// vertical taps of the padded-size upsample (:341-346) for output row Y: two low-resolution row pointers + weights
-struct RowTap {
-    const float *r0, *r1;
-    float hy, ly;
-};
-__device__ __forceinline__ RowTap row_tap(const float *__restrict__ pl, const ResizeParams &p, int Y)
+// value of the padded-size upsample (:341-346) from its two low-resolution rows and their weights
+__device__ __forceinline__ float stage1(const float *__restrict__ r0, const float *__restrict__ r1, float hy, float ly, int x0,
+                                        int x1, float hx, float lx)
 {
-    int y0, y1;
-    RowTap r;
-    src_tap(p.s1y, Y, p.hm, y0, y1, r.hy, r.ly);
-    r.r0 = pl + (long)y0 * p.wm;
-    r.r1 = pl + (long)y1 * p.wm;
-    return r;
-}
-__device__ __forceinline__ float stage1(const RowTap &r, int x0, int x1, float hx, float lx)
-{
-    return r.hy * (hx * r.r0[x0] + lx * r.r0[x1]) + r.ly * (hx * r.r1[x0] + lx * r.r1[x1]);
+    return hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
 }
 
 // A thread owns 4 consecutive elements of one mask (flat index over [T][oh][ow]); 8 lanes make one 32-bit word.  The
 // vertical taps are formed once per thread and again only when its 4 elements wrap into the next row.
+template <bool SAME>
 __global__ __launch_bounds__(256) void infer_resize_kernel(ResizeParams p)
 {
     const int k = blockIdx.y;
@@ -134,45 +123,53 @@ __global__ __launch_bounds__(256) void infer_resize_kernel(ResizeParams p)
             const long r = i0 - (long)t * frame;
             y = (int)(r / p.ow); x = (int)(r - (long)y * p.ow);
         }
-        RowTap ra, rb;                                   // stage-1 rows under the two stage-2 rows (same: only ra)
-        float HY = 1.f, LY = 0.f;
-        auto set_row = [&]() {
-            const float *pl = p.planes + ((long)k * p.T + t) * p.hm * p.wm;
-            if (p.same) ra = row_tap(pl, p, y);
-            else {
-                int Y0, Y1;
-                src_tap(p.s2y, y, p.ih, Y0, Y1, HY, LY);
-                ra = row_tap(pl, p, Y0);
-                rb = row_tap(pl, p, Y1);
-            }
-        };
-        set_row();
+        // stage-1 rows (a: under stage-2 row Y0, b: under Y1; SAME uses a only) and the stage-2 vertical weights
+        const float *a0 = nullptr, *a1 = nullptr, *b0 = nullptr, *b1 = nullptr;
+        float hya = 0.f, lya = 0.f, hyb = 0.f, lyb = 0.f, HY = 1.f, LY = 0.f;
+#define S2D_SET_ROW()                                                                           \
+        do {                                                                                    \
+            const float *pl = p.planes + ((long)k * p.T + t) * p.hm * p.wm;                     \
+            int q0, q1;                                                                         \
+            if (SAME) {                                                                         \
+                src_tap(p.s1y, y, p.hm, q0, q1, hya, lya);                                      \
+                a0 = pl + q0 * p.wm; a1 = pl + q1 * p.wm;                                       \
+            } else {                                                                            \
+                int Y0, Y1;                                                                     \
+                src_tap(p.s2y, y, p.ih, Y0, Y1, HY, LY);                                        \
+                src_tap(p.s1y, Y0, p.hm, q0, q1, hya, lya);                                     \
+                a0 = pl + q0 * p.wm; a1 = pl + q1 * p.wm;                                       \
+                src_tap(p.s1y, Y1, p.hm, q0, q1, hyb, lyb);                                     \
+                b0 = pl + q0 * p.wm; b1 = pl + q1 * p.wm;                                       \
+            }                                                                                   \
+        } while (0)
+        S2D_SET_ROW();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (i0 + j < p.N) {
                 float v;
-                int a0, a1, b0, b1;
-                float ha, la, hb, lb;
-                if (p.same) {
-                    src_tap(p.s1x, x, p.wm, a0, a1, ha, la);
-                    v = stage1(ra, a0, a1, ha, la);
+                int xa0, xa1;
+                float ha, la;
+                if (SAME) {
+                    src_tap(p.s1x, x, p.wm, xa0, xa1, ha, la);
+                    v = stage1(a0, a1, hya, lya, xa0, xa1, ha, la);
                 } else {
-                    int X0, X1;
-                    float HX, LX;
+                    int X0, X1, xb0, xb1;
+                    float HX, LX, hb, lb;
                     src_tap(p.s2x, x, p.iw, X0, X1, HX, LX);
-                    src_tap(p.s1x, X0, p.wm, a0, a1, ha, la);
-                    src_tap(p.s1x, X1, p.wm, b0, b1, hb, lb);
-                    v = HY * (HX * stage1(ra, a0, a1, ha, la) + LX * stage1(ra, b0, b1, hb, lb)) +
-                        LY * (HX * stage1(rb, a0, a1, ha, la) + LX * stage1(rb, b0, b1, hb, lb));
+                    src_tap(p.s1x, X0, p.wm, xa0, xa1, ha, la);
+                    src_tap(p.s1x, X1, p.wm, xb0, xb1, hb, lb);
+                    v = HY * (HX * stage1(a0, a1, hya, lya, xa0, xa1, ha, la) + LX * stage1(a0, a1, hya, lya, xb0, xb1, hb, lb)) +
+                        LY * (HX * stage1(b0, b1, hyb, lyb, xa0, xa1, ha, la) + LX * stage1(b0, b1, hyb, lyb, xb0, xb1, hb, lb));
                 }
                 nib |= (v > 0.f ? 1u : 0u) << j;
             }
             if (++x == p.ow) {
                 x = 0;
                 if (++y == p.oh) { y = 0; ++t; }
-                if (j < 3 && i0 + j + 1 < p.N) set_row();
+                if (j < 3 && i0 + j + 1 < p.N) S2D_SET_ROW();
             }
         }
+#undef S2D_SET_ROW
         uint8_t *mo = p.masks + (long)k * p.N + i0;
         if (i0 + 4 <= p.N && (reinterpret_cast<uintptr_t>(mo) & 3) == 0)
             *reinterpret_cast<uint32_t *>(mo) = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
@@ -276,7 +273,8 @@ int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm,
     p.same = (ih == oh && iw == ow) ? 1 : 0;
     p.masks = masks; p.bits = bits;
     const long nthreads = (p.words * 32 + 3) / 4;       // whole words: the tail lanes write the zero padding bits
-    hipLaunchKernelGGL(infer_resize_kernel, dim3(cdiv(nthreads, 256), K), dim3(256), 0, stream, p);
+    if (p.same) hipLaunchKernelGGL(infer_resize_kernel<true>, dim3(cdiv(nthreads, 256), K), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(infer_resize_kernel<false>, dim3(cdiv(nthreads, 256), K), dim3(256), 0, stream, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
