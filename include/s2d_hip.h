@@ -230,6 +230,32 @@ int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm,
  * of two full-tensor reductions and a host sync per pair.  inter [K][K] (zeroed here). */
 int s2d_mask_pair_counts_u64(const uint32_t *bits, int K, long words, unsigned long long *inter, hipStream_t stream);
 
+/* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */
+
+/* Tensor table shared by the two entry points (all arrays on the device): ptrs [ntensors][5] = {param, grad or NULL,
+ * exp_avg, exp_avg_sq, ema target or NULL} (float32 each, numel[i] elements); the work list (chunk_tensor[c],
+ * chunk_off[c]) names a tensor and an element offset, `chunk` elements (multiple of 4) per entry, one workgroup each.
+ *
+ * GradScaler.unscale_ + clip_grad_norm_ over all parameters (train_net_video.py:188-203, engine/train_loop.py:709-726)
+ * without touching the gradients and without a host sync: normbuf[0] = || grads * inv_scale ||_2, normbuf[1] =
+ * min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0), normbuf[2] = 1 if any gradient is inf/nan else 0.
+ * partial: double[nchunks] scratch (fixed slots, fixed-order reduction: reproducible). */
+int s2d_optim_grad_norm_f32(const void *const *ptrs, const long *numel, const int *chunk_tensor, const long *chunk_off,
+                            int nchunks, int chunk, float inv_scale, float max_norm, double *partial, float *normbuf,
+                            hipStream_t stream);
+
+/* torch.optim.AdamW.step (train_net_video.py:205-213; single-tensor formula, fp32, its operation order) on
+ * g * inv_scale * normbuf[1], fused with the EMA teacher update ema = ema_m * ema + (1 - ema_m) * param
+ * (engine/train_loop.py:754-764; ema_m < 0: no EMA).  hyper [ntensors][2] = {lr, weight_decay} as double; lr is
+ * multiplied by lr_factor (the scheduler's factor).  bias_correction1 = 1 - beta1^step, bias_correction2_sqrt =
+ * sqrt(1 - beta2^step), formed by the caller in double as torch does.  normbuf NULL: no clipping, no inf check;
+ * normbuf[2] != 0: parameters and moments are left untouched (GradScaler skips the step), the EMA still runs.
+ * Tensors whose grad pointer is NULL get the EMA only.  The (unscaled, clipped) gradients are not written back. */
+int s2d_optim_adamw_ema_f32(const void *const *ptrs, const long *numel, const double *hyper, const int *chunk_tensor,
+                            const long *chunk_off, int nchunks, int chunk, double lr_factor, double beta1, double beta2,
+                            double eps, double bias_correction1, double bias_correction2_sqrt, float inv_scale, double ema_m,
+                            const float *normbuf, hipStream_t stream);
+
 /* ---- keymask discovery (paths relative to /root/reference/keymask_ident) ------------------------------- */
 
 /* pred_tracks_to_binary_masks(return_mask=False), cotracker_matching.py:453-503: tracks [T][Np][2] (x,y px) ->

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built):
     # the drop-in entry points SURVEY.md 8b names
     for name in ("s2d_msda_forward_f32", "s2d_msda_backward_f32", "s2d_gemm_nt_f32", "s2d_matcher_cost_f32", "s2d_lsap_f32",
                  "s2d_point_loss_f32", "s2d_masked_attn_f32", "s2d_kd_targets_u8", "s2d_infer_select_f32", "s2d_infer_masks_u8",
-                 "s2d_mask_pair_counts_u64"):
+                 "s2d_mask_pair_counts_u64", "s2d_optim_grad_norm_f32", "s2d_optim_adamw_ema_f32"):
         assert name in protos
 
 

@@ -47,3 +47,60 @@ def test_shard_clips_properties():
             assert allc == list(range(n))
             sizes = [len(shard_clips(n, r, w)) for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _allreduce_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from s2d_amd.optim import allreduce_flat
+    dist.init_process_group("gloo")
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    f = allreduce_flat(flat, bucket_bytes=4 * 96)          # 11 buckets, the last one partial
+    q.put((rank, f, flat.clone()))
+    dist.destroy_process_group()
+
+
+def test_gradient_arena_allreduce_two_ranks_gloo():
+    """the one exchange step of training, a bucketed SUM all-reduce of the flat gradient arena; the mean is
+    folded into the optimizer's inv_scale (returned factor 1/world)"""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, f, flat in got:
+        assert f == 0.5
+        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
+
+
+def test_param_groups_follow_reference_rules():
+    """Trainer.build_optimizer (train_net_video.py:134-186): one group per trainable parameter, norm / embedding weight
+    decay overrides, 'backbone' matched against the MODULE name"""
+    import torch
+    from s2d_amd.modeling import build_kd_model
+    from s2d_amd.optim import param_groups_like_reference, ema_momentum_schedule
+    model = build_kd_model(num_queries=8, num_frames=2, num_points=64, dec_layers=3)
+    groups = param_groups_like_reference(model, 1e-4, 0.05, weight_decay_norm=0.0, weight_decay_embed=0.0, backbone_multiplier=0.1)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    assert len(groups) == len(trainable) and all(len(g["params"]) == 1 for g in groups)
+    by_id = {id(g["params"][0]): g for g in groups}
+    dec = model.student[1].predictor
+    assert by_id[id(dec.query_feat.weight)]["weight_decay"] == 0.0            # nn.Embedding
+    assert by_id[id(dec.decoder_norm.weight)]["weight_decay"] == 0.0          # nn.LayerNorm
+    lin = next(p for n, p in model.student[1].named_parameters() if n.endswith("linear1.weight"))
+    assert by_id[id(lin)]["weight_decay"] == 0.05 and by_id[id(lin)]["lr"] == 1e-4
+    # student.0.* is the backbone but the module NAME does not contain 'backbone': no multiplier, as in the reference
+    bb = next(iter(model.student[0].parameters()))
+    assert by_id[id(bb)]["lr"] == 1e-4
+    assert not any(id(p) in by_id for p in model.teacher.parameters())        # frozen teacher
+    assert abs(ema_momentum_schedule(0, 0.99, 0.9999, 1000) - 0.99) < 1e-12
+    assert abs(ema_momentum_schedule(1000, 0.99, 0.9999, 1000) - 0.9999) < 1e-12
