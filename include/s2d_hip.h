@@ -230,6 +230,30 @@ int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm,
  * of two full-tensor reductions and a host sync per pair.  inter [K][K] (zeroed here). */
 int s2d_mask_pair_counts_u64(const uint32_t *bits, int K, long words, unsigned long long *inter, hipStream_t stream);
 
+/* ---- COCO run-length encoding of masks (wire format after inference_video / of the keymask annotations) ------- */
+
+/* pycocotools rleEncode (third party, restated) of F binary masks u8 [F][H][W] (non-zero = set), column-major runs.
+ * Pass 1: col_off [F][W] = exclusive count of run boundaries before column x (a boundary = pixel != its column-major
+ * predecessor, the pixel before (0,0) counting as 0); nbound[F] = boundaries per mask (runs = nbound + 1); area[F] =
+ * set pixels (mask_util.area); bbox [F][4] = x, y, w, h of the tight box, 0,0,0,0 if empty (mask_util.toBbox).
+ * ytvis_eval.py:345-350, keymask_ident/annotations.py:100-106. */
+int s2d_rle_count_u8(const uint8_t *masks, int F, int H, int W, int *col_off, int *nbound, int *area, int *bbox,
+                     hipStream_t stream);
+
+/* Pass 2: positions[frame_off[f] + i] = column-major index x*H + y of the i-th boundary of mask f (ascending);
+ * frame_off[F] = exclusive prefix of nbound.  Run lengths are the differences (first run = positions[0], last =
+ * H*W - positions[last]). */
+int s2d_rle_positions_u8(const uint8_t *masks, int F, int H, int W, const int *col_off, const long *frame_off,
+                         int *positions, hipStream_t stream);
+
+/* maskApi.c rleToString on the device: the run lengths implied by `positions` (frame_off [F+1] = exclusive prefix of
+ * nbound, ncounts = frame_off[F] + F runs in all) become the ASCII strings, concatenated in chars (capacity 7 * ncounts
+ * bytes); str_off [F+1] = byte offset of every mask's string (str_off[F] = total).  hw = H*W.
+ * workspace: s2d_rle_string_workspace_bytes(ncounts) bytes. */
+long s2d_rle_string_workspace_bytes(long ncounts);
+int s2d_rle_strings_u8(const int *positions, const long *frame_off, int F, long hw, long ncounts, void *workspace,
+                       long workspace_bytes, uint8_t *chars, long *str_off, hipStream_t stream);
+
 /* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */
 
 /* Tensor table shared by the two entry points (all arrays on the device): ptrs [ntensors][5] = {param, grad or NULL,

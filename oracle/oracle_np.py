@@ -705,3 +705,68 @@ def local_correlation(fmap, coords, support, r=3):
                 nb += np.where(ok[..., None], v, 0.0) * w[..., None]
         out[t] = np.einsum("nic,njc->nij", nb, support.astype(np.float64))
     return out
+
+
+# --------------------------------------------------------------------------- COCO RLE (pycocotools, third party: restated, unpinned)
+def rle_encode(mask):
+    """maskApi.c rleEncode + rleToString for one [H,W] mask (what mask_util.encode returns for np.array(mask[:, :, None],
+    order="F"): ytvis_eval.py:347, keymask_ident/annotations.py:100).  Pure-python loops: small cases only."""
+    H, W = mask.shape
+    flat = (np.asarray(mask) != 0).T.reshape(-1)          # column-major
+    cnts, p, c = [], False, 0
+    for v in flat:
+        if v != p:
+            cnts.append(c)
+            c, p = 0, v
+        c += 1
+    cnts.append(c)
+    s = bytearray()
+    for i, x in enumerate(cnts):
+        x = int(x)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            s.append(ch + 48)
+    return {"size": [H, W], "counts": bytes(s)}, cnts
+
+
+def rle_decode(rle):
+    """rleFrString + rleDecode: the inverse, used for round-trip checks"""
+    H, W = rle["size"]
+    s = rle["counts"] if isinstance(rle["counts"], (bytes, bytearray)) else rle["counts"].encode()
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            ch = s[p] - 48
+            x |= (ch & 0x1F) << (5 * k)
+            more = bool(ch & 0x20)
+            p += 1
+            k += 1
+            if not more and (ch & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    flat = np.zeros(H * W, np.uint8)
+    pos, v = 0, 0
+    for c in cnts:
+        flat[pos:pos + c] = v
+        pos += c
+        v ^= 1
+    return flat.reshape(W, H).T
+
+
+def rle_area_bbox(mask):
+    """mask_util.area / toBbox of a binary mask: set pixels; tight [x, y, w, h], zeros when empty"""
+    m = np.asarray(mask) != 0
+    if not m.any():
+        return 0, [0.0, 0.0, 0.0, 0.0]
+    ys, xs = np.nonzero(m)
+    return int(m.sum()), [float(xs.min()), float(ys.min()), float(xs.max() - xs.min() + 1), float(ys.max() - ys.min() + 1)]

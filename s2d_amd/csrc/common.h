@@ -28,6 +28,10 @@ int s2d_zero_async(void *p, size_t bytes, hipStream_t stream);
 int s2d_radix_sort_pairs_u32(const unsigned int *keys_in, unsigned int *keys_out, const unsigned int *vals_in, unsigned int *vals_out,
                              size_t n, int end_bit, void *temp, size_t temp_bytes, hipStream_t stream);
 
+// exclusive prefix sum of n ints (sort.hip, rocPRIM)
+int s2d_exclusive_scan_i32(const int *in, int *out, size_t n, void *temp, size_t temp_bytes, hipStream_t stream);
+size_t s2d_exclusive_scan_i32_temp_bytes(size_t n);
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float wave_sum(float v)
 {

@@ -36,11 +36,12 @@ def greedy_mask_nms(inter, labels, thr):
 
 @torch.no_grad()
 def inference_video(class_logits, mask_logits, dims, padded, img_size, out_size, num_predictions, use_nms=False,
-                    nms_threshold=0.75):
+                    nms_threshold=0.75, rle=False):
     """class_logits [Q,C+1]; mask_logits pixel-major [T*hm*wm, ldq] of ONE video; dims = (T, hm, wm); padded = network
     input size (Hp,Wp), img_size = size without padding, out_size = (height, width) of the original video.
     Returns the reference's dict: image_size, pred_scores (list of float), pred_labels (list of int), pred_masks (list of
-    CPU bool tensors [T,H,W])."""
+    CPU bool tensors [T,H,W]).  rle=True: the masks stay on the device and `pred_masks` holds, per prediction, the list of T
+    COCO RLE dicts that instances_to_coco_json_video (data_video/ytvis_eval.py:345-350) would build from them."""
     if class_logits.shape[0] == 0:                                   # :584-587
         return {"image_size": tuple(out_size), "pred_scores": [], "pred_labels": [], "pred_masks": []}
     scores, query, label = ops.infer_select(class_logits, num_predictions)
@@ -51,6 +52,10 @@ def inference_video(class_logits, mask_logits, dims, padded, img_size, out_size,
         keep = greedy_mask_nms(inter, labels_h, nms_threshold)
         sel = torch.as_tensor(keep, device=masks.device, dtype=torch.long)
         masks, scores, label = masks[sel], scores[sel], label[sel]
+    if rle:
+        from ..rle import encode_video_predictions
+        return {"image_size": tuple(out_size), "pred_scores": scores.tolist(), "pred_labels": label.tolist(),
+                "pred_masks": encode_video_predictions(masks), "pred_masks_format": "coco_rle"}
     masks_h = torch.empty(masks.shape, dtype=torch.uint8, pin_memory=True)   # pinned: the copy runs at PCIe rate, not pageable rate
     masks_h.copy_(masks, non_blocking=True)
     torch.cuda.current_stream().synchronize()
