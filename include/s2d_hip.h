@@ -296,6 +296,14 @@ int s2d_point_id_counts(const uint8_t *point_masks, const int64_t *idmap, int T,
 /* presence[t][id] = id occurs in frame t (torch.unique at :680); u8 [T][max_id+1]. */
 int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_id, uint8_t *presence, hipStream_t stream);
 
+/* load_masks (cotracker_matching.py:22-84) after the PNG decode: rgb u8 [T][H][W][3] -> ids int64 [T][H][W], per frame
+ * black = 0 and the other distinct colours 1..n in lexicographic (R,G,B) order; n_ids[T] = n.  At most 4096 distinct
+ * colours per frame: *overflow is set to 1 otherwise (ids are then invalid).  workspace: s2d_color_ids_workspace_words(T)
+ * 32-bit words. */
+long s2d_color_ids_workspace_words(int T);
+int s2d_color_masks_to_ids(const uint8_t *rgb, int T, int H, int W, unsigned int *workspace, int *n_ids, int64_t *ids,
+                           int *overflow, hipStream_t stream);
+
 /* cotracker_occlusions.py:359: curve[t] = mean_n(visibility[t][n] != 0). */
 int s2d_visibility_curve_f32(const uint8_t *visibility, int T, int Np, float *curve, hipStream_t stream);
 

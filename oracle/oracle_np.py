@@ -643,6 +643,19 @@ def kd_forward_losses(s_logits, s_masks, gt_targets, kd_tgts, rand_gt, rand_kd, 
 
 
 # --------------------------------------------------------------------------- keymask (paths rel. /root/reference/keymask_ident)
+def color_masks_to_ids(frames):
+    """load_masks, cotracker_matching.py:49-72 (after the PNG decode): frames u8 [T,H,W,3] RGB -> int64 [T,H,W,1]; per frame
+    black 0, the other unique colours 1..n in sorted (R,G,B) order (tuple order == order of the packed 24-bit key)."""
+    T, H, W, _ = frames.shape
+    out = np.zeros((T, H, W, 1), np.int64)
+    for t in range(T):
+        key = (frames[t, ..., 0].astype(np.int64) << 16) | (frames[t, ..., 1].astype(np.int64) << 8) | frames[t, ..., 2]
+        uniq = np.unique(key)
+        uniq = uniq[uniq != 0]
+        out[t, ..., 0] = np.where(key == 0, 0, np.searchsorted(uniq, key) + 1)
+    return out
+
+
 def tracks_to_masks(tracks, H, W):
     """pred_tracks_to_binary_masks(return_mask=False), cotracker_matching.py:453-503. tracks [T,Np,2] -> [T,H,W] u8."""
     tr = _c(tracks, np.float32)

@@ -128,9 +128,117 @@ __global__ __launch_bounds__(256) void local_corr_kernel(const float *__restrict
     }
 }
 
+// ---- colour masks -> id maps (load_masks, cotracker_matching.py:22-84) ------------------------------------------------
+// Per frame: the distinct non-black colours, sorted lexicographically by (R,G,B) (= numerically as R<<16|G<<8|B), get ids
+// 1..n; black is 0.  The reference loops over the colours with a full-frame compare each (O(#colours * H * W) numpy); here:
+// (1) distinct keys of a frame go into a small open-addressing table -- a lane skips the atomic when its left neighbour in
+// the wave holds the same key, which is almost always (masks are piecewise constant); (2) one workgroup per frame sorts
+// the table (bitonic, LDS); (3) every pixel looks its key up by binary search in the sorted list held in LDS.
+constexpr int IDSLOTS = 8192, IDMAX = 4096;           // table slots / most distinct colours per frame
+constexpr unsigned int IDEMPTY = 0u;                  // black is never inserted, so 0 marks a free slot (table zero-filled)
+
+__device__ __forceinline__ unsigned int rgb_key(const uint8_t *__restrict__ px)
+{
+    return ((unsigned int)px[0] << 16) | ((unsigned int)px[1] << 8) | (unsigned int)px[2];
+}
+
+__global__ __launch_bounds__(256) void idmap_collect_kernel(const uint8_t *__restrict__ rgb, long HW, unsigned int *__restrict__ table,
+                                                            int *__restrict__ overflow)
+{
+    const int t = blockIdx.y;
+    unsigned int *tab = table + (long)t * IDSLOTS;
+    const uint8_t *fr = rgb + (long)t * HW * 3;
+    const long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const int lane = threadIdx.x & 63;
+    for (long base = p0; base < p1; base += 256) {          // uniform trip count per block: shuffles need whole waves
+        const long i = base + threadIdx.x;
+        const unsigned int key = i < p1 ? rgb_key(fr + i * 3) : 0u;
+        const unsigned int left = __shfl_up(key, 1, 64);
+        if (key != 0u && (lane == 0 || left != key)) {
+            unsigned int h = (key * 2654435761u) >> 19;     // 13 bits
+            int probes = 0;
+            while (true) {
+                const unsigned int old = atomicCAS(&tab[h], IDEMPTY, key);
+                if (old == IDEMPTY || old == key) break;
+                h = (h + 1) & (IDSLOTS - 1);
+                if (++probes >= IDSLOTS) { atomicExch(overflow, 1); break; }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void idmap_sort_kernel(unsigned int *__restrict__ table, int *__restrict__ n_ids, int *__restrict__ overflow)
+{
+    __shared__ unsigned int s[IDSLOTS];
+    __shared__ int cnt;
+    unsigned int *tab = table + (long)blockIdx.x * IDSLOTS;
+    if (threadIdx.x == 0) cnt = 0;
+    for (int i = threadIdx.x; i < IDSLOTS; i += 1024) s[i] = tab[i];
+    __syncthreads();
+    for (int k = 2; k <= IDSLOTS; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < IDSLOTS; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned int a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    int mine = 0;
+    for (int i = threadIdx.x; i < IDSLOTS; i += 1024) { tab[i] = s[i]; mine += s[i] != IDEMPTY; }
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n_ids[blockIdx.x] = cnt;
+        if (cnt > IDMAX) atomicExch(overflow, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void idmap_apply_kernel(const uint8_t *__restrict__ rgb, long HW, const unsigned int *__restrict__ table,
+                                                          const int *__restrict__ n_ids, int64_t *__restrict__ ids)
+{
+    __shared__ unsigned int s[IDMAX];
+    const int t = blockIdx.y;
+    const int n = min(n_ids[t], IDMAX);
+    for (int i = threadIdx.x; i < n; i += 256) s[i] = table[(long)t * IDSLOTS + (IDSLOTS - n) + i];   // empties (0) sort first
+    __syncthreads();
+    const uint8_t *fr = rgb + (long)t * HW * 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const unsigned int key = rgb_key(fr + i * 3);
+        int lo = 0, hi = n;                              // first index with s[idx] >= key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        ids[(long)t * HW + i] = key == 0u ? 0 : (int64_t)(lo + 1);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+long s2d_color_ids_workspace_words(int T) { return (long)T * IDSLOTS; }
+
+int s2d_color_masks_to_ids(const uint8_t *rgb, int T, int H, int W, unsigned int *workspace, int *n_ids, int64_t *ids, int *overflow,
+                           hipStream_t stream)
+{
+    if (T < 0 || H < 1 || W < 1) return S2D_ERR_ARG;
+    if (s2d_zero_async(overflow, sizeof(int), stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (T == 0) return S2D_OK;
+    const long HW = (long)H * W;
+    if (s2d_zero_async(workspace, sizeof(unsigned int) * (size_t)T * IDSLOTS, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    const int bx = (int)(HW / 4096 > 0 ? (HW / 4096 < 256 ? HW / 4096 : 256) : 1);
+    hipLaunchKernelGGL(idmap_collect_kernel, dim3(bx, T), dim3(256), 0, stream, rgb, HW, workspace, overflow);
+    hipLaunchKernelGGL(idmap_sort_kernel, dim3(T), dim3(1024), 0, stream, workspace, n_ids, overflow);
+    hipLaunchKernelGGL(idmap_apply_kernel, dim3(bx, T), dim3(256), 0, stream, rgb, HW, workspace, n_ids, ids);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_tracks_to_masks_u8(const float *tracks, int T, int Np, int H, int W, uint8_t *masks, hipStream_t stream)
 {

@@ -82,6 +82,24 @@ def extract_mask_matches(segm_mask_hw, pred_tracks, idmap: IdMap, v_range, match
     return matches, allc
 
 
+def color_masks_to_ids(rgb):
+    """load_masks (cotracker_matching.py:22-84) after the PNG decode: rgb CUDA u8 [T,H,W,3] -> int64 [T,H,W,1]; per frame
+    black -> 0, the other colours -> 1..n in sorted (R,G,B) order.  Raises if a frame has more than 4096 colours."""
+    ops._chk(rgb, torch.uint8)
+    T, H, W, C = rgb.shape
+    if C != 3:
+        raise ValueError("rgb must be [T,H,W,3]")
+    dev = rgb.device
+    ws = torch.empty((lib().call("s2d_color_ids_workspace_words", T),), device=dev, dtype=torch.int32)
+    n_ids = torch.empty((T,), device=dev, dtype=torch.int32)
+    ids = torch.empty((T, H, W, 1), device=dev, dtype=torch.int64)
+    ovf = torch.empty((1,), device=dev, dtype=torch.int32)
+    lib().call("s2d_color_masks_to_ids", rgb, T, H, W, ws, n_ids, ids, ovf, _stream())
+    if int(ovf) != 0:
+        raise RuntimeError("a frame holds more than 4096 distinct colours: not a colour-mask image")
+    return ids
+
+
 def visibility_curve(pred_visibility):
     """pred_visibility [1,T,P] bool -> [T] float32 (cotracker_occlusions.py:359)"""
     v = pred_visibility[0].to(device="cuda", dtype=torch.uint8).contiguous()

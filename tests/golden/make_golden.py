@@ -586,12 +586,49 @@ def g_inference():
     save("inference", **arrs)
 
 
+def g_idmaps():
+    """cotracker_matching.py:22-84 load_masks: ordered multi-colour PNG masks -> per-frame id maps (black 0, the other
+    colours 1..n in lexicographic (R,G,B) order, numbered per frame).  The PNGs are written with PIL; OpenCV (absent) is
+    represented by three name-only stand-ins with its documented semantics: imread -> BGR array, cvtColor = channel swap."""
+    import tempfile
+    from PIL import Image
+    cv2 = sys.modules["cv2"]
+    cv2.IMREAD_COLOR, cv2.COLOR_BGR2RGB, cv2.COLOR_RGB2BGR = 1, 4, 4
+    cv2.imread = lambda p, flag=1: np.ascontiguousarray(np.array(Image.open(p).convert("RGB"))[..., ::-1])
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
+    km = R.ref("cotracker_matching")
+    seed, T, H, W = 97, 5, 40, 52
+    rng = synth.rng_for(seed, 0)
+    palette = rng.integers(0, 256, (9, 3)).astype(np.uint8)
+    palette[0] = (0, 0, 0)
+    palette[1] = (0, 0, 1)          # nearly black, blue only
+    palette[2] = (1, 0, 0)          # sorts after every (0, *, *) colour
+    palette[3] = (0, 255, 255)
+    palette[4] = (255, 255, 255)
+    frames = np.zeros((T, H, W, 3), np.uint8)
+    for t in range(T):
+        lab = np.zeros((H, W), np.int64)
+        use = rng.permutation(np.arange(1, 9))[:int(rng.integers(0, 8))] if t != 2 else np.array([], np.int64)   # frame 2: all black
+        for c in use:
+            cy, cx, ry, rx = rng.uniform(5, H - 5), rng.uniform(5, W - 5), rng.uniform(3, 10), rng.uniform(3, 12)
+            yy, xx = np.mgrid[0:H, 0:W]
+            lab[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = c
+        frames[t] = palette[lab]
+    with tempfile.TemporaryDirectory() as d:
+        for t in range(T):
+            Image.fromarray(frames[t]).save(os.path.join(d, f"frame{t:04d}.png"))
+        open(os.path.join(d, "notes.txt"), "w").write("ignored")
+        out = km.load_masks(d)
+    assert out.shape == (T, H, W, 1) and out.dtype == torch.int64
+    save("idmaps", seed=seed, frames=frames, ids=out.numpy().astype(np.int16), n_ids=np.array([int(out[t].max()) for t in range(T)]))
+
+
 def main():
     assert R.available(), "/root/reference not present: goldens can only be generated in the build container"
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

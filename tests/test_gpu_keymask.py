@@ -64,3 +64,28 @@ def test_local_correlation_vs_oracle(oracle):
     ref = oracle.local_correlation(fmap, coords, sup, r)
     out = km.local_correlation(torch.from_numpy(fmap).cuda(), torch.from_numpy(coords).cuda(), torch.from_numpy(sup).cuda(), r)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_color_masks_to_ids_golden_and_random(oracle):
+    """colour-PNG frames -> id maps (cotracker_matching.py:22-84): golden from the reference, then 500-colour frames vs the oracle"""
+    import torch
+    from tests.conftest import golden
+    from s2d_amd import keymask
+    g = golden("idmaps")
+    out = keymask.color_masks_to_ids(torch.from_numpy(g["frames"]).to("cuda:0"))
+    assert out.dtype == torch.int64 and tuple(out.shape) == g["ids"].shape
+    np.testing.assert_array_equal(out.cpu().numpy(), g["ids"])
+    rng = np.random.default_rng(0)
+    T, H, W = 3, 131, 97                                            # odd sizes; many colours; noisy (few runs)
+    pal = rng.integers(0, 256, (500, 3)).astype(np.uint8)
+    pal[0] = 0
+    lab = rng.integers(0, 500, (T, H, W))
+    lab[1] = np.repeat(np.repeat(rng.integers(0, 500, (H // 8 + 1, W // 8 + 1)), 8, 0), 8, 1)[:H, :W]   # blocky frame
+    lab[2] = 0                                                      # all black
+    frames = pal[lab]
+    out = keymask.color_masks_to_ids(torch.from_numpy(frames).to("cuda:0"))
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.color_masks_to_ids(frames))
+    # more than 4096 colours in a frame is refused loudly
+    many = rng.integers(0, 256, (1, 128, 128, 3)).astype(np.uint8)
+    with pytest.raises(RuntimeError):
+        keymask.color_masks_to_ids(torch.from_numpy(many).to("cuda:0"))

@@ -393,3 +393,12 @@ def test_rle_host_vectorised_strings_equal_oracle(oracle):
         r, cnts = oracle.rle_encode(g)
         assert list(counts[coff[f]:coff[f + 1]]) == cnts
         assert strs[f] == r["counts"]
+
+
+def test_color_masks_to_ids_golden(oracle):
+    """load_masks (cotracker_matching.py:22-84): golden from the reference's own function on PNGs written with PIL"""
+    g = golden("idmaps")
+    out = oracle.color_masks_to_ids(g["frames"])
+    assert out.dtype == np.int64 and out.shape == g["ids"].shape
+    np.testing.assert_array_equal(out, g["ids"])
+    assert [int(out[t].max()) for t in range(out.shape[0])] == g["n_ids"].tolist()
