@@ -241,6 +241,29 @@ class VideoMaskFormer(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
 
+    @classmethod
+    def from_config(cls, cfg):  # video_maskformer_model.py:97-187 (the sparse-class / entropy / DropLoss variants are not on the path)
+        mf = cfg.MODEL.MASK_FORMER
+        if getattr(mf, "SPARSE_CLASS_WEIGHT", 0.0) > 0.0 or getattr(mf, "MASK_DROPLOSS", False) or getattr(mf, "LABEL_DROPLOSS", False):
+            raise NotImplementedError("SPARSE_CLASS_WEIGHT / MASK_DROPLOSS / LABEL_DROPLOSS criterion variants")
+        head = MaskFormerHead.from_config(cfg)
+        cw, dw, mw = mf.CLASS_WEIGHT, mf.DICE_WEIGHT, mf.MASK_WEIGHT
+        matcher = VideoHungarianMatcher(0.0 if getattr(mf, "NO_CLASS_MATCH", False) else cw, mw, dw, mf.TRAIN_NUM_POINTS)
+        wd = {"loss_ce": cw, "loss_mask": mw, "loss_dice": dw}
+        if mf.DEEP_SUPERVISION:
+            aux = {}
+            for i in range(mf.DEC_LAYERS - 1):
+                aux.update({k + f"_{i}": v for k, v in wd.items()})
+            wd.update(aux)
+        crit = VideoSetCriterion(head.num_classes, matcher=matcher, weight_dict=wd, eos_coef=mf.NO_OBJECT_WEIGHT,
+                                 losses=["labels", "masks"], num_points=mf.TRAIN_NUM_POINTS, oversample_ratio=mf.OVERSAMPLE_RATIO,
+                                 importance_sample_ratio=mf.IMPORTANCE_SAMPLE_RATIO, loss_strategy=mf.LOSS_STRATEGY)
+        m = cls(backbone=ResNet50(), sem_seg_head=head, criterion=crit, num_queries=mf.NUM_OBJECT_QUERIES,
+                num_frames=cfg.INPUT.SAMPLING_FRAME_NUM, size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                pixel_std=cfg.MODEL.PIXEL_STD, **_test_kwargs(mf, "num_predictions"))
+        m.accum_iter = cfg.SOLVER.ACCUM_ITER
+        return m
+
     @property
     def device(self):
         return self.pixel_mean.device

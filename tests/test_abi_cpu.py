@@ -79,3 +79,35 @@ def test_kd_model_keys_and_weight_dict():
     wd = m.criterion.weight_dict
     assert len(wd) == 60 and wd["kd_loss_mask_8"] == 5.0 and wd["loss_ce"] == 0.0
     assert all(not p.requires_grad for p in m.teacher.parameters())
+
+
+def _reference_cfg():
+    """the keys of configs/imagenet_video/ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml (+ its bases) that the
+    path's from_config methods read, as the yacs node the reference passes"""
+    from types import SimpleNamespace as NS
+    mf = NS(NUM_OBJECT_QUERIES=100, DEC_LAYERS=10, HIDDEN_DIM=256, NHEADS=8, DIM_FEEDFORWARD=2048, DROPOUT=0.0, PRE_NORM=False,
+            ENFORCE_INPUT_PROJ=False, TRAIN_NUM_POINTS=12544, OVERSAMPLE_RATIO=3.0, IMPORTANCE_SAMPLE_RATIO=0.75,
+            CLASS_WEIGHT=2.0, MASK_WEIGHT=5.0, DICE_WEIGHT=5.0, KD_CLASS_WEIGHT=0.0, KD_MASK_WEIGHT=5.0, KD_DICE_WEIGHT=5.0,
+            NO_OBJECT_WEIGHT=0.1, DEEP_SUPERVISION=True, LOSS_STRATEGY="full", DISTILLATION_LOSS_STRATEGY="full",
+            NUM_PREDICTIONS_DISTILLATION=100, SCORE_THRESHOLD_DISTILLATION=0.75, SIZE_DIVISIBILITY=32,
+            TEST=NS(NUM_PREDICTIONS=10, USE_NMS=True, NMS_THRESH=0.75, EVAL_STUDENT=False))
+    return NS(MODEL=NS(MASK_FORMER=mf, SEM_SEG_HEAD=NS(CONVS_DIM=256, MASK_DIM=256, NUM_CLASSES=1, TRANSFORMER_ENC_LAYERS=6),
+                       PIXEL_MEAN=[123.675, 116.280, 103.530], PIXEL_STD=[58.395, 57.120, 57.375]),
+              INPUT=NS(SAMPLING_FRAME_NUM=2), SOLVER=NS(ACCUM_ITER=1))
+
+
+def test_meta_archs_build_from_config_through_the_registry():
+    """drop-in boundary 8b(1): both registry entries construct from the reference's config keys and expose what the trainer
+    touches (train_loop.py:355, 695-698, 754-764; checkpoint.py:211-236)"""
+    from s2d_amd.modeling.meta_arch import META_ARCH_REGISTRY
+    cfg = _reference_cfg()
+    kd = META_ARCH_REGISTRY.get("KDVideoMaskFormer").from_config(cfg)
+    wd = kd.criterion.weight_dict
+    assert len(wd) == 6 * 10 and wd["loss_mask_8"] == 5.0 and wd["kd_loss_ce"] == 0.0
+    assert kd.num_queries == 100 and kd.num_frames == 2 and kd.accum_iter == 1
+    assert (kd.use_nms, kd.nms_threshold, kd.num_predictions_inference, kd.eval_student) == (True, 0.75, 10, False)
+    assert all(k.startswith(("0.", "1.")) for k in kd.student.state_dict())            # student.0.* / student.1.*
+    assert not any(p.requires_grad for p in kd.teacher.parameters())
+    vm = META_ARCH_REGISTRY.get("VideoMaskFormer").from_config(cfg)
+    assert len(vm.criterion.weight_dict) == 3 * 10 and (vm.use_nms, vm.num_predictions) == (True, 10)
+    assert set(kd.student[1].state_dict()) == {k.replace("sem_seg_head.", "") for k in vm.state_dict() if k.startswith("sem_seg_head.")}
