@@ -140,12 +140,14 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
 /* floats of workspace s2d_masked_attn_f32 needs */
 long s2d_attn_workspace_floats(int B, int H, int K);
 
-/* out[b][q][:] = concat_h softmax_k(q_h k_h^T / sqrt(32) + mask) v_h with q [B][Q][C], k/v [B][K][C] already
- * projected, C = 32*H, Q <= 128.  bits/unmasked from s2d_attn_mask_bits (NULL = no mask: the self-attention
+/* out[b][q][:] = concat_h softmax_k(q_h k_h^T / sqrt(32) + mask) v_h with q [B][Q][C], k/v [B][K] rows of C floats
+ * at row strides ldk / ldv >= C (a column slice of a wider projection output; multiples of 4), already projected,
+ * C = 32*H, Q <= 128.  bits/unmasked from s2d_attn_mask_bits (NULL = no mask: the self-attention
  * of :41-51); a query with no attendable key attends everywhere (the fix at :413).  Replaces the core of
  * nn.MultiheadAttention at :99-111 without materialising the [B*8,Q,K] mask or the scores. */
-int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *unmasked,
-                        int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream);
+int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out,
+                        hipStream_t stream);
 
 /* ---- VideoHungarianMatcher on the device -------------------------------------------------------------- */
 /* A criterion pass handles NL prediction layers x B clips = NL*B independent "problems" (problem = layer*B +

@@ -132,6 +132,7 @@ struct AttnParams {
     const uint32_t *unmasked;    // [B][QW] or null
     float *wo, *wm, *wl;         // partials: wo [B][H][S][32][128], wm/wl [B][H][S][128]
     int Q, K, C, H, S, tiles_per_split;
+    long ldk, ldv;               // row strides of k and v (>= C): a slice of a wider projection output
     float qscale;                // 1/sqrt(d) * log2(e)
 };
 
@@ -181,16 +182,16 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
 
     // staging: thread t loads float4 #(t&7) of key row (t>>3) for K and V; threads < 128 load one mask word
     const int srow = tid >> 3, sc4 = tid & 7;
-    const float *kbase = p.k + (long)b * p.K * p.C + hd * 32 + sc4 * 4;
-    const float *vbase = p.v + (long)b * p.K * p.C + hd * 32 + sc4 * 4;
+    const float *kbase = p.k + (long)b * p.K * p.ldk + hd * 32 + sc4 * 4;
+    const float *vbase = p.v + (long)b * p.K * p.ldv + hd * 32 + sc4 * 4;
     f32x4 rk, rv;
     uint32_t rm = 0u;
     auto load_tile = [&](int tile) {
         const long key = (long)tile * KT + srow;
         rk = f32x4(0.f); rv = f32x4(0.f);
         if (key < p.K) {
-            rk = *reinterpret_cast<const f32x4 *>(kbase + key * p.C);
-            rv = *reinterpret_cast<const f32x4 *>(vbase + key * p.C);
+            rk = *reinterpret_cast<const f32x4 *>(kbase + key * p.ldk);
+            rv = *reinterpret_cast<const f32x4 *>(vbase + key * p.ldv);
         }
         if (p.bits && tid < KT * QW) {
             const long mk = (long)tile * KT + (tid >> 2);
@@ -352,15 +353,16 @@ long s2d_attn_workspace_floats(int B, int H, int K)
     return (long)B * H * S * (32 * 128 + 2 * 128);
 }
 
-int s2d_masked_attn_f32(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *unmasked,
-                        int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream)
+int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream)
 {
-    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0) return S2D_ERR_ARG;
+    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0 || ldk < C || ldv < C || (ldk & 3) || (ldv & 3)) return S2D_ERR_ARG;
     if (B == 0) return S2D_OK;
     const int tiles = (K + KT - 1) / KT;
     int S = tiles / 4; if (S < 1) S = 1; if (S > 32) S = 32;   // 64 / 128 splits measured slower (merge + per-workgroup fixed cost)
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.bits = bits; p.unmasked = unmasked;
+    p.ldk = ldk; p.ldv = ldv;
     p.Q = Q; p.K = K; p.C = C; p.H = H; p.S = S; p.tiles_per_split = (tiles + S - 1) / S;
     p.wo = workspace;
     p.wm = workspace + (long)B * H * S * 32 * 128;

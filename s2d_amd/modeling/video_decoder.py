@@ -64,7 +64,7 @@ class SelfAttentionLayer(nn.Module):
         qk_in = ops.add_bcast(tgt, query_pos)
         qk = ops.gemm_nt(qk_in.view(-1, C), W[:2 * C], bias=bi[:2 * C]).view(B, Q, 2 * C)
         v = ops.gemm_nt(tgt.view(-1, C), W[2 * C:], bias=bi[2 * C:]).view(B, Q, C)
-        a = ops.masked_attn(qk[..., :C].contiguous(), qk[..., C:].contiguous(), v, H=self.nhead)
+        a = ops.masked_attn(qk[..., :C].contiguous(), qk[..., C:], v, H=self.nhead)        # k: a column slice, read in place
         x = ops.gemm_nt(a.view(-1, C), self.self_attn.out_proj.weight, bias=self.self_attn.out_proj.bias, res=tgt.view(-1, C))
         return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
 
@@ -76,13 +76,12 @@ class CrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
 
-    def forward(self, tgt, k_in, v_in, bits, unmasked, query_pos):  # forward_post :99-111
+    def forward(self, tgt, k, v, bits, unmasked, query_pos):  # forward_post :99-111
+        """k, v [B,K,C]: the memory already through this layer's key / value projections (column slices of the per-level
+        projections the decoder makes once for the three layers that read a level, `_project_memory`)."""
         B, Q, C = tgt.shape
-        K = k_in.shape[1]
         W, bi = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
         q = ops.gemm_nt(ops.add_bcast(tgt, query_pos).view(-1, C), W[:C], bias=bi[:C]).view(B, Q, C)
-        k = ops.gemm_nt(k_in.view(-1, C), W[C:2 * C], bias=bi[C:2 * C]).view(B, K, C)
-        v = ops.gemm_nt(v_in.view(-1, C), W[2 * C:], bias=bi[2 * C:]).view(B, K, C)
         a = ops.masked_attn(q, k, v, bits, unmasked, H=self.nhead)
         x = ops.gemm_nt(a.view(-1, C), self.multihead_attn.out_proj.weight, bias=self.multihead_attn.out_proj.bias,
                         res=tgt.view(-1, C))
@@ -139,6 +138,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self._pos_cache = {}
         self._tap_cache = {}
+        self._kv_cache = None
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification=True):  # :344-372
@@ -157,6 +157,39 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
                 ops.pe_sine(T, h, w, self.hidden_dim // 2, add_c=le[i].detach().contiguous(), device=device)
                 for i, (h, w) in enumerate(sizes)]}
         return self._pos_cache["posl"]
+
+    def _kv_packed(self):
+        """per level: the key and the value in-projection weights / biases of the layers that attend to it (i % 3 == level),
+        stacked to [n*C, C] so that the memory of a level is read once for all of them instead of once per layer"""
+        C = self.hidden_dim
+        mh = [l.multihead_attn for l in self.transformer_cross_attention_layers]
+        key = tuple(m.in_proj_weight._version for m in mh) + tuple(m.in_proj_bias._version for m in mh) + (mh[0].in_proj_weight.device,)
+        if self._kv_cache is None or self._kv_cache[0] != key:
+            packs = []
+            for lvl in range(3):
+                ms = [mh[i] for i in range(self.num_layers) if i % 3 == lvl]
+                wk = torch.cat([m.in_proj_weight.detach()[C:2 * C] for m in ms], 0).contiguous()
+                bk = torch.cat([m.in_proj_bias.detach()[C:2 * C] for m in ms], 0).contiguous()
+                wv = torch.cat([m.in_proj_weight.detach()[2 * C:] for m in ms], 0).contiguous()
+                bv = torch.cat([m.in_proj_bias.detach()[2 * C:] for m in ms], 0).contiguous()
+                packs.append((ops.mark_static(wk), bk, ops.mark_static(wv), bv))
+            self._kv_cache = (key, packs)
+        return self._kv_cache[1]
+
+    def _project_memory(self, multi_scale, B, T, posl):
+        """keys and values of every layer, per level [B, T*h*w, n*C] (layer i reads columns (i // 3)*C .. of level i % 3).
+        K_i = (src + level_embed + pos) . Wk_i^T + bk_i as the reference forms it (:386-394, nn.MultiheadAttention);
+        V_i = (src + level_embed) . Wv_i^T + bv_i = src . Wv_i^T + (level_embed . Wv_i^T + bv_i): the bracket is one row
+        per level and layer, so src + level_embed is never stored."""
+        C = self.hidden_dim
+        ks, vs = [], []
+        for lvl, ((tok, (h, w)), (wk, bk, wv, bv)) in enumerate(zip(multi_scale, self._kv_packed())):
+            x = tok.view(B, T * h * w, C)
+            kin = ops.add_bcast(x, posl[lvl])                                               # src + level_embed + pos
+            ks.append(ops.gemm_nt(kin.view(-1, C), wk, bias=bk).view(B, T * h * w, -1))
+            bvf = ops.gemm_nt(self.level_embed.weight[lvl:lvl + 1].detach().contiguous(), wv, bias=bv).view(-1)
+            vs.append(ops.gemm_nt(x.reshape(-1, C), wv, bias=bvf).view(B, T * h * w, -1))
+        return ks, vs
 
     def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm, ml_slot=None, mf_taps=None):
         """forward_prediction_heads :448-467 for all clips; writes slot `layer_slot` of the class buffer and slot `ml_slot`
@@ -190,11 +223,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         dev = mask_features.device
         sizes = [s for _, s in multi_scale]
         posl = self._pos(T, sizes, dev)
-        k_in, v_in = [], []
-        for i, (tok, (h, w)) in enumerate(multi_scale):
-            x = tok.view(B, T * h * w, C)
-            k_in.append(ops.add_bcast(x, posl[i]))                                         # src + level_embed + pos
-            v_in.append(ops.add_bcast(x, self.level_embed.weight[i].detach().contiguous()))  # src + level_embed
+        ks, vs = self._project_memory(multi_scale, B, T, posl)
         mf = mask_features.view(B, T * hm * wm, C)
         ldq = (Q + 3) // 4 * 4
         # slot s (the prediction after layer s-1) feeds the attention mask of layer s at level s % 3; a level whose keys
@@ -225,7 +254,8 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         bits, unm = heads(0, output)
         for i in range(self.num_layers):
             lvl = i % 3
-            output = self.transformer_cross_attention_layers[i](output, k_in[lvl], v_in[lvl], bits, unm, qe)
+            c0 = (i // 3) * C
+            output = self.transformer_cross_attention_layers[i](output, ks[lvl][..., c0:c0 + C], vs[lvl][..., c0:c0 + C], bits, unm, qe)
             output = self.transformer_self_attention_layers[i](output, qe)
             output = self.transformer_ffn_layers[i](output)
             bits, unm = heads(i + 1, output)

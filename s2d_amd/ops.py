@@ -284,15 +284,17 @@ def attn_mask_tap_index(T, hm, wm, hl, wl, device):
 
 
 def masked_attn(q, k, v, bits=None, unmasked=None, H=8):
-    """q [B,Q,C], k/v [B,K,C] (projected) -> [B,Q,C]."""
-    for t in (q, k, v):
-        _chk(t)
+    """q [B,Q,C], k/v [B,K,C] (projected; k and v may be column slices of a wider [B,K,ld] projection output) -> [B,Q,C]."""
+    _chk(q)
     B, Q, C = q.shape
     K = k.shape[1]
+    for t in (k, v):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(0) == K * t.stride(1)):
+            raise RuntimeError("k / v must be float32 CUDA [B,K,C] with unit column stride and batch stride K * row stride")
     n = lib().call("s2d_attn_workspace_floats", B, H, K)
     ws = torch.empty((n,), device=q.device, dtype=torch.float32)
     out = torch.empty_like(q)
-    lib().call("s2d_masked_attn_f32", q, k, v, bits, unmasked, B, Q, K, C, H, ws, out, _stream())
+    lib().call("s2d_masked_attn_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, B, Q, K, C, H, ws, out, _stream())
     return out
 
 

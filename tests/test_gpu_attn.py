@@ -94,3 +94,20 @@ def test_attn_mask_bits_compact_matches_full():
         b0, u0 = ops.attn_mask_bits(ml, B, Q, T, hm, wm, hl, wl)
         b1, u1 = ops.attn_mask_bits(ml.index_select(1, idx).contiguous(), B, Q, T, hm, wm, hl, wl, compact=True)
         assert torch.equal(b0, b1) and torch.equal(u0, u1)
+
+
+def test_masked_attn_reads_column_slices_in_place():
+    """k / v as column slices of a wider projection output (row stride > C) == the same values copied out, bitwise"""
+    import torch
+    from s2d_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, Q, K, C = 2, 100, 1500, 256
+    q = torch.randn((B, Q, C), device="cuda", generator=g)
+    wide_k = torch.randn((B, K, 3 * C), device="cuda", generator=g)
+    wide_v = torch.randn((B, K, 2 * C), device="cuda", generator=g)
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (B, K, 4), device="cuda", dtype=torch.int32, generator=g)
+    unm = torch.full((B, 4), -1, device="cuda", dtype=torch.int32)
+    ks, vs = wide_k[..., C:2 * C], wide_v[..., C:]
+    a = ops.masked_attn(q, ks, vs, bits, unm)
+    b = ops.masked_attn(q, ks.contiguous(), vs.contiguous(), bits, unm)
+    assert torch.equal(a, b)
