@@ -5,11 +5,12 @@
     python scripts/pmc_traffic.py gpurun_out/pmc_FETCH gpurun_out/pmc_WRITE profiles/r1_pmc_traffic.json
 
 Counter unit is KB.  FETCH_SIZE is doubled for the "corrected" figures (MI355X_MICROARCH.md: it under-reports wide
-coalesced reads 2x on gfx950); WRITE_SIZE is used as is.  Launch counts include the calibration forward and the warmup
-step: 1 + 1 + 2 steps minus the loss-free calibration = 3.5 step-equivalents of forward work."""
+coalesced reads 2x on gfx950); WRITE_SIZE is used as is.  Launch counts include everything bench.py runs: the loss-free
+calibration forward (0.5 step), the warmup step, the 2 timed steps and, with the default two-stream schedule, the two
+re-check steps of the bitwise comparison: 5.5 step-equivalents (3.5 with --no-overlap; pass the figure as 4th argument)."""
 import collections, csv, glob, json, sys
 
-STEP_EQUIV = 3.5
+STEP_EQUIV = float(sys.argv[4]) if len(sys.argv) > 4 else 5.5
 
 
 def family(name):
