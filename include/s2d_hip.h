@@ -256,6 +256,18 @@ long s2d_rle_string_workspace_bytes(long ncounts);
 int s2d_rle_strings_u8(const int *positions, const long *frame_off, int F, long hw, long ncounts, void *workspace,
                        long workspace_bytes, uint8_t *chars, long *str_off, hipStream_t stream);
 
+/* ---- gradients of the dense layers: HBM-bound helpers around s2d_gemm_nt_f32 ----------- */
+
+/* out[c][r] = in[r][c]; in [R][ldi], out [C][ldo].  dW = dY^T . X runs as an NT GEMM on the transposed operands. */
+int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream);
+
+/* out[i] = beta * out[i] + sum_{s < S} part[s * stride + i], s ascending (fixed order: reproducible split-K) */
+int s2d_reduce_slices_f32(const float *part, int S, long n, long stride, float beta, float *out, hipStream_t stream);
+
+/* part[s][c] = sum of in[r][c] over the rows of slice s (rows_per_slice rows each, ceil(R / rows_per_slice) slices):
+ * bias gradients, finished by s2d_reduce_slices_f32 */
+int s2d_colsum_slices_f32(const float *in, long R, long C, long ldi, long rows_per_slice, float *part, hipStream_t stream);
+
 /* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */
 
 /* Tensor table shared by the two entry points (all arrays on the device): ptrs [ntensors][5] = {param, grad or NULL,

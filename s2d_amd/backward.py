@@ -1,0 +1,83 @@
+"""Gradients of the dense layers on the forward kernels (csrc/backward.hip for the helpers).
+
+What `losses.backward()` (engine/train_loop.py:720) does for an nn.Linear / 1x1 convolution y = x W^T + b:
+    dx = dy W,   dW = dy^T x,   db = sum_rows dy.
+dx is an NT GEMM against W^T.  dW contracts over the M rows (3e5..9e5): dy and x are transposed once, the contraction is
+cut into S slices that run as the batch dimension of ONE NT-GEMM launch, and the S partial products are added in a
+fixed order, so the result is reproducible.  Same split-fp16 x3 arithmetic as the forward (fp32-class accuracy)."""
+import torch
+
+from . import ops
+from ._lib import lib
+
+
+def _st():
+    return ops._stream()
+
+
+def transpose(x, pad_to=None):
+    """x [R,C] -> [C, ld] with ld = pad_to or R (columns >= R zero-filled)"""
+    ops._chk(x)
+    R, C = x.shape
+    ld = pad_to or R
+    out = torch.empty((C, ld), device=x.device, dtype=torch.float32) if ld == R else torch.zeros((C, ld), device=x.device, dtype=torch.float32)
+    lib().call("s2d_transpose_f32", x, R, C, C, out, ld, _st())
+    return out
+
+
+def _slices(M, out_tiles):
+    """number of contraction slices: enough workgroups to fill 256 CUs twice, slices of at least 512 rows, multiple of 32"""
+    S = max(1, min((512 + out_tiles - 1) // out_tiles, M // 512 if M >= 512 else 1, 256))
+    chunk = ((M + S - 1) // S + 31) // 32 * 32
+    S = (M + chunk - 1) // chunk
+    return S, chunk
+
+
+def weight_grad(dy, x, out=None, beta=0.0):
+    """dW [N,K] = dy[M,N]^T @ x[M,K]  (out given: out = beta * out + dW)"""
+    ops._chk(dy); ops._chk(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M
+    S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128))
+    Mp = S * chunk
+    dyt, xt = transpose(dy, Mp), transpose(x, Mp)
+    part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
+    # batch b: A = dyt[:, b*chunk : (b+1)*chunk] (row stride Mp), B = xt[:, same], C = part[b]
+    lib().call("s2d_gemm_nt_f32", dyt, xt, part, N, K, chunk, Mp, Mp, K, S, chunk, chunk, N * K, None, None, None, K, 0, 0, 0, 0, None, _st())
+    if out is None:
+        out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+        beta = 0.0
+    lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
+    return out
+
+
+def bias_grad(dy, out=None, beta=0.0):
+    """db [N] = column sums of dy [M,N]"""
+    ops._chk(dy)
+    M, N = dy.shape
+    rows = max(256, (M + 255) // 256)
+    S = (M + rows - 1) // rows
+    part = torch.empty((S, N), device=dy.device, dtype=torch.float32)
+    lib().call("s2d_colsum_slices_f32", dy, M, N, N, rows, part, _st())
+    if out is None:
+        out = torch.empty((N,), device=dy.device, dtype=torch.float32)
+        beta = 0.0
+    lib().call("s2d_reduce_slices_f32", part, S, N, N, float(beta), out, _st())
+    return out
+
+
+def input_grad(dy, w, res=None):
+    """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection)"""
+    N = dy.shape[1]
+    Np = (N + 3) // 4 * 4                                             # the GEMM wants a contraction length % 4 == 0
+    wt = transpose(w.detach().contiguous())                           # [K,N]: small, once per step
+    if Np != N:                                                       # e.g. the 2-way class head: zero-pad the contraction
+        wt = torch.nn.functional.pad(wt, (0, Np - N))
+        dy = torch.nn.functional.pad(dy, (0, Np - N))
+    return ops.gemm_nt(dy, wt, res=res)
+
+
+def linear_backward(x, w, dy, need_dx=True, has_bias=True):
+    """gradients of y = x @ w.T + b -> (dx or None, dW, db or None)"""
+    return (input_grad(dy, w) if need_dx else None, weight_grad(dy, x), bias_grad(dy) if has_bias else None)
