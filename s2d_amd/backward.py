@@ -81,3 +81,63 @@ def input_grad(dy, w, res=None):
 def linear_backward(x, w, dy, need_dx=True, has_bias=True):
     """gradients of y = x @ w.T + b -> (dx or None, dW, db or None)"""
     return (input_grad(dy, w) if need_dx else None, weight_grad(dy, x), bias_grad(dy) if has_bias else None)
+
+
+# --------------------------------------------------------------------------- convolutions (NHWC, weights [Cout,KH,KW,Cin])
+def conv_input_grad(dy, w, stride, pad, in_hw):
+    """dx [N,H,W,Cin] of y = conv2d_nhwc(x, w, stride, pad): a stride-1 convolution of dy (zero-dilated by `stride`) with
+    the flipped, channel-transposed kernel and padding KH-1-pad -- the forward implicit-GEMM kernel again."""
+    ops._chk(dy)
+    N, Ho, Wo, Co = dy.shape
+    Co2, KH, KW, Ci = w.shape
+    H, W = in_hw
+    wf = w.detach().flip(1, 2).permute(3, 1, 2, 0).contiguous()       # [Cin,KH,KW,Cout]
+    if KH == 1 and KW == 1 and pad == 0:
+        g = ops.gemm_nt(dy.view(-1, Co), wf.view(Ci, Co)).view(N, Ho, Wo, Ci)
+        if stride == 1:
+            return g
+        dx = torch.zeros((N, H, W, Ci), device=dy.device, dtype=torch.float32)
+        dx[:, ::stride, ::stride][:, :Ho, :Wo] = g
+        return dx
+    if stride > 1:                                                     # zero-dilate: rows/cols of dy land on the stride grid
+        Hd, Wd = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1            # size that a stride-1 conv of x would have had
+        d = torch.zeros((N, Hd, Wd, Co), device=dy.device, dtype=torch.float32)
+        d[:, ::stride, ::stride][:, :Ho, :Wo] = dy
+        dy = d
+    return ops.conv2d_nhwc(dy, wf, stride=1, pad=KH - 1 - pad)
+
+
+def conv_weight_grad(dy, x, KH, KW, stride, pad):
+    """dW [Cout,KH,KW,Cin] = sum over positions of dy (x) shifted x.  On the zero-padded input grid a tap is a constant
+    offset of the flattened position, so with dy scattered onto that grid (zeros elsewhere) every tap is one contraction
+    dYg^T . shift(Xp): the transposed operands are made once and the KH*KW taps are NT GEMMs on shifted views of them
+    (contraction sliced and reduced in a fixed order as in weight_grad)."""
+    ops._chk(dy); ops._chk(x)
+    N, H, W, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    if KH == 1 and KW == 1 and pad == 0:
+        xs = x if stride == 1 else x[:, ::stride, ::stride][:, :Ho, :Wo].contiguous()
+        return weight_grad(dy.view(-1, Co), xs.view(-1, Ci)).view(Co, 1, 1, Ci)
+    Hp, Wp = H + 2 * pad, (W + 2 * pad + 3) // 4 * 4                   # row length % 4: row shifts stay 16-B aligned
+    xp = torch.zeros((N, Hp, Wp, Ci), device=x.device, dtype=torch.float32)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    dg = torch.zeros((N, Hp, Wp, Co), device=x.device, dtype=torch.float32)
+    dg[:, 0:Ho * stride:stride, 0:Wo * stride:stride] = dy             # output (y,x) reads input rows y*stride + ky
+    P = N * Hp * Wp
+    tail = (KH - 1) * Wp + KW                                          # the farthest shift a tap applies
+    S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 127) // 128))
+    Pp = S * chunk
+    dgt = transpose(dg.view(P, Co), Pp)                                # [Co, Pp]
+    ld = (Pp + tail + 3) // 4 * 4
+    xpt = transpose(xp.view(P, Ci), ld)                                # [Ci, ld], zero beyond P
+    part = torch.empty((S, Co, Ci), device=x.device, dtype=torch.float32)
+    dw = torch.empty((Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
+    tmp = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
+    for ky in range(KH):
+        for kx in range(KW):
+            shifted = xpt[:, ky * Wp + kx:]                            # a view: same row stride, later start
+            lib().call("s2d_gemm_nt_f32", dgt, shifted, part, Co, Ci, chunk, Pp, ld, Ci, S, chunk, chunk, Co * Ci, None, None, None, Ci,
+                       0, 0, 0, 0, None, _st())
+            lib().call("s2d_reduce_slices_f32", part, S, Co * Ci, Co * Ci, 0.0, tmp, _st())
+            dw[:, ky, kx] = tmp
+    return dw

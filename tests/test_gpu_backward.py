@@ -46,3 +46,27 @@ def test_transpose_odd_shapes():
         assert torch.equal(t[:, :R], x.t())
         if pad:
             assert float(t[:, R:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,KH,stride,pad", [(2, 23, 40, 64, 64, 3, 1, 1), (2, 24, 41, 128, 64, 3, 2, 1), (3, 16, 20, 256, 128, 1, 1, 0),
+                                                      (2, 17, 21, 64, 128, 1, 2, 0), (1, 46, 80, 256, 256, 3, 1, 1)])
+def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
+    from s2d_amd import backward, ops
+    g = torch.Generator().manual_seed(N * H + W + Ci + Co + KH + stride)
+    x = torch.randn((N, Ci, H, W), generator=g)
+    w = torch.randn((Co, Ci, KH, KH), generator=g) / (Ci * KH * KH) ** 0.5
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xd, wd, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy.double()).sum().backward()
+    x_h = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w_h = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dy_h = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    # forward first (same layout conventions as the gradients)
+    y_h = ops.conv2d_nhwc(x_h, w_h, stride=stride, pad=pad)
+    assert rel(y_h.permute(0, 3, 1, 2).cpu().numpy(), y.detach().numpy()) < 2e-6
+    dx = backward.conv_input_grad(dy_h, w_h, stride, pad, (H, W))
+    assert tuple(dx.shape) == (N, H, W, Ci)
+    assert rel(dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()) < 2e-6
+    dw = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
+    assert rel(dw.permute(0, 3, 1, 2).cpu().numpy(), wd.grad.numpy()) < 5e-6
