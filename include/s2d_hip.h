@@ -268,6 +268,18 @@ int s2d_reduce_slices_f32(const float *part, int S, long n, long stride, float b
  * bias gradients, finished by s2d_reduce_slices_f32 */
 int s2d_colsum_slices_f32(const float *in, long R, long C, long ldi, long rows_per_slice, float *part, hipStream_t stream);
 
+/* LayerNorm backward for y = LN(x + res) (res may be NULL) over the last dim C (C % 4 == 0, C <= 1024): dx [rows][C]
+ * (= the gradient of x and of res), and per-workgroup partials part [blocks][2][C] (dgamma rows, then dbeta rows) with
+ * blocks = s2d_layernorm_backward_blocks(rows); finish with s2d_reduce_slices_f32(part, blocks, 2*C, 2*C, ...). */
+long s2d_layernorm_backward_blocks(long rows);
+int s2d_layernorm_backward_f32(const float *x, const float *res, const float *dy, const float *gamma, long rows, int C,
+                               float eps, float *dx, float *part, hipStream_t stream);
+
+/* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
+ * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU).  n elements, C innermost. */
+int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz,
+                                hipStream_t stream);
+
 /* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */
 
 /* Tensor table shared by the two entry points (all arrays on the device): ptrs [ntensors][5] = {param, grad or NULL,

@@ -141,3 +141,29 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
             lib().call("s2d_reduce_slices_f32", part, S, Co * Ci, Co * Ci, 0.0, tmp, _st())
             dw[:, ky, kx] = tmp
     return dw
+
+
+# --------------------------------------------------------------------------- normalisation / activation
+def layernorm_backward(x, dy, gamma, res=None, eps=1e-5):
+    """y = LayerNorm(x + res) * gamma + beta -> (dx (also the gradient of res), dgamma, dbeta)"""
+    for t in (x, dy, gamma, res):
+        ops._chk(t)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    nb = lib().call("s2d_layernorm_backward_blocks", rows)
+    part = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    lib().call("s2d_layernorm_backward_f32", x, res, dy, gamma, rows, C, float(eps), dx, part, _st())
+    gb = torch.empty((2, C), device=x.device, dtype=torch.float32)
+    lib().call("s2d_reduce_slices_f32", part, nb, 2 * C, 2 * C, 0.0, gb, _st())
+    return dx, gb[0], gb[1]
+
+
+def relu_scale_backward(dy, y=None, scale=None):
+    """gradient through y = relu(z * scale + bias): dz = dy * (y > 0) * scale (channels innermost)"""
+    for t in (dy, y, scale):
+        ops._chk(t)
+    C = dy.shape[-1]
+    dz = torch.empty_like(dy)
+    lib().call("s2d_relu_scale_backward_f32", dy, y, scale, dy.numel(), C, dz, _st())
+    return dz

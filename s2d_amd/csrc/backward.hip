@@ -80,9 +80,125 @@ __global__ __launch_bounds__(256) void colsum_slices_kernel(const float *__restr
     part[(long)s * C + c] = (a0 + a1) + (a2 + a3);
 }
 
+// LayerNorm backward over the last dim C (C % 4 == 0, C <= 1024), one wavefront per row, the input row recomputed into
+// registers as the forward does (x + res; statistics in the forward's order):
+//   xhat = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),
+//   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy: each workgroup walks a fixed set of rows in a fixed order and
+//   leaves one partial row per quantity (part [nblocks][2][C]), finished by s2d_reduce_slices_f32 (reproducible).
+constexpr int LNB_ROWS = 64;       // rows per wavefront (a workgroup = 4 wavefronts = 256 rows)
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                                 const float *__restrict__ dy, const float *__restrict__ gamma, long rows,
+                                                                 int C, float eps, float *__restrict__ dx, float *__restrict__ part)
+{
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = C / 4;
+    f32x4 ga[4], dg[4], db[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c4 = lane + 64 * k;
+        ga[k] = c4 < q ? *reinterpret_cast<const f32x4 *>(gamma + c4 * 4) : f32x4(0.f);
+        dg[k] = f32x4(0.f); db[k] = f32x4(0.f);
+    }
+    const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
+    for (long row = r0; row < r0 + LNB_ROWS && row < rows; ++row) {
+        f32x4 v[4], d[4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c4 = lane + 64 * k;
+            v[k] = f32x4(0.f); d[k] = f32x4(0.f);
+            if (c4 < q) {
+                v[k] = *reinterpret_cast<const f32x4 *>(x + row * C + c4 * 4);
+                if (res) v[k] += *reinterpret_cast<const f32x4 *>(res + row * C + c4 * 4);
+                d[k] = *reinterpret_cast<const f32x4 *>(dy + row * C + c4 * 4);
+                s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+            }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c4 = lane + 64 * k;
+            if (c4 < q) {
+                v[k] = v[k] - mean;
+                ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = v[k] * rstd;                               // xhat (0 in the lanes beyond C)
+            const f32x4 g = d[k] * ga[k];
+            sg += g[0] + g[1] + g[2] + g[3];
+            sgx += g[0] * v[k][0] + g[1] * v[k][1] + g[2] * v[k][2] + g[3] * v[k][3];
+            dg[k] += d[k] * v[k];
+            db[k] += d[k];
+        }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c4 = lane + 64 * k;
+            if (c4 < q) *reinterpret_cast<f32x4 *>(dx + row * C + c4 * 4) = (d[k] * ga[k] - mg - v[k] * mgx) * rstd;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < q) {
+            *reinterpret_cast<f32x4 *>(&red[wv][0][c4 * 4]) = dg[k];
+            *reinterpret_cast<f32x4 *>(&red[wv][1][c4 * 4]) = db[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int w = i / C, c = i - w * C;
+        part[((long)blockIdx.x * 2 + w) * C + c] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
+    }
+}
+
+// dz = dy * (y > 0) * scale[c]: gradient through y = relu(z * scale + bias) (the conv -> FrozenBN -> ReLU epilogue);
+// scale NULL = 1, y NULL = no ReLU.  n elements, C channels innermost, 16-B accesses.
+__global__ __launch_bounds__(256) void relu_scale_backward_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                  const float *__restrict__ scale, long n4, int C4, float *__restrict__ dz)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 g = reinterpret_cast<const f32x4 *>(dy)[i];
+    if (y) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(y)[i];
+        g[0] = v[0] > 0.f ? g[0] : 0.f; g[1] = v[1] > 0.f ? g[1] : 0.f; g[2] = v[2] > 0.f ? g[2] : 0.f; g[3] = v[3] > 0.f ? g[3] : 0.f;
+    }
+    if (scale) g = g * reinterpret_cast<const f32x4 *>(scale)[i % C4];
+    reinterpret_cast<f32x4 *>(dz)[i] = g;
+}
+
 }  // namespace
 
 extern "C" {
+
+long s2d_layernorm_backward_blocks(long rows) { return (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS); }
+
+int s2d_layernorm_backward_f32(const float *x, const float *res, const float *dy, const float *gamma, long rows, int C, float eps,
+                               float *dx, float *part, hipStream_t stream)
+{
+    if ((C & 3) || C > 1024 || rows < 0) return S2D_ERR_ARG;
+    if (rows == 0) return S2D_OK;
+    hipLaunchKernelGGL(layernorm_backward_kernel, dim3((unsigned int)s2d_layernorm_backward_blocks(rows)), dim3(256), 0, stream, x, res, dy, gamma,
+                       rows, C, eps, dx, part);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz, hipStream_t stream)
+{
+    if ((n & 3) || (C & 3) || C <= 0 || n % C) return S2D_ERR_ARG;
+    if (n == 0) return S2D_OK;
+    hipLaunchKernelGGL(relu_scale_backward_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, dy, y, scale, n / 4, C / 4, dz);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream)
 {

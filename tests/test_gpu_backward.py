@@ -70,3 +70,30 @@ def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
     assert rel(dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()) < 2e-6
     dw = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
     assert rel(dw.permute(0, 3, 1, 2).cpu().numpy(), wd.grad.numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("rows,C,with_res", [(1000, 256, True), (77, 256, False), (5000, 1024, True), (3, 8, False)])
+def test_layernorm_backward_vs_autograd(rows, C, with_res):
+    from s2d_amd import backward
+    g = torch.Generator().manual_seed(rows + C)
+    x, r, dy = (torch.randn((rows, C), generator=g) for _ in range(3))
+    gam, bet = torch.randn((C,), generator=g), torch.randn((C,), generator=g)
+    xd, rd, gd, bd = (t.double().requires_grad_(True) for t in (x, r, gam, bet))
+    inp = xd + rd if with_res else xd
+    (torch.nn.functional.layer_norm(inp, (C,), gd, bd, 1e-5) * dy.double()).sum().backward()
+    dx, dg, db = backward.layernorm_backward(x.to(DEV), dy.to(DEV), gam.to(DEV), r.to(DEV) if with_res else None)
+    assert rel(dx.cpu().numpy(), xd.grad.numpy()) < 5e-6
+    assert rel(dg.cpu().numpy(), gd.grad.numpy()) < 5e-6
+    assert rel(db.cpu().numpy(), bd.grad.numpy()) < 5e-6
+    dx2, dg2, _ = backward.layernorm_backward(x.to(DEV), dy.to(DEV), gam.to(DEV), r.to(DEV) if with_res else None)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2)
+
+
+def test_relu_scale_backward():
+    from s2d_amd import backward
+    g = torch.Generator().manual_seed(1)
+    dy, y = torch.randn((6, 5, 7, 64), generator=g), torch.randn((6, 5, 7, 64), generator=g)
+    sc = torch.rand((64,), generator=g) + 0.5
+    out = backward.relu_scale_backward(dy.to(DEV), y.to(DEV), sc.to(DEV)).cpu()
+    assert torch.equal(out, dy * (y > 0) * sc)
+    assert torch.equal(backward.relu_scale_backward(dy.to(DEV)).cpu(), dy)
