@@ -275,6 +275,19 @@ long s2d_layernorm_backward_blocks(long rows);
 int s2d_layernorm_backward_f32(const float *x, const float *res, const float *dy, const float *gamma, long rows, int C,
                                float eps, float *dx, float *part, hipStream_t stream);
 
+/* GroupNorm backward for y = GN_G(x) * gamma + beta, x / dy NHWC: dx, and per-block partials part_c
+ * [s2d_groupnorm_backward_blocks(N,H,W)][2][C] (dgamma rows, dbeta rows), finished by s2d_reduce_slices_f32.  ws:
+ * 2 * s2d_groupnorm_workspace_doubles(N,H,W,G) doubles.  The ReLU / upsample-add branches of the forward are separate
+ * gradient steps (s2d_relu_scale_backward_f32, s2d_resize_bilinear_backward_nhwc_f32). */
+long s2d_groupnorm_backward_blocks(int N, int H, int W);
+int s2d_groupnorm_backward_f32(const float *x, const float *dy, const float *gamma, int N, int H, int W, int C, int G, float eps,
+                               double *ws, float *dx, float *part_c, hipStream_t stream);
+
+/* adjoint of bilinear_resize(up [N,hu,wu,C] -> (H,W), align_corners=False): dup [N,hu,wu,C] from dy [N,H,W,C] (gather
+ * form, reproducible); the gradient of the upsample-add branch of s2d_groupnorm_nhwc_f32 (msdeformattn.py:349). */
+int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, int C, int hu, int wu, float *dup,
+                                          hipStream_t stream);
+
 /* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
  * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU).  n elements, C innermost. */
 int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz,

@@ -167,3 +167,34 @@ def relu_scale_backward(dy, y=None, scale=None):
     dz = torch.empty_like(dy)
     lib().call("s2d_relu_scale_backward_f32", dy, y, scale, dy.numel(), C, dz, _st())
     return dz
+
+
+def groupnorm_backward(x, dy, G, gamma, eps=1e-5):
+    """y = GroupNorm_G(x) * gamma + beta, NHWC -> (dx, dgamma, dbeta)"""
+    for t in (x, dy, gamma):
+        ops._chk(t)
+    N, H, W, C = x.shape
+    ws = torch.empty((2 * lib().call("s2d_groupnorm_workspace_doubles", N, H, W, G),), device=x.device, dtype=torch.float64)
+    nb = lib().call("s2d_groupnorm_backward_blocks", N, H, W)
+    part = torch.empty((nb, 2, C), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    lib().call("s2d_groupnorm_backward_f32", x, dy, gamma, N, H, W, C, G, float(eps), ws, dx, part, _st())
+    gb = torch.empty((2, C), device=x.device, dtype=torch.float32)
+    lib().call("s2d_reduce_slices_f32", part, nb, 2 * C, 2 * C, 0.0, gb, _st())
+    return dx, gb[0], gb[1]
+
+
+def resize_bilinear_backward(dy, hu, wu):
+    """adjoint of the bilinear (align_corners=False) resize [N,hu,wu,C] -> dy's [N,H,W,C]"""
+    ops._chk(dy)
+    N, H, W, C = dy.shape
+    dup = torch.empty((N, hu, wu, C), device=dy.device, dtype=torch.float32)
+    lib().call("s2d_resize_bilinear_backward_nhwc_f32", dy, N, H, W, C, hu, wu, dup, _st())
+    return dup
+
+
+def groupnorm_up_relu_backward(x, y, dy, G, gamma, up_hw=None, relu=False, eps=1e-5):
+    """gradients of ops.groupnorm_nhwc(x, G, gamma, beta, up, relu): -> (dx, dgamma, dbeta, dup or None)"""
+    g = relu_scale_backward(dy, y) if relu else dy
+    dup = resize_bilinear_backward(g, *up_hw) if up_hw is not None else None
+    return groupnorm_backward(x, g, G, gamma, eps) + (dup,)

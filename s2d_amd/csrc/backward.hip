@@ -174,9 +174,59 @@ __global__ __launch_bounds__(256) void relu_scale_backward_kernel(const float *_
     reinterpret_cast<f32x4 *>(dz)[i] = g;
 }
 
+// Adjoint of F.interpolate(up [N,hu,wu,C] -> (H,W), bilinear, align_corners=False) (the top-down add of the pixel decoder,
+// msdeformattn.py:349), as a gather so that it is reproducible: low-resolution pixel (yl, xl) collects w_y * w_x * dy from
+// every high-resolution pixel whose source taps include it (the forward's own source rule decides the weights).
+__device__ __forceinline__ float tap_weight(float scale, int dst, int in_size, int want)
+{
+    float s = scale * (dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    const int i0 = (int)s, i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    const float l1 = s - i0, l0 = 1.f - l1;
+    return (i0 == want ? l0 : 0.f) + (i1 == want ? l1 : 0.f);
+}
+__global__ __launch_bounds__(256) void resize_backward_kernel(const float *__restrict__ dy, int N, int H, int W, int C, int hu, int wu,
+                                                              float *__restrict__ dup)
+{
+    const int q = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * hu * wu * q) return;
+    const int c4 = (int)(i % q);
+    const long pix = i / q;
+    const int xl = (int)(pix % wu), yl = (int)((pix / wu) % hu), n = (int)(pix / ((long)wu * hu));
+    const float sy = (float)hu / H, sx = (float)wu / W, ry = (float)H / hu, rx = (float)W / wu;
+    // high-resolution rows / columns whose source coordinate can fall in (yl - 1, yl + 1)
+    int Y0 = (int)floorf((yl - 0.5f) * ry - 0.5f) - 1, Y1 = (int)ceilf((yl + 1.5f) * ry - 0.5f) + 1;
+    int X0 = (int)floorf((xl - 0.5f) * rx - 0.5f) - 1, X1 = (int)ceilf((xl + 1.5f) * rx - 0.5f) + 1;
+    Y0 = max(Y0, 0); X0 = max(X0, 0); Y1 = min(Y1, H - 1); X1 = min(X1, W - 1);
+    if (yl == hu - 1) Y1 = H - 1;                       // clamped taps at the bottom / right edge all land here
+    if (xl == wu - 1) X1 = W - 1;
+    f32x4 acc = f32x4(0.f);
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        const float wy = tap_weight(sy, Y, hu, yl);
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            const float wx = tap_weight(sx, X, wu, xl);
+            if (wx == 0.f) continue;
+            acc += *reinterpret_cast<const f32x4 *>(dy + (((long)n * H + Y) * W + X) * C + c4 * 4) * (wy * wx);
+        }
+    }
+    *reinterpret_cast<f32x4 *>(dup + i * 4) = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, int C, int hu, int wu, float *dup, hipStream_t stream)
+{
+    if ((C & 3) || N < 0 || H < 1 || W < 1 || hu < 1 || wu < 1) return S2D_ERR_ARG;
+    const long total = (long)N * hu * wu * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(resize_backward_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, N, H, W, C, hu, wu, dup);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 long s2d_layernorm_backward_blocks(long rows) { return (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS); }
 

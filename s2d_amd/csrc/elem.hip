@@ -113,6 +113,89 @@ __global__ __launch_bounds__(64) void gn_reduce_kernel(const double *__restrict_
     }
 }
 
+// ---- GroupNorm backward.  y = xhat * gamma + beta, xhat = (x - mean_g) * rstd_g per (sample, group):
+//   g = dy * gamma,  dx = rstd * (g - mean_g(g) - xhat * mean_g(g * xhat)),  dgamma = sum dy * xhat,  dbeta = sum dy.
+// gnb_sums_kernel has the thread layout of gn_stats_kernel and leaves, per (sample, row block), the group sums of g and
+// g * xhat (double) and the per-channel sums of dy * xhat and dy (float, row slots added in a fixed order); both are finished
+// by fixed-order reductions, so the gradients are bitwise reproducible.
+__device__ __forceinline__ void gn_mean_rstd(const double *__restrict__ stats, int n, int g, int G, double cnt, float eps, float &mean, float &rstd)
+{
+    const double mu = stats[((long)n * G + g) * 2] / cnt;
+    const double var = stats[((long)n * G + g) * 2 + 1] / cnt - mu * mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean = (float)mu;
+}
+
+__global__ __launch_bounds__(256) void gnb_sums_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
+                                                       const double *__restrict__ stats, int HW, int C, int G, float eps, int rows_per_blk,
+                                                       double *__restrict__ part_g, float *__restrict__ part_c)
+{
+    __shared__ double sh[2][256];
+    __shared__ float shc[2][256][4];
+    const int n = blockIdx.y;
+    const int q = C / 4, tpr = 256 / q;
+    const int c4 = threadIdx.x % q, rslot = threadIdx.x / q;
+    const long r0 = (long)blockIdx.x * rows_per_blk;
+    const long r1 = min((long)HW, r0 + rows_per_blk);
+    double s1 = 0., s2 = 0.;
+    f32x4 dgam = f32x4(0.f), dbet = f32x4(0.f);
+    if (rslot < tpr) {
+        float mean, rstd;
+        gn_mean_rstd(stats, n, (c4 * 4) / (C / G), G, (double)HW * (C / G), eps, mean, rstd);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
+        const long base = ((long)n * HW) * C + c4 * 4;
+        for (long r = r0 + rslot; r < r1; r += tpr) {
+            const f32x4 xh = (*reinterpret_cast<const f32x4 *>(x + base + r * C) - mean) * rstd;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dy + base + r * C);
+            const f32x4 g = d * ga;
+            s1 += (double)g[0] + (double)g[1] + (double)g[2] + (double)g[3];
+            s2 += (double)g[0] * xh[0] + (double)g[1] * xh[1] + (double)g[2] * xh[2] + (double)g[3] * xh[3];
+            dgam += d * xh;
+            dbet += d;
+        }
+        sh[0][threadIdx.x] = s1;
+        sh[1][threadIdx.x] = s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { shc[0][threadIdx.x][j] = dgam[j]; shc[1][threadIdx.x][j] = dbet[j]; }
+    }
+    __syncthreads();
+    const int cpg4 = (C / G) / 4;
+    if (threadIdx.x < G) {
+        double a = 0., b = 0.;
+        for (int k = 0; k < cpg4; ++k)
+            for (int rs = 0; rs < tpr; ++rs) { a += sh[0][rs * q + threadIdx.x * cpg4 + k]; b += sh[1][rs * q + threadIdx.x * cpg4 + k]; }
+        double *o = part_g + (((long)n * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
+        o[0] = a; o[1] = b;
+    }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int w = i / C, c = i - w * C;
+        float a = 0.f;
+        for (int rs = 0; rs < tpr; ++rs) a += shc[w][rs * q + (c >> 2)][c & 3];
+        part_c[(((long)n * gridDim.x + blockIdx.x) * 2 + w) * C + c] = a;
+    }
+}
+
+template <typename I>
+__global__ void gnb_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
+                                 const double *__restrict__ stats, const double *__restrict__ stats2, int N, int HW, int C, int G, float eps,
+                                 float *__restrict__ dx)
+{
+    const int q = C / 4;
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const I total = (I)N * HW * q;
+    if (i >= total) return;
+    const int c4 = (int)(i % (I)q);
+    const int n = (int)((i / (I)q) / (I)HW);
+    const int g = (c4 * 4) / (C / G);
+    const double cnt = (double)HW * (C / G);
+    float mean, rstd;
+    gn_mean_rstd(stats, n, g, G, cnt, eps, mean, rstd);
+    const float m1 = (float)(stats2[((long)n * G + g) * 2] / cnt), m2 = (float)(stats2[((long)n * G + g) * 2 + 1] / cnt);
+    const f32x4 xh = (*reinterpret_cast<const f32x4 *>(x + (long)i * 4) - mean) * rstd;
+    const f32x4 gg = *reinterpret_cast<const f32x4 *>(dy + (long)i * 4) * *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
+    *reinterpret_cast<f32x4 *>(dx + (long)i * 4) = (gg - m1 - xh * m2) * rstd;
+}
+
 // y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
 template <typename I>
 __global__ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
@@ -334,6 +417,39 @@ int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, co
     else
         hipLaunchKernelGGL(gn_apply_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W, C, G,
                            eps, up, hu, wu, relu, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+/* part_c rows (float [rows][2][C]) and workspace doubles of s2d_groupnorm_backward_f32 */
+long s2d_groupnorm_backward_blocks(int N, int H, int W)
+{
+    const long HW = (long)H * W;
+    if (N <= 0 || HW <= 0) return 0;
+    return (long)N * cdiv(HW, (long)gn_rows_per_blk(HW));
+}
+
+int s2d_groupnorm_backward_f32(const float *x, const float *dy, const float *gamma, int N, int H, int W, int C, int G, float eps,
+                               double *ws, float *dx, float *part_c, hipStream_t stream)
+{
+    if ((C & 3) || C / 4 > 256 || 256 % (C / 4) || C % G || (C / G) & 3 || G > 256) return S2D_ERR_ARG;
+    const long HW = (long)H * W;
+    if (N == 0 || HW == 0) return S2D_OK;
+    const int rows_per_blk = gn_rows_per_blk(HW);
+    const int nblk = (int)cdiv(HW, (long)rows_per_blk);
+    const long half = 2L * N * G * (1 + nblk);                       // = s2d_groupnorm_workspace_doubles
+    double *stats = ws, *part = ws + 2L * N * G, *stats2 = ws + half, *part2 = ws + half + 2L * N * G;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, (int)HW, C, G, rows_per_blk, part);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(N * G), dim3(64), 0, stream, part, nblk, G, stats);
+    hipLaunchKernelGGL(gnb_sums_kernel, dim3(nblk, N), dim3(256), 0, stream, x, dy, gamma, stats, (int)HW, C, G, eps, rows_per_blk, part2, part_c);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(N * G), dim3(64), 0, stream, part2, nblk, G, stats2);
+    const long total = (long)N * HW * (C / 4);
+    if (total < (1L << 31))
+        hipLaunchKernelGGL(gnb_apply_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, dy, gamma, stats, stats2, N, (int)HW, C,
+                           G, eps, dx);
+    else
+        hipLaunchKernelGGL(gnb_apply_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, dy, gamma, stats, stats2, N, (int)HW, C, G, eps,
+                           dx);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

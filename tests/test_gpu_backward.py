@@ -97,3 +97,33 @@ def test_relu_scale_backward():
     out = backward.relu_scale_backward(dy.to(DEV), y.to(DEV), sc.to(DEV)).cpu()
     assert torch.equal(out, dy * (y > 0) * sc)
     assert torch.equal(backward.relu_scale_backward(dy.to(DEV)).cpu(), dy)
+
+
+@pytest.mark.parametrize("N,H,W,C,up,relu", [(2, 23, 40, 256, None, False), (3, 46, 80, 256, (23, 40), True), (1, 17, 9, 128, (5, 4), False),
+                                            (2, 184, 320, 256, (92, 160), True)])
+def test_groupnorm_upsample_relu_backward_vs_autograd(N, H, W, C, up, relu):
+    """the pixel decoder's conv -> GN(32) [+ bilinear upsample-add] [-> ReLU] (msdeformattn.py:213-226, 343-351)"""
+    from s2d_amd import backward, ops
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.randn((N, C, H, W), generator=g)
+    gam, bet = torch.randn((C,), generator=g), torch.randn((C,), generator=g)
+    u = torch.randn((N, C) + up, generator=g) if up else None
+    dy = torch.randn((N, C, H, W), generator=g)
+    xd, gd, bd = (t.double().requires_grad_(True) for t in (x, gam, bet))
+    ud = u.double().requires_grad_(True) if up else None
+    y = torch.nn.functional.group_norm(xd, 32, gd, bd, 1e-5)
+    if up:
+        y = y + torch.nn.functional.interpolate(ud, size=(H, W), mode="bilinear", align_corners=False)
+    if relu:
+        y = torch.relu(y)
+    (y * dy.double()).sum().backward()
+    h = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    x_h, dy_h = h(x), h(dy)
+    y_h = ops.groupnorm_nhwc(x_h, 32, gam.to(DEV), bet.to(DEV), up=h(u) if up else None, relu=relu)
+    dx, dg, db, dup = backward.groupnorm_up_relu_backward(x_h, y_h, dy_h, 32, gam.to(DEV), up, relu)
+    back = lambda t: t.permute(0, 3, 1, 2).cpu().numpy()
+    assert rel(back(dx), xd.grad.numpy()) < 1e-5
+    assert rel(dg.cpu().numpy(), gd.grad.numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), bd.grad.numpy()) < 1e-5
+    if up:
+        assert rel(back(dup), ud.grad.numpy()) < 2e-6
