@@ -288,6 +288,11 @@ int s2d_groupnorm_backward_f32(const float *x, const float *dy, const float *gam
 int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, int C, int hu, int wu, float *dup,
                                           hipStream_t stream);
 
+/* backward of s2d_maxpool3x3s2_nhwc_f32: dx [N,H,W,C] from x and dy [N,(H+1)/2,(W+1)/2,C]; ties go to the first maximum
+ * in window scan order (torch's rule).  Gather form: reproducible. */
+int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, int H, int W, int C, float *dx,
+                                       hipStream_t stream);
+
 /* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
  * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU).  n elements, C innermost. */
 int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz,

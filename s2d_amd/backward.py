@@ -198,3 +198,12 @@ def groupnorm_up_relu_backward(x, y, dy, G, gamma, up_hw=None, relu=False, eps=1
     g = relu_scale_backward(dy, y) if relu else dy
     dup = resize_bilinear_backward(g, *up_hw) if up_hw is not None else None
     return groupnorm_backward(x, g, G, gamma, eps) + (dup,)
+
+
+def maxpool_backward(x, dy):
+    """gradient of ops.maxpool3x3s2_nhwc"""
+    ops._chk(x); ops._chk(dy)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib().call("s2d_maxpool3x3s2_backward_nhwc_f32", x, dy, N, H, W, C, dx, _st())
+    return dx

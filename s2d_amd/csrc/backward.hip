@@ -214,9 +214,62 @@ __global__ __launch_bounds__(256) void resize_backward_kernel(const float *__res
     *reinterpret_cast<f32x4 *>(dup + i * 4) = acc;
 }
 
+// 3x3 / stride 2 / pad 1 max-pool backward (detectron2 BasicStem), NHWC, as a gather: an input pixel belongs to at most
+// 2 x 2 windows; for each, the window's arg-max is recomputed with the forward's rule (scan in (ky, kx) order, the first
+// maximum wins, which is also where torch's max_pool2d backward routes the gradient) and dy is taken if it is this pixel.
+__global__ __launch_bounds__(256) void maxpool_backward_kernel(const float *__restrict__ x, const float *__restrict__ dy, int N, int H, int W,
+                                                               int C, int Ho, int Wo, float *__restrict__ dx)
+{
+    const int q = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W * q) return;
+    const int c4 = (int)(i % q);
+    const long pix = i / q;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const float *xb = x + (long)n * H * W * C + c4 * 4;
+    f32x4 acc = f32x4(0.f);
+    for (int oy = (py + 0) / 2; oy <= (py + 1) / 2; ++oy) {           // windows with 2*oy - 1 <= py <= 2*oy + 1
+        if (oy >= Ho) continue;
+        for (int ox = (px + 0) / 2; ox <= (px + 1) / 2; ++ox) {
+            if (ox >= Wo) continue;
+            f32x4 best = f32x4(-INFINITY);
+            int by[4] = {-1, -1, -1, -1}, bx[4] = {-1, -1, -1, -1};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy - 1 + ky;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = 2 * ox - 1 + kx;
+                    if (ix < 0 || ix >= W) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + ((long)iy * W + ix) * C);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (v[j] > best[j] || by[j] < 0) { best[j] = v[j]; by[j] = iy; bx[j] = ix; }
+                }
+            }
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + oy) * Wo + ox) * C + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (by[j] == py && bx[j] == px) acc[j] += g[j];
+        }
+    }
+    *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, int H, int W, int C, float *dx, hipStream_t stream)
+{
+    if ((C & 3) || N < 0 || H < 1 || W < 1) return S2D_ERR_ARG;
+    const long total = (long)N * H * W * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(maxpool_backward_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, dy, N, H, W, C, (H + 1) / 2, (W + 1) / 2, dx);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, int C, int hu, int wu, float *dup, hipStream_t stream)
 {

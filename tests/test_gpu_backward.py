@@ -127,3 +127,21 @@ def test_groupnorm_upsample_relu_backward_vs_autograd(N, H, W, C, up, relu):
     assert rel(db.cpu().numpy(), bd.grad.numpy()) < 1e-5
     if up:
         assert rel(back(dup), ud.grad.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 20, 64), (1, 17, 23, 64), (2, 5, 4, 8)])
+def test_maxpool_backward_vs_autograd(N, H, W, C):
+    """BasicStem's 3x3/2 pad-1 max pool on ReLU outputs (many exact ties at 0: the first maximum takes the gradient)"""
+    from s2d_amd import backward
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.relu(torch.randn((N, C, H, W), generator=g))
+    xd = x.double().requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(xd, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy.double()).sum().backward()
+    h = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = backward.maxpool_backward(h(x), h(dy))
+    # routing is exact; a pixel that is the arg-max of several windows adds 2..4 gradients (fp32 here, float64 in the check)
+    got, want = dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()
+    np.testing.assert_array_equal(got != 0, want != 0)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
