@@ -64,14 +64,47 @@ class ConvBN(nn.Module):
             return y.view(N, H, W, -1)
         return ops.conv2d_nhwc(x, w, self.stride, self.pad, scale, shift, res, relu)
 
+    def backward(self, x, y, dy, relu=True, has_res=False, need_dx=True, dx_res=None):
+        """gradients of y = act(conv(x) * scale + shift [+ res]): accumulates into self.weight.grad and returns
+        (dx [+ dx_res: a gradient arriving at x over another path, added in the dgrad epilogue for 1x1 kernels], dres)."""
+        from .. import backward as B
+        w, scale, _ = self.packed()
+        dres = B.relu_scale_backward(dy, y) if (has_res and relu) else (dy if has_res else None)
+        dz = B.relu_scale_backward(dy, y if relu else None, scale)              # d(conv output)
+        dw = B.conv_weight_grad(dz, x, self.k, self.k, self.stride, self.pad)  # [O,kh,kw,C(4)]
+        dw = dw[..., :self.weight.shape[1]].permute(0, 3, 1, 2)
+        if self.weight.grad is None:
+            self.weight.grad = dw.contiguous()
+        else:
+            self.weight.grad += dw
+        dx = None
+        if need_dx:
+            if self.k == 1 and self.stride == 1:
+                N, H, W, C = x.shape
+                dx = B.input_grad(dz.view(-1, dz.shape[-1]), w.view(w.shape[0], -1), None if dx_res is None else dx_res.view(-1, C)).view(N, H, W, C)
+            else:
+                dx = B.conv_input_grad(dz, w, self.stride, self.pad, x.shape[1:3])
+                if dx_res is not None:
+                    dx = dx + dx_res
+        return dx, dres
+
 
 class BasicStem(nn.Module):
     def __init__(self):
         super().__init__()
         self.conv1 = ConvBN(3, 64, 7, 2, 3)
 
-    def forward(self, x):
-        return ops.maxpool3x3s2(self.conv1(x))
+    def forward(self, x, tape=None):
+        c = self.conv1(x)
+        y = ops.maxpool3x3s2(c)
+        if tape is not None:
+            tape.append((self, x, c))
+        return y
+
+    def backward(self, saved, dy):
+        from .. import backward as B
+        _, x, c = saved
+        self.conv1.backward(x, c, B.maxpool_backward(c, dy), relu=True, need_dx=False)   # the image needs no gradient
 
 
 class BottleneckBlock(nn.Module):
@@ -82,10 +115,24 @@ class BottleneckBlock(nn.Module):
         self.conv2 = ConvBN(mid, mid, 3, stride, 1)     # STRIDE_IN_1X1 False: stride on the 3x3
         self.conv3 = ConvBN(mid, cout, 1, 1, 0)
 
-    def forward(self, x):
+    def forward(self, x, tape=None):
         sc = x if self.shortcut is None else self.shortcut(x, relu=False)
-        y = self.conv2(self.conv1(x))
-        return self.conv3(y, res=sc, relu=True)
+        y1 = self.conv1(x)
+        y2 = self.conv2(y1)
+        out = self.conv3(y2, res=sc, relu=True)
+        if tape is not None:
+            tape.append((self, x, sc, y1, y2, out))
+        return out
+
+    def backward(self, saved, dout):
+        """d(block input) from d(block output); parameter gradients accumulate in the ConvBN weights"""
+        _, x, sc, y1, y2, out = saved
+        d2, dsc = self.conv3.backward(y2, out, dout, relu=True, has_res=True)
+        d1, _ = self.conv2.backward(y1, y2, d2)
+        if self.shortcut is not None:
+            dsc, _ = self.shortcut.backward(x, sc, dsc, relu=False)
+        dx, _ = self.conv1.backward(x, y1, d1, dx_res=dsc)             # both paths meet at x
+        return dx
 
 
 class ResNet50(nn.Module):
@@ -107,13 +154,30 @@ class ResNet50(nn.Module):
     def output_shape(self):
         return {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
 
-    def forward(self, x):
-        y = self.stem(x)
+    def forward(self, x, tape=None):
+        """tape: a list that receives what backward() needs (the activations the reference's autograd would keep)"""
+        y = self.stem(x, tape)
         out = {}
         for name, *_ in R50_STAGES:
-            y = getattr(self, name)(y)
+            for blk in getattr(self, name):
+                y = blk(y, tape)
             out[name] = y
         return out
+
+    def backward(self, tape, grads):
+        """grads: {"res2".."res5": d(loss)/d(output)} (missing = zero).  Walks the tape backwards, accumulating the weight
+        gradients of all 53 convolutions (FREEZE_AT 0: the whole trunk trains, Base-YouTubeVIS...yaml:3)."""
+        last = {getattr(self, name)[-1]: name for name, *_ in R50_STAGES}
+        d = None
+        for saved in reversed(tape):
+            mod = saved[0]
+            if isinstance(mod, BasicStem):
+                mod.backward(saved, d)
+                continue
+            g = grads.get(last.get(mod))
+            if g is not None:
+                d = g if d is None else d + g
+            d = mod.backward(saved, d)
 
 
 def build_resnet_backbone(cfg=None, input_shape=None):

@@ -145,3 +145,54 @@ def test_maxpool_backward_vs_autograd(N, H, W, C):
     got, want = dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()
     np.testing.assert_array_equal(got != 0, want != 0)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+
+
+def test_resnet50_backward_vs_autograd():
+    """the whole trunk: 53 conv weight gradients from d(loss)/d(res2..res5), vs torch autograd (float64, CPU) on the same
+    architecture (7x7/2 stem + max pool, bottlenecks with the stride on the 3x3, FrozenBN as a per-channel affine)"""
+    import torch.nn.functional as F
+    from s2d_amd.modeling import ResNet50
+    from s2d_amd import ops
+    torch.manual_seed(0)
+    net = ResNet50()
+    for m in net.modules():                                           # non-trivial frozen statistics
+        if hasattr(m, "running_var"):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    N, H, W = 1, 64, 96
+    img = torch.randn((N, 3, H, W))
+
+    def conv_bn(m, x, relu=True, res=None):
+        s = (m.norm.weight * (m.norm.running_var + m.norm.eps).rsqrt()).double()
+        b = (m.norm.bias - m.norm.running_mean * s.float()).double()
+        y = F.conv2d(x, m.wd, stride=m.stride, padding=m.pad) * s[None, :, None, None] + b[None, :, None, None]
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+
+    convs = [m for m in net.modules() if hasattr(m, "norm")]
+    for m in convs:
+        m.wd = m.weight.detach().double().requires_grad_(True)
+    y = F.max_pool2d(conv_bn(net.stem.conv1, img.double()), 3, 2, 1)
+    outs = {}
+    for name in ("res2", "res3", "res4", "res5"):
+        for blk in getattr(net, name):
+            sc = y if blk.shortcut is None else conv_bn(blk.shortcut, y, relu=False)
+            y = conv_bn(blk.conv3, conv_bn(blk.conv2, conv_bn(blk.conv1, y)), res=sc)
+        outs[name] = y
+    g = torch.Generator().manual_seed(1)
+    douts = {k: torch.randn(v.shape, generator=g) for k, v in outs.items()}
+    sum((outs[k] * douts[k].double()).sum() for k in outs).backward()
+
+    net = net.to(DEV)
+    x4 = torch.zeros((N, H, W, 4), device=DEV)
+    x4[..., :3] = img.permute(0, 2, 3, 1).to(DEV)
+    tape = []
+    with torch.no_grad():
+        out_h = net(x4, tape)
+        for k in outs:
+            assert rel(out_h[k].permute(0, 3, 1, 2).cpu().numpy(), outs[k].detach().numpy()) < 2e-5
+        net.backward(tape, {k: v.permute(0, 2, 3, 1).contiguous().to(DEV) for k, v in douts.items()})
+    worst = 0.0
+    for m in convs:
+        worst = max(worst, rel(m.weight.grad.cpu().numpy(), m.wd.grad.numpy()))
+    assert worst < 1e-4, worst
