@@ -91,6 +91,14 @@ int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const 
 int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
                                int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream);
 
+/* Backward of the fused form = prep (raw offsets / logits -> loc [N,S,M,L,P,2], softmaxed attn [N,S,M,L,P] with the
+ * forward's reference points), s2d_msda_backward_f32 on those, chain (d_loc, d_attn -> d_offs_logits [N,S,ldd], the
+ * gradient of the merged projection output: d_off = d_loc / (W_l, H_l), d_logit = a (d_a - sum a d_a)). */
+int s2d_msda_fused_prep_f32(const float *offs_logits, int ldoa, const int64_t *shapes_host, int N, int S, int M, int L, int P,
+                            float *loc, float *attn, hipStream_t stream);
+int s2d_msda_fused_chain_f32(const float *attn, const float *grad_loc, const float *grad_attn, const int64_t *shapes_host, int N,
+                             int S, int M, int L, int P, float *d_offs_logits, int ldd, hipStream_t stream);
+
 /* ---- bandwidth-bound glue (HBM-bound, 16-B accesses) ----------------------------------------------- */
 
 /* (x - mean)/std per frame + zero pad bottom/right to (Hp,Wp): kd_video_maskformer_model.py:263-269 and

@@ -207,3 +207,23 @@ def maxpool_backward(x, dy):
     dx = torch.empty_like(x)
     lib().call("s2d_maxpool3x3s2_backward_nhwc_f32", x, dy, N, H, W, C, dx, _st())
     return dx
+
+
+# --------------------------------------------------------------------------- multi-scale deformable attention (fused form)
+def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4):
+    """gradients of ops.msda_fused_forward(value [N,S,C], shapes, offs_logits [N,S,>=288]) -> (d_value [N,S,C],
+    d_offs_logits [N,S,M*L*P*3]).  value / offs_logits may be the column slices of the merged projection output."""
+    N, S, C = value.shape
+    sh = ops._host_i64(shapes)
+    L = sh.shape[0]
+    D = C // M
+    dev = value.device
+    loc = torch.empty((N, S, M, L, P, 2), device=dev, dtype=torch.float32)
+    attn = torch.empty((N, S, M, L, P), device=dev, dtype=torch.float32)
+    lib().call("s2d_msda_fused_prep_f32", offs_logits, offs_logits.stride(1), sh, N, S, M, L, P, loc, attn, _st())
+    lsi = ops._host_i64(torch.cat([torch.zeros(1, dtype=torch.int64), torch.as_tensor(sh).prod(1).cumsum(0)[:-1]]))
+    gv, gl, ga = ops.msda_backward(value.contiguous().view(N, S, M, D), sh, lsi, loc, attn, grad_out.contiguous())
+    ldd = M * L * P * 3
+    doa = torch.empty((N, S, ldd), device=dev, dtype=torch.float32)
+    lib().call("s2d_msda_fused_chain_f32", attn, gl, ga, sh, N, S, M, L, P, doa, ldd, _st())
+    return gv.view(N, S, C), doa

@@ -244,9 +244,87 @@ int fill_levels(Levels &lv, const int64_t *shapes, const int64_t *lsi, int L, lo
     return S2D_OK;
 }
 
+// ---- backward of the fused form: the drop-in backward kernel works on explicit sampling locations
+// and softmaxed weights, so the fused projection output is first expanded (prep) and the gradients it returns are chained
+// back to the raw offsets / logits (chain): d_off = d_loc / (W_l, H_l); d_logit = a * (d_a - sum_j a_j d_a_j).
+__global__ __launch_bounds__(256) void msda_fused_prep_kernel(const float *__restrict__ oa, int ldoa, Levels lv, int S, int M, int L, int P,
+                                                              float *__restrict__ loc, float *__restrict__ attn)
+{
+    const int n = blockIdx.y;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long)S * M) return;
+    const int m = (int)(item % M), q = (int)(item / M);
+    int lq = 0;
+    while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
+    const int qi = q - (int)lv.start[lq];
+    const int qy = qi / lv.W[lq], qx = qi - qy * lv.W[lq];
+    const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq], ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
+    const int LP = L * P;
+    const float *row = oa + ((long)n * S + q) * ldoa;
+    const float *offp = row + m * (LP * 2), *lgp = row + M * LP * 2 + m * LP;
+    float *lo = loc + (((long)n * S + q) * M + m) * LP * 2, *ao = attn + (((long)n * S + q) * M + m) * LP;
+    float mx = -INFINITY;
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
+    float den = 0.f;
+    for (int i = 0; i < LP; ++i) den += expf(lgp[i] - mx);
+    const float inv = 1.f / den;
+    for (int i = 0; i < LP; ++i) {
+        const int l = i / P;
+        ao[i] = expf(lgp[i] - mx) * inv;
+        lo[2 * i] = ref_x + offp[2 * i] / (float)lv.W[l];
+        lo[2 * i + 1] = ref_y + offp[2 * i + 1] / (float)lv.H[l];
+    }
+}
+
+__global__ __launch_bounds__(256) void msda_fused_chain_kernel(const float *__restrict__ attn, const float *__restrict__ gloc,
+                                                               const float *__restrict__ gattn, Levels lv, int S, int M, int L, int P,
+                                                               float *__restrict__ doa, int ldd)
+{
+    const int n = blockIdx.y;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long)S * M) return;
+    const int m = (int)(item % M), q = (int)(item / M);
+    const int LP = L * P;
+    const long base = (((long)n * S + q) * M + m) * LP;
+    float *row = doa + ((long)n * S + q) * ldd;
+    float dot = 0.f;
+    for (int i = 0; i < LP; ++i) dot += attn[base + i] * gattn[base + i];
+    for (int i = 0; i < LP; ++i) {
+        const int l = i / P;
+        row[m * (LP * 2) + 2 * i] = gloc[(base + i) * 2] / (float)lv.W[l];
+        row[m * (LP * 2) + 2 * i + 1] = gloc[(base + i) * 2 + 1] / (float)lv.H[l];
+        row[M * LP * 2 + m * LP + i] = attn[base + i] * (gattn[base + i] - dot);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_msda_fused_prep_f32(const float *offs_logits, int ldoa, const int64_t *shapes_host, int N, int S, int M, int L, int P, float *loc,
+                            float *attn, hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
+    if (ldoa < M * L * P * 3) return S2D_ERR_ARG;
+    if (N <= 0) return S2D_OK;
+    hipLaunchKernelGGL(msda_fused_prep_kernel, dim3(cdiv((long)S * M, 256), N), dim3(256), 0, stream, offs_logits, ldoa, lv, S, M, L, P, loc, attn);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_msda_fused_chain_f32(const float *attn, const float *grad_loc, const float *grad_attn, const int64_t *shapes_host, int N, int S,
+                             int M, int L, int P, float *d_offs_logits, int ldd, hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
+    if (ldd < M * L * P * 3) return S2D_ERR_ARG;
+    if (N <= 0) return S2D_OK;
+    hipLaunchKernelGGL(msda_fused_chain_kernel, dim3(cdiv((long)S * M, 256), N), dim3(256), 0, stream, attn, grad_loc, grad_attn, lv, S, M, L, P,
+                       d_offs_logits, ldd);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
                          const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P,

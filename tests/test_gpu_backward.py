@@ -196,3 +196,47 @@ def test_resnet50_backward_vs_autograd():
     for m in convs:
         worst = max(worst, rel(m.weight.grad.cpu().numpy(), m.wd.grad.numpy()))
     assert worst < 1e-4, worst
+
+
+def _msda_fused_torch(value, shapes, oa, M=8, P=4):
+    """ms_deform_attn.py:101-113 + ms_deform_attn_func.py:52-72 (pure-torch core) with the pixel decoder's own reference
+    points (msdeformattn.py:141-153, valid ratios 1): the differentiable restatement autograd runs through"""
+    N, S, C = value.shape
+    L, D, LP = len(shapes), C // M, len(shapes) * P
+    offs = oa[..., :M * LP * 2].reshape(N, S, M, L, P, 2)
+    attn = torch.softmax(oa[..., M * LP * 2:M * LP * 3].reshape(N, S, M, LP), -1).reshape(N, S, M, L, P)
+    refs = []
+    for (H, W) in shapes:
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=value.dtype), torch.arange(W, dtype=value.dtype), indexing="ij")
+        refs.append(torch.stack([(xx.reshape(-1) + 0.5) / W, (yy.reshape(-1) + 0.5) / H], -1))
+    ref = torch.cat(refs, 0)                                                   # [S,2]
+    norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=value.dtype)      # (W_l, H_l)
+    loc = ref[None, :, None, None, None, :] + offs / norm[None, None, None, :, None, :]
+    out, start = 0, 0
+    v = value.reshape(N, S, M, D)
+    for l, (H, W) in enumerate(shapes):
+        vl = v[:, start:start + H * W].permute(0, 2, 3, 1).reshape(N * M, D, H, W)
+        grid = (2 * loc[:, :, :, l] - 1).permute(0, 2, 1, 3, 4).reshape(N * M, S, P, 2)
+        smp = torch.nn.functional.grid_sample(vl, grid, mode="bilinear", padding_mode="zeros", align_corners=False)   # [N*M,D,S,P]
+        out = out + (smp * attn[:, :, :, l].permute(0, 2, 1, 3).reshape(N * M, 1, S, P)).sum(-1)
+        start += H * W
+    return out.reshape(N, M, D, S).permute(0, 3, 1, 2).reshape(N, S, C)
+
+
+def test_msda_fused_backward_vs_autograd():
+    from s2d_amd import backward, ops
+    shapes = [(5, 7), (10, 14), (20, 28)]
+    S = sum(h * w for h, w in shapes)
+    N, C = 2, 256
+    g = torch.Generator().manual_seed(3)
+    value = torch.randn((N, S, C), generator=g)
+    oa = torch.cat([torch.randn((N, S, 192), generator=g) * 2.0, torch.randn((N, S, 96), generator=g)], -1)   # offsets reach outside
+    go = torch.randn((N, S, C), generator=g)
+    vd, od = value.double().requires_grad_(True), oa.double().requires_grad_(True)
+    out = _msda_fused_torch(vd, shapes, od)
+    (out * go.double()).sum().backward()
+    v_h, o_h = value.to(DEV), oa.to(DEV)
+    assert rel(ops.msda_fused_forward(v_h, shapes, o_h).cpu().numpy(), out.detach().numpy()) < 2e-6
+    dv, doa = backward.msda_fused_backward(v_h, shapes, o_h, go.to(DEV))
+    assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 1e-5
+    assert rel(doa.cpu().numpy(), od.grad.numpy()) < 1e-5
