@@ -15,6 +15,24 @@ def _st():
     return ops._stream()
 
 
+def acc(param, g):
+    """accumulate a gradient into param.grad (allocating it on first use), as autograd's AccumulateGrad does"""
+    g = g.reshape(param.shape)
+    if param.grad is None:
+        param.grad = g.contiguous().clone() if g.data_ptr() == param.data_ptr() else g.contiguous()
+    else:
+        param.grad += g
+
+
+def sum_slices(x):
+    """x [S, ...] -> sum over the leading dim in a fixed order"""
+    ops._chk(x)
+    n = x[0].numel()
+    out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+    lib().call("s2d_reduce_slices_f32", x, x.shape[0], n, n, 0.0, out, _st())
+    return out
+
+
 def transpose(x, pad_to=None):
     """x [R,C] -> [C, ld] with ld = pad_to or R (columns >= R zero-filled)"""
     ops._chk(x)

@@ -60,7 +60,7 @@ class MSDeformAttn(nn.Module):
             self._packed = (key, ops.mark_static(w_all), b_all, ops.mark_static(w_oa), b_oa)
         return self._packed[1:]
 
-    def forward_fused(self, src, pos, shapes, res):
+    def forward_fused(self, src, pos, shapes, res, tape=None):
         """self-attention over the flattened pyramid with query = src + pos (query positions == value positions;
         pos [S, C] is shared by all N frames).  Returns output_proj(msda(...)) + res.
         (src + pos) . W_oa^T = src . W_oa^T + pos . W_oa^T: the second term is one small [S, 288] product per layer and
@@ -72,7 +72,38 @@ class MSDeformAttn(nn.Module):
         both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa).view(N, S, n_oa + C)
         samp = ops.msda_fused_forward(both[..., n_oa:], shapes, both[..., :n_oa], self.n_heads, self.n_points)
         out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C))
+        if tape is not None:
+            tape.append((self, src, pos, shapes, both, samp))
         return out.view(N, S, C)
+
+    def backward_fused(self, saved, d_out):
+        """d(src) (the attention input, including the residual path res == src) and d(pos) [S,C] from d(output);
+        parameter gradients accumulate into .grad.  Mirrors forward_fused step by step."""
+        from .. import backward as B
+        _, src, pos, shapes, both, samp = saved
+        N, S, C = src.shape
+        w_all, _, w_oa, _ = self.packed()
+        n_oa = w_oa.shape[0]
+        n_off = self.sampling_offsets.weight.shape[0]
+        d2 = d_out.reshape(-1, C)
+        B.acc(self.output_proj.weight, B.weight_grad(d2, samp.view(-1, C)))
+        B.acc(self.output_proj.bias, B.bias_grad(d2))
+        d_samp = B.input_grad(d2, self.output_proj.weight).view(N, S, C)
+        d_val, d_oa = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points)
+        d_both = torch.cat([d_oa, d_val], -1).view(-1, n_oa + C)
+        dw = B.weight_grad(d_both, src.view(-1, C))                       # rows: offsets | logits | value
+        d_pos_oa = B.sum_slices(d_oa)                                     # the row-periodic term: same pos row for every frame
+        dw_pos = B.weight_grad(d_pos_oa.contiguous(), pos.view(S, C))
+        B.acc(self.sampling_offsets.weight, dw[:n_off] + dw_pos[:n_off])
+        B.acc(self.attention_weights.weight, dw[n_off:n_oa] + dw_pos[n_off:])
+        B.acc(self.value_proj.weight, dw[n_oa:])
+        db = B.bias_grad(d_both)
+        B.acc(self.sampling_offsets.bias, db[:n_off])
+        B.acc(self.attention_weights.bias, db[n_off:n_oa])
+        B.acc(self.value_proj.bias, db[n_oa:])
+        d_src = B.input_grad(d_both, w_all, res=d2).view(N, S, C)         # + the residual path (res == src)
+        d_pos = B.input_grad(d_pos_oa.contiguous(), w_oa)
+        return d_src, d_pos
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
@@ -105,17 +136,36 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout
 
-    def forward(self, src, pos, shapes):
+    def forward(self, src, pos, shapes, tape=None):
         """msdeformattn.py:122-131 (post-norm).  src [N,S,C], pos [S,C]."""
         if self.dropout_p:
             raise NotImplementedError("dropout > 0 (training noise) is not on the measured fwd+loss parity path; "
                                       "set MODEL.MASK_FORMER.DROPOUT 0.0 (SURVEY.md Appendix C)")
         N, S, C = src.shape
-        x = self.self_attn.forward_fused(src, pos, shapes, res=src)
-        src = ops.layernorm(x, self.norm1.weight, self.norm1.bias)
-        h = ops.gemm_nt(src.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
-        x = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=src.view(-1, C)).view(N, S, C)
-        return ops.layernorm(x, self.norm2.weight, self.norm2.bias)
+        sub = [] if tape is not None else None
+        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub)
+        s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
+        h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
+        x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C)).view(N, S, C)
+        if tape is not None:
+            tape.append((self, sub[0], x1, s1, h, x2))
+        return ops.layernorm(x2, self.norm2.weight, self.norm2.bias)
+
+    def backward(self, saved, d_out):
+        """-> (d_src, d_pos)"""
+        from .. import backward as B
+        _, attn_saved, x1, s1, h, x2 = saved
+        N, S, C = x1.shape
+        d_x2, dg, db = B.layernorm_backward(x2, d_out.contiguous(), self.norm2.weight)
+        B.acc(self.norm2.weight, dg); B.acc(self.norm2.bias, db)
+        d2 = d_x2.view(-1, C)
+        B.acc(self.linear2.weight, B.weight_grad(d2, h)); B.acc(self.linear2.bias, B.bias_grad(d2))
+        d_h = B.relu_scale_backward(B.input_grad(d2, self.linear2.weight), h)
+        B.acc(self.linear1.weight, B.weight_grad(d_h, s1.view(-1, C))); B.acc(self.linear1.bias, B.bias_grad(d_h))
+        d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
+        d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)
+        B.acc(self.norm1.weight, dg); B.acc(self.norm1.bias, db)
+        return self.self_attn.backward_fused(attn_saved, d_x1)
 
 
 class _Encoder(nn.Module):
@@ -198,22 +248,24 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return self._pos_cache["pos"]
 
     @torch.no_grad()
-    def forward_features(self, features):
+    def forward_features(self, features, tape=None):
         C = self.conv_dim
-        srcs, shapes = [], []
+        srcs, shapes, proj = [], [], []
         for idx, f in enumerate(("res5", "res4", "res3")):   # msdeformattn.py:319-322
             x = features[f]
             N, h, w, cin = x.shape
             conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
-            y = ops.gemm_nt(x.view(-1, cin), conv.weight.view(C, cin), bias=conv.bias).view(N, h, w, C)
-            y = ops.groupnorm_nhwc(y, 32, gn.weight, gn.bias, eps=gn.eps)
+            z = ops.gemm_nt(x.view(-1, cin), conv.weight.view(C, cin), bias=conv.bias).view(N, h, w, C)
+            y = ops.groupnorm_nhwc(z, 32, gn.weight, gn.bias, eps=gn.eps)
+            proj.append((x, z))
             srcs.append(y.view(N, h * w, C))
             shapes.append((h, w))
         src = torch.cat(srcs, 1).contiguous()
         pos = self._pos(shapes, src.device)
         shp = torch.tensor(shapes, dtype=torch.int64)
+        enc = [] if tape is not None else None
         for layer in self.transformer.encoder.layers:
-            src = layer(src, pos, shp)
+            src = layer(src, pos, shp, enc)
         N = src.shape[0]
         outs, o = [], 0
         for (h, w) in shapes:
@@ -224,9 +276,71 @@ class MSDeformAttnPixelDecoder(nn.Module):
         _, h2, w2, c2 = x.shape
         cur = ops.gemm_nt(x.view(-1, c2), self.adapter_1.weight.view(C, c2)).view(N, h2, w2, C)
         h3, w3 = shapes[-1]
-        y = ops.groupnorm_nhwc(cur, 32, self.adapter_1.norm.weight, self.adapter_1.norm.bias, up=outs[-1].view(N, h3, w3, C),
-                               eps=self.adapter_1.norm.eps)
-        y = ops.conv2d_nhwc(y, self.layer_1.packed(), 1, 1)
-        y = ops.groupnorm_nhwc(y, 32, self.layer_1.norm.weight, self.layer_1.norm.bias, relu=True, eps=self.layer_1.norm.eps)
-        mf = ops.gemm_nt(y.view(-1, C), self.mask_features.weight.view(-1, C), bias=self.mask_features.bias).view(N, h2, w2, -1)
+        y1 = ops.groupnorm_nhwc(cur, 32, self.adapter_1.norm.weight, self.adapter_1.norm.bias, up=outs[-1].view(N, h3, w3, C),
+                                eps=self.adapter_1.norm.eps)
+        y2 = ops.conv2d_nhwc(y1, self.layer_1.packed(), 1, 1)
+        y3 = ops.groupnorm_nhwc(y2, 32, self.layer_1.norm.weight, self.layer_1.norm.bias, relu=True, eps=self.layer_1.norm.eps)
+        mf = ops.gemm_nt(y3.view(-1, C), self.mask_features.weight.view(-1, C), bias=self.mask_features.bias).view(N, h2, w2, -1)
+        if tape is not None:
+            tape.append((self, proj, shapes, enc, x, cur, y1, y2, y3))
         return mf, [(outs[i], shapes[i]) for i in range(3)]
+
+    @torch.no_grad()
+    def backward_features(self, saved, d_mf, d_outs):
+        """gradients of forward_features: d_mf [N,h2,w2,mask_dim], d_outs: 3 x [N,h*w,C] (None = zero) ->
+        {"res2".."res5": d(feature)}; parameter gradients accumulate into .grad (msdeformattn.py:314-358 backwards)."""
+        from .. import backward as B
+        _, proj, shapes, enc, x2, cur, y1, y2, y3 = saved
+        C = self.conv_dim
+        N, h2, w2, c2 = x2.shape
+        h3, w3 = shapes[-1]
+        grads = {}
+        # mask_features 1x1 conv <- layer_1 (3x3 conv, GN, ReLU) <- adapter_1 (1x1 conv, GN) + upsampled level-2 tokens
+        d = d_mf.reshape(-1, d_mf.shape[-1])
+        B.acc(self.mask_features.weight, B.weight_grad(d, y3.view(-1, C)).view_as(self.mask_features.weight))
+        B.acc(self.mask_features.bias, B.bias_grad(d))
+        d_y3 = B.input_grad(d, self.mask_features.weight.view(-1, C)).view(N, h2, w2, C)
+        d_y2, dg, db, _ = B.groupnorm_up_relu_backward(y2, y3, d_y3, 32, self.layer_1.norm.weight, relu=True, eps=self.layer_1.norm.eps)
+        B.acc(self.layer_1.norm.weight, dg); B.acc(self.layer_1.norm.bias, db)
+        B.acc(self.layer_1.weight, B.conv_weight_grad(d_y2, y1, 3, 3, 1, 1).permute(0, 3, 1, 2))
+        d_y1 = B.conv_input_grad(d_y2, self.layer_1.packed(), 1, 1, (h2, w2))
+        d_cur, dg, db, d_up = B.groupnorm_up_relu_backward(cur, y1, d_y1, 32, self.adapter_1.norm.weight, up_hw=(h3, w3),
+                                                           eps=self.adapter_1.norm.eps)
+        B.acc(self.adapter_1.norm.weight, dg); B.acc(self.adapter_1.norm.bias, db)
+        dc = d_cur.view(-1, C)
+        B.acc(self.adapter_1.weight, B.weight_grad(dc, x2.view(-1, c2)).view_as(self.adapter_1.weight))
+        grads["res2"] = B.input_grad(dc, self.adapter_1.weight.view(C, c2)).view(N, h2, w2, c2)
+        # encoder output tokens: the decoder's gradient per level (+ the FPN's into the finest level)
+        parts = []
+        for i, (h, w) in enumerate(shapes):
+            g = d_outs[i] if d_outs[i] is not None else torch.zeros((N, h * w, C), device=d_mf.device, dtype=torch.float32)
+            if i == len(shapes) - 1:
+                g = g + d_up.view(N, h * w, C)
+            parts.append(g)
+        d_src = torch.cat(parts, 1).contiguous()
+        d_pos = None
+        for layer, saved_l in zip(reversed(self.transformer.encoder.layers), reversed(enc)):
+            d_src, dp = layer.backward(saved_l, d_src)
+            d_pos = dp if d_pos is None else d_pos + dp
+        # pos = sine encoding (constant) + level_embed[level]: the embedding's gradient is the per-level row sum
+        o, dle = 0, []
+        for (h, w) in shapes:
+            dle.append(B.bias_grad(d_pos[o:o + h * w].contiguous()))
+            o += h * w
+        B.acc(self.transformer.level_embed, torch.stack(dle, 0))
+        # input projections: tokens -> GN -> 1x1 conv -> backbone features
+        o = 0
+        for idx, f in enumerate(("res5", "res4", "res3")):
+            h, w = shapes[idx]
+            x, z = proj[idx]
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            d_y = d_src[:, o:o + h * w].contiguous().view(N, h, w, C)
+            o += h * w
+            d_z, dg, db = B.groupnorm_backward(z, d_y, 32, gn.weight, gn.eps)
+            B.acc(gn.weight, dg); B.acc(gn.bias, db)
+            dz = d_z.view(-1, C)
+            cin = x.shape[-1]
+            B.acc(conv.weight, B.weight_grad(dz, x.view(-1, cin)).view_as(conv.weight))
+            B.acc(conv.bias, B.bias_grad(dz))
+            grads[f] = B.input_grad(dz, conv.weight.view(C, cin)).view(N, h, w, cin)
+        return grads

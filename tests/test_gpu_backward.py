@@ -240,3 +240,70 @@ def test_msda_fused_backward_vs_autograd():
     dv, doa = backward.msda_fused_backward(v_h, shapes, o_h, go.to(DEV))
     assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 1e-5
     assert rel(doa.cpu().numpy(), od.grad.numpy()) < 1e-5
+
+
+def test_pixel_decoder_backward_vs_autograd():
+    """MSDeformAttnPixelDecoder.backward_features (input projections + GN, 2 deformable encoder layers, FPN level with
+    upsample-add, mask_features) against autograd through a float64 torch restatement of msdeformattn.py:314-358"""
+    import torch.nn.functional as F
+    from s2d_amd.modeling import MSDeformAttnPixelDecoder
+    from s2d_amd import ops
+    torch.manual_seed(0)
+    pd = MSDeformAttnPixelDecoder(transformer_enc_layers=2)
+    with torch.no_grad():
+        for n_, p in pd.named_parameters():                            # zero-initialised projections would hide gradient paths
+            if p.abs().max() == 0:
+                p.normal_(0, 0.05)
+            if "norm" in n_ and n_.endswith("weight"):
+                p.uniform_(0.5, 1.5)
+    N, h2, w2, C = 2, 16, 24, 256
+    g = torch.Generator().manual_seed(1)
+    feats = {"res2": torch.randn((N, 256, h2, w2), generator=g), "res3": torch.randn((N, 512, h2 // 2, w2 // 2), generator=g),
+             "res4": torch.randn((N, 1024, h2 // 4, w2 // 4), generator=g), "res5": torch.randn((N, 2048, h2 // 8, w2 // 8), generator=g)}
+    shapes = [(h2 // 8, w2 // 8), (h2 // 4, w2 // 4), (h2 // 2, w2 // 2)]
+    P = {k: v.detach().double().requires_grad_(True) for k, v in pd.named_parameters()}
+    Fd = {k: v.double().requires_grad_(True) for k, v in feats.items()}
+    pe = [ops.pe_sine(0, h, w, 128, add_c=torch.zeros(256, device=DEV), device=torch.device(DEV)).cpu().double() for h, w in shapes]
+
+    srcs = []
+    for idx, f in enumerate(("res5", "res4", "res3")):
+        y = F.conv2d(Fd[f], P[f"input_proj.{idx}.0.weight"], P[f"input_proj.{idx}.0.bias"])
+        y = F.group_norm(y, 32, P[f"input_proj.{idx}.1.weight"], P[f"input_proj.{idx}.1.bias"])
+        srcs.append(y.flatten(2).transpose(1, 2))
+    src = torch.cat(srcs, 1)
+    pos = torch.cat([pe[i] + P["transformer.level_embed"][i] for i in range(3)], 0)
+    for li in range(2):
+        pre = f"transformer.encoder.layers.{li}."
+        q = src + pos
+        lin = lambda x, n: F.linear(x, P[pre + n + ".weight"], P[pre + n + ".bias"])
+        oa = torch.cat([lin(q, "self_attn.sampling_offsets"), lin(q, "self_attn.attention_weights")], -1)
+        samp = _msda_fused_torch(lin(src, "self_attn.value_proj"), shapes, oa)
+        s1 = F.layer_norm(lin(samp, "self_attn.output_proj") + src, (C,), P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+        x2 = lin(torch.relu(lin(s1, "linear1")), "linear2") + s1
+        src = F.layer_norm(x2, (C,), P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+    outs, o = [], 0
+    for (h, w) in shapes:
+        outs.append(src[:, o:o + h * w]); o += h * w
+    cur = F.group_norm(F.conv2d(Fd["res2"], P["adapter_1.weight"]), 32, P["adapter_1.norm.weight"], P["adapter_1.norm.bias"])
+    up = outs[-1].transpose(1, 2).reshape(N, C, *shapes[-1])
+    y1 = cur + F.interpolate(up, size=(h2, w2), mode="bilinear", align_corners=False)
+    y3 = torch.relu(F.group_norm(F.conv2d(y1, P["layer_1.weight"], padding=1), 32, P["layer_1.norm.weight"], P["layer_1.norm.bias"]))
+    mf = F.conv2d(y3, P["mask_features.weight"], P["mask_features.bias"])
+    d_mf = torch.randn(mf.shape, generator=g)
+    d_outs = [torch.randn(o_.shape, generator=g) for o_ in outs]
+    ((mf * d_mf.double()).sum() + sum((o_ * d.double()).sum() for o_, d in zip(outs, d_outs))).backward()
+
+    pd = pd.to(DEV)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    tape = []
+    mf_h, ms = pd.forward_features({k: nhwc(v) for k, v in feats.items()}, tape)
+    assert rel(mf_h.permute(0, 3, 1, 2).cpu().numpy(), mf.detach().numpy()) < 1e-5
+    grads = pd.backward_features(tape[0], nhwc(d_mf), [d.to(DEV) for d in d_outs])
+    for k in ("res2", "res3", "res4", "res5"):
+        assert rel(grads[k].permute(0, 3, 1, 2).cpu().numpy(), Fd[k].grad.numpy()) < 2e-5, k
+    worst = {}
+    for k, p in pd.named_parameters():
+        assert p.grad is not None, k
+        worst[k] = rel(p.grad.cpu().numpy(), P[k].grad.numpy())
+    bad = {k: v for k, v in worst.items() if v > 5e-5}
+    assert not bad, bad
