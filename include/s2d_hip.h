@@ -151,11 +151,21 @@ long s2d_attn_workspace_floats(int B, int H, int K);
 /* out[b][q][:] = concat_h softmax_k(q_h k_h^T / sqrt(32) + mask) v_h with q [B][Q][C], k/v [B][K] rows of C floats
  * at row strides ldk / ldv >= C (a column slice of a wider projection output; multiples of 4), already projected,
  * C = 32*H, Q <= 128.  bits/unmasked from s2d_attn_mask_bits (NULL = no mask: the self-attention
- * of :41-51); a query with no attendable key attends everywhere (the fix at :413).  Replaces the core of
+ * of :41-51); a query with no attendable key attends everywhere (the fix at :413).  lse (may be NULL) [B][H][128]
+ * receives the base-2 log-sum-exp of the scaled scores, which the backward needs.  Replaces the core of
  * nn.MultiheadAttention at :99-111 without materialising the [B*8,Q,K] mask or the scores. */
 int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
-                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out,
+                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out, float *lse,
                         hipStream_t stream);
+
+/* Backward of s2d_masked_attn_f32.  lse [B][H][128]: the base-2 log-sum-exp the forward leaves when
+ * its `lse` argument is non-NULL; out = the forward output; dout [B][Q][C].  dq [B][Q][C], dk / dv [B][K][C] (dense).
+ * Probabilities are recomputed from lse; dQ partials over key ranges are added in a fixed order.  workspace:
+ * s2d_attn_backward_workspace_floats(B, H, K) floats. */
+long s2d_attn_backward_workspace_floats(int B, int H, int K);
+int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                                 const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q,
+                                 int K, int C, int H, float *workspace, float *dq, float *dk, float *dv, hipStream_t stream);
 
 /* ---- VideoHungarianMatcher on the device -------------------------------------------------------------- */
 /* A criterion pass handles NL prediction layers x B clips = NL*B independent "problems" (problem = layer*B +

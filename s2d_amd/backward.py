@@ -245,3 +245,18 @@ def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4):
     doa = torch.empty((N, S, ldd), device=dev, dtype=torch.float32)
     lib().call("s2d_msda_fused_chain_f32", attn, gl, ga, sh, N, S, M, L, P, doa, ldd, _st())
     return gv.view(N, S, C), doa
+
+
+# --------------------------------------------------------------------------- masked attention
+def masked_attn_backward(q, k, v, out, lse, dout, bits=None, unmasked=None, H=8):
+    """gradients of ops.masked_attn(q, k, v, bits, unmasked) -> (dq [B,Q,C], dk [B,K,C], dv [B,K,C])"""
+    ops._chk(q); ops._chk(out); ops._chk(dout); ops._chk(lse)
+    B, Q, C = q.shape
+    K = k.shape[1]
+    ws = torch.empty((lib().call("s2d_attn_backward_workspace_floats", B, H, K),), device=q.device, dtype=torch.float32)
+    dq = torch.empty_like(q)
+    dk = torch.empty((B, K, C), device=q.device, dtype=torch.float32)
+    dv = torch.empty((B, K, C), device=q.device, dtype=torch.float32)
+    lib().call("s2d_masked_attn_backward_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, out, lse, dout, B, Q, K, C, H, ws, dq, dk, dv,
+               _st())
+    return dq, dk, dv

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(AttnParams p)
 
 // merge the S partials: out[b][q][hd*32+d]
 __global__ void attn_merge_kernel(const float *__restrict__ wo, const float *__restrict__ wm, const float *__restrict__ wl,
-                                  int B, int Q, int C, int H, int S, float *__restrict__ out)
+                                  int B, int Q, int C, int H, int S, float *__restrict__ out, float *__restrict__ lse)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * H * 32 * 128;
@@ -326,6 +326,198 @@ __global__ void attn_merge_kernel(const float *__restrict__ wo, const float *__r
         O += wo[((base + s) * 32 + d) * 128 + q] * f;
     }
     out[((long)b * Q + q) * C + hd * 32 + d] = O / L;
+    if (lse && d == 0) lse[((long)b * H + hd) * 128 + q] = M + log2f(L);      // base-2 log-sum-exp of the scaled scores (backward)
+}
+
+// ---- backward.  With s = q.k * scale (+ mask), P = softmax_k(s), O = P V:
+//   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - rowsum(dO o O)),   dQ = dS K * scale,   dK = dS^T Q * scale.
+// P is recomputed from the saved log-sum-exp (nothing of size Q x K is stored).  Two fp32 kernels, neither needs a
+// cross-lane reduction in its inner loop: attn_bwd_kv_kernel owns a tile of 64 keys (a thread = one key x a quarter of the
+// queries, accumulating that key's dK / dV rows in registers), attn_bwd_q_kernel owns the queries over a range of key tiles
+// (a thread = one query x half of the keys, accumulating the query's dQ row) and leaves per-range partials that
+// attn_bwd_merge_kernel adds in a fixed order (reproducible).
+struct AttnBwdParams {
+    const float *q, *k, *v, *o, *dout, *lse;
+    long ldk, ldv;
+    const uint32_t *bits, *unmasked;
+    int Q, K, C, H, S, tiles_per_split;
+    float qscale;                      // 1/sqrt(d) * log2(e)
+    float *dk, *dv, *dq_part;          // dk, dv [B][K][C]; dq_part [B][H][S][128][32]
+};
+constexpr int BT = 64;                 // keys per backward tile
+constexpr float LN2 = 0.6931471805599453f;
+
+// stage this head's scaled q rows, dO rows, delta = sum_d dO o O and lse for all queries
+__device__ __forceinline__ void stage_queries(const AttnBwdParams &p, int b, int hd, float (*qs)[33], float (*dos)[33], float *delta, float *lses)
+{
+    for (int i = threadIdx.x; i < 128 * 8; i += 256) {
+        const int qq = i >> 3, c = (i & 7) * 4;
+        f32x4 a = f32x4(0.f), g = f32x4(0.f);
+        if (qq < p.Q) {
+            a = *reinterpret_cast<const f32x4 *>(p.q + ((long)b * p.Q + qq) * p.C + hd * 32 + c) * p.qscale;
+            g = *reinterpret_cast<const f32x4 *>(p.dout + ((long)b * p.Q + qq) * p.C + hd * 32 + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qs[qq][c + j] = a[j]; dos[qq][c + j] = g[j]; }
+    }
+    if (threadIdx.x < 128) {
+        const int qq = threadIdx.x;
+        float dl = 0.f, ls = 0.f;
+        if (qq < p.Q) {
+            const float *op = p.o + ((long)b * p.Q + qq) * p.C + hd * 32, *gp = p.dout + ((long)b * p.Q + qq) * p.C + hd * 32;
+            for (int d = 0; d < 32; ++d) dl += op[d] * gp[d];
+            ls = p.lse[((long)b * p.H + hd) * 128 + qq];
+        }
+        delta[qq] = dl; lses[qq] = ls;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams p)
+{
+    __shared__ float qs[128][33], dos[128][33];
+    __shared__ float delta[128], lses[128];
+    __shared__ uint32_t ign[QW];                       // queries whose mask is ignored (no attendable key, :413)
+    const int hd = blockIdx.y, b = blockIdx.z;
+    const int kk = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const long key = (long)blockIdx.x * BT + kk;
+    const bool kok = key < p.K;
+    stage_queries(p, b, hd, qs, dos, delta, lses);
+    if (threadIdx.x < QW) ign[threadIdx.x] = (p.bits && p.unmasked) ? ~p.unmasked[b * QW + threadIdx.x] : (p.bits ? 0u : 0xFFFFFFFFu);
+    float kr[32], vr[32], dK[32], dV[32];
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        f32x4 a = f32x4(0.f), c = f32x4(0.f);
+        if (kok) {
+            a = *reinterpret_cast<const f32x4 *>(p.k + ((long)b * p.K + key) * p.ldk + hd * 32 + d);
+            c = *reinterpret_cast<const f32x4 *>(p.v + ((long)b * p.K + key) * p.ldv + hd * 32 + d);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kr[d + j] = a[j]; vr[d + j] = c[j]; dK[d + j] = 0.f; dV[d + j] = 0.f; }
+    }
+    uint32_t mw[QW] = {0u, 0u, 0u, 0u};
+    if (p.bits && kok)
+#pragma unroll
+        for (int w = 0; w < QW; ++w) mw[w] = p.bits[((long)b * p.K + key) * QW + w];
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QW; ++w) mw[w] &= ~ign[w];     // bit set = this (query, key) pair does not attend
+    for (int qq = quarter; qq < p.Q; qq += 4) {
+        if ((mw[qq >> 5] >> (qq & 31)) & 1u) continue;
+        float s2 = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { s2 += qs[qq][d] * kr[d]; dp += dos[qq][d] * vr[d]; }
+        const float pr = kok ? exp2f(s2 - lses[qq]) : 0.f;
+        const float ds = pr * (dp - delta[qq]);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { dV[d] += pr * dos[qq][d]; dK[d] += ds * qs[qq][d]; }
+    }
+    __syncthreads();
+    // add the four query quarters (fixed order) through LDS: reuse qs / dos as [4][64][33] would not fit -> two rounds
+    float (*red)[64][33] = reinterpret_cast<float (*)[64][33]>(&qs[0][0]);   // 2 x 64 x 33 floats fit in qs (128 x 33)
+    for (int round = 0; round < 2; ++round) {
+        const float *src = round == 0 ? dK : dV;
+        // quarters 1..3 deposit in turn, quarter 0 accumulates: three steps keep the order fixed
+        for (int step = 1; step < 4; ++step) {
+            if (quarter == step)
+#pragma unroll
+                for (int d = 0; d < 32; ++d) red[0][kk][d] = src[d];
+            __syncthreads();
+            if (quarter == 0) {
+                float *dst = round == 0 ? dK : dV;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dst[d] += red[0][kk][d];
+            }
+            __syncthreads();
+        }
+    }
+    if (quarter == 0 && kok) {
+        float *ko = p.dk + ((long)b * p.K + key) * p.C + hd * 32, *vo = p.dv + ((long)b * p.K + key) * p.C + hd * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const f32x4 a = {dK[d] * LN2, dK[d + 1] * LN2, dK[d + 2] * LN2, dK[d + 3] * LN2};   // qs carries log2(e): back to natural scale
+            const f32x4 c = {dV[d], dV[d + 1], dV[d + 2], dV[d + 3]};
+            *reinterpret_cast<f32x4 *>(ko + d) = a;
+            *reinterpret_cast<f32x4 *>(vo + d) = c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams p)
+{
+    __shared__ float ks[BT][33], vs[BT][33];
+    __shared__ uint32_t ms[BT][QW];
+    __shared__ float red[128][33];
+    const int split = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int qq = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const bool qok = qq < p.Q;
+    float qr[32], gr[32], dq[32];
+    float dl = 0.f, ls = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { qr[d] = 0.f; gr[d] = 0.f; dq[d] = 0.f; }
+    if (qok) {
+        const float *qp = p.q + ((long)b * p.Q + qq) * p.C + hd * 32, *gp = p.dout + ((long)b * p.Q + qq) * p.C + hd * 32;
+        const float *op = p.o + ((long)b * p.Q + qq) * p.C + hd * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qr[d] = qp[d] * p.qscale; gr[d] = gp[d]; dl += op[d] * gp[d]; }
+        ls = p.lse[((long)b * p.H + hd) * 128 + qq];
+    }
+    bool use_mask = p.bits != nullptr;
+    if (use_mask && p.unmasked && qok && !((p.unmasked[b * QW + (qq >> 5)] >> (qq & 31)) & 1u)) use_mask = false;
+    const int ntiles = (p.K + BT - 1) / BT;
+    const int t0 = split * p.tiles_per_split, t1 = min(ntiles, t0 + p.tiles_per_split);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < BT * 8; i += 256) {
+            const int r = i >> 3, c = (i & 7) * 4;
+            const long key = (long)t * BT + r;
+            f32x4 a = f32x4(0.f), g = f32x4(0.f);
+            if (key < p.K) {
+                a = *reinterpret_cast<const f32x4 *>(p.k + ((long)b * p.K + key) * p.ldk + hd * 32 + c);
+                g = *reinterpret_cast<const f32x4 *>(p.v + ((long)b * p.K + key) * p.ldv + hd * 32 + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ks[r][c + j] = a[j]; vs[r][c + j] = g[j]; }
+        }
+        if (threadIdx.x < BT * QW) {
+            const int r = threadIdx.x / QW, w = threadIdx.x % QW;
+            const long key = (long)t * BT + r;
+            ms[r][w] = key < p.K ? (p.bits ? p.bits[((long)b * p.K + key) * QW + w] : 0u) : 0xFFFFFFFFu;   // keys past K never attend
+        }
+        __syncthreads();
+        if (!qok) continue;
+        for (int r = half; r < BT; r += 2) {
+            const uint32_t w = ms[r][qq >> 5];
+            const bool beyond = (long)t * BT + r >= p.K;
+            if (beyond || (use_mask && ((w >> (qq & 31)) & 1u))) continue;
+            float s2 = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s2 += qr[d] * ks[r][d]; dp += gr[d] * vs[r][d]; }
+            const float ds = exp2f(s2 - ls) * (dp - dl);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dq[d] += ds * ks[r][d];
+        }
+    }
+    __syncthreads();
+    if (half == 1)
+#pragma unroll
+        for (int d = 0; d < 32; ++d) red[qq][d] = dq[d];
+    __syncthreads();
+    if (half == 0) {
+        float *o = p.dq_part + ((((long)b * p.H + hd) * p.S + split) * 128 + qq) * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = dq[d] + red[qq][d];
+    }
+}
+
+__global__ void attn_bwd_merge_kernel(const float *__restrict__ part, int B, int Q, int C, int H, int S, float factor, float *__restrict__ dq)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Q * C) return;
+    const int c = (int)(i % C), q = (int)((i / C) % Q), b = (int)(i / ((long)C * Q));
+    const int hd = c >> 5, d = c & 31;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[((((long)b * H + hd) * S + s) * 128 + q) * 32 + d];
+    dq[i] = a * factor;
 }
 
 }  // namespace
@@ -353,8 +545,41 @@ long s2d_attn_workspace_floats(int B, int H, int K)
     return (long)B * H * S * (32 * 128 + 2 * 128);
 }
 
+static int attn_bwd_splits(int K)
+{
+    const int tiles = (K + BT - 1) / BT;
+    int S = tiles / 4; if (S < 1) S = 1; if (S > 64) S = 64;
+    return S;
+}
+
+long s2d_attn_backward_workspace_floats(int B, int H, int K) { return (long)B * H * attn_bwd_splits(K) * 128 * 32; }
+
+int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                                 const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q, int K,
+                                 int C, int H, float *workspace, float *dq, float *dk, float *dv, hipStream_t stream)
+{
+    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0 || ldk < C || ldv < C || (ldk & 3) || (ldv & 3)) return S2D_ERR_ARG;
+    if (B == 0) return S2D_OK;
+    AttnBwdParams p;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = lse; p.ldk = ldk; p.ldv = ldv; p.bits = bits; p.unmasked = unmasked;
+    p.Q = Q; p.K = K; p.C = C; p.H = H;
+    p.S = attn_bwd_splits(K);
+    const int tiles = (K + BT - 1) / BT;
+    p.tiles_per_split = (tiles + p.S - 1) / p.S;
+    p.qscale = 0.17677669529663687f * 1.4426950408889634f;
+    p.dk = dk; p.dv = dv; p.dq_part = workspace;
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(tiles, H, B), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(p.S, H, B), dim3(256), 0, stream, p);
+    const long total = (long)B * Q * C;
+    hipLaunchKernelGGL(attn_bwd_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, workspace, B, Q, C, H, p.S,
+                       0.17677669529663687f, dq);      // dS carries natural-scale probabilities; dQ = dS K / sqrt(d)
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
-                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out, hipStream_t stream)
+                        const uint32_t *unmasked, int B, int Q, int K, int C, int H, float *workspace, float *out, float *lse,
+                        hipStream_t stream)
 {
     if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0 || ldk < C || ldv < C || (ldk & 3) || (ldv & 3)) return S2D_ERR_ARG;
     if (B == 0) return S2D_OK;
@@ -370,7 +595,7 @@ int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk
     p.qscale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
     hipLaunchKernelGGL(cross_attn_kernel, dim3(S, H, B), dim3(256), 0, stream, p);
     const long total = (long)B * H * 32 * 128;
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.wo, p.wm, p.wl, B, Q, C, H, S, out);
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.wo, p.wm, p.wl, B, Q, C, H, S, out, lse);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -16,7 +16,7 @@ namespace {
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, long R, long C, long ldi, float *__restrict__ out, long ldo)
 {
     __shared__ float tile[64][65];
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const long r0 = (long)blockIdx.x * 64, c0 = (long)blockIdx.y * 64;          // rows (millions of positions) on grid.x
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x 16 threads, each 4 columns x 4 rows
     const bool vin = ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
 #pragma unroll
@@ -307,8 +307,8 @@ int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, lon
 {
     if (R < 0 || C < 0 || ldi < C || ldo < R) return S2D_ERR_ARG;
     if (R == 0 || C == 0) return S2D_OK;
-    if ((R + 63) / 64 > 65535) return S2D_ERR_ARG;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, stream, in, R, C, ldi, out, ldo);
+    if ((C + 63) / 64 > 65535 || (R + 63) / 64 >= (1L << 31)) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(R, 64), cdiv(C, 64)), dim3(256), 0, stream, in, R, C, ldi, out, ldo);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

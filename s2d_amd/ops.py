@@ -283,8 +283,9 @@ def attn_mask_tap_index(T, hm, wm, hl, wl, device):
     return (t + pix[None]).reshape(-1).contiguous()
 
 
-def masked_attn(q, k, v, bits=None, unmasked=None, H=8):
-    """q [B,Q,C], k/v [B,K,C] (projected; k and v may be column slices of a wider [B,K,ld] projection output) -> [B,Q,C]."""
+def masked_attn(q, k, v, bits=None, unmasked=None, H=8, want_lse=False):
+    """q [B,Q,C], k/v [B,K,C] (projected; k and v may be column slices of a wider [B,K,ld] projection output) -> [B,Q,C]
+    (and, want_lse, the base-2 log-sum-exp [B,H,128] the backward needs)."""
     _chk(q)
     B, Q, C = q.shape
     K = k.shape[1]
@@ -294,8 +295,9 @@ def masked_attn(q, k, v, bits=None, unmasked=None, H=8):
     n = lib().call("s2d_attn_workspace_floats", B, H, K)
     ws = torch.empty((n,), device=q.device, dtype=torch.float32)
     out = torch.empty_like(q)
-    lib().call("s2d_masked_attn_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, B, Q, K, C, H, ws, out, _stream())
-    return out
+    lse = torch.empty((B, H, 128), device=q.device, dtype=torch.float32) if want_lse else None
+    lib().call("s2d_masked_attn_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, B, Q, K, C, H, ws, out, lse, _stream())
+    return (out, lse) if want_lse else out
 
 
 # ----------------------------------------------------------------------------- matcher / criterion

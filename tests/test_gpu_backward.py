@@ -307,3 +307,46 @@ def test_pixel_decoder_backward_vs_autograd():
         worst[k] = rel(p.grad.cpu().numpy(), P[k].grad.numpy())
     bad = {k: v for k, v in worst.items() if v > 5e-5}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,Q,K,masked", [(2, 100, 1500, True), (1, 100, 100, False), (2, 37, 333, True), (1, 100, 20000, True)])
+def test_masked_attention_backward_vs_autograd(B, Q, K, masked):
+    """decoder attention core (nn.MultiheadAttention after the in-projections, video_mask2former_transformer_decoder.py:41-51,
+    99-111) incl. the all-masked-row fix (:413): dq, dk, dv vs float64 autograd"""
+    from s2d_amd import backward, ops
+    g = torch.Generator().manual_seed(B * 1000 + Q + K)
+    C, H = 256, 8
+    q, dout = torch.randn((B, Q, C), generator=g), torch.randn((B, Q, C), generator=g)
+    k, v = torch.randn((B, K, C), generator=g), torch.randn((B, K, C), generator=g)
+    mask = (torch.rand((B, Q, K), generator=g) < 0.6) if masked else torch.zeros((B, Q, K), dtype=torch.bool)
+    if masked:
+        mask[0, 3] = True                                            # a query with every key masked attends everywhere
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    eff = mask.clone()
+    eff[eff.all(-1)] = False
+    sc = torch.einsum("bqhd,bkhd->bhqk", qd.view(B, Q, H, 32), kd.view(B, K, H, 32)) / 32 ** 0.5
+    sc = sc.masked_fill(eff[:, None], float("-inf"))
+    out = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), vd.view(B, K, H, 32)).reshape(B, Q, C)
+    (out * dout.double()).sum().backward()
+    bits = unm = None
+    if masked:
+        m = mask.permute(0, 2, 1).numpy()                            # [B,K,Q]
+        words = np.zeros((B, K, 4), np.uint32)
+        for qq in range(Q):
+            words[:, :, qq >> 5] |= m[:, :, qq].astype(np.uint32) << np.uint32(qq & 31)
+        unw = np.zeros((B, 4), np.uint32)
+        anyfree = (~mask).any(-1).numpy()                            # [B,Q]
+        for qq in range(Q):
+            unw[:, qq >> 5] |= anyfree[:, qq].astype(np.uint32) << np.uint32(qq & 31)
+        bits = torch.from_numpy(words.view(np.int32)).to(DEV)
+        unm = torch.from_numpy(unw.view(np.int32)).to(DEV)
+    # k / v as column slices of a wider buffer, as the decoder passes them
+    wide = torch.zeros((B, K, 3 * C), device=DEV)
+    wide[..., C:2 * C] = k.to(DEV); wide[..., 2 * C:] = v.to(DEV)
+    ks, vs = wide[..., C:2 * C], wide[..., 2 * C:]
+    o_h, lse = ops.masked_attn(q.to(DEV), ks, vs, bits, unm, want_lse=True)
+    assert rel(o_h.cpu().numpy(), out.detach().numpy()) < 1e-5
+    dq, dk, dv = backward.masked_attn_backward(q.to(DEV), ks, vs, o_h, lse, dout.to(DEV), bits, unm)
+    assert rel(dq.cpu().numpy(), qd.grad.numpy()) < 2e-5
+    assert rel(dk.cpu().numpy(), kd.grad.numpy()) < 2e-5
+    assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 2e-5
