@@ -342,6 +342,23 @@ int s2d_optim_adamw_ema_f32(const void *const *ptrs, const long *numel, const do
                             double eps, double bias_correction1, double bias_correction2_sqrt, float inv_scale, double ema_m,
                             const float *normbuf, hipStream_t stream);
 
+/* Backward of s2d_point_loss_f32: same arguments, the workspace the forward call left behind
+ * (thresholds, tie state, stored point samples, per-row sums), plus the loss weights.  grad_rows
+ * [NL*B*min(Q,Nmax)*T][hm*wm] = d(w_mask * loss_mask + w_dice * loss_dice, all layers) / d(logit map of row
+ * ((layer*B + b)*maxm + slot)*T + t); rows of unmatched slots and dropped frames are zero.  The selected points are
+ * exactly the forward's (same threshold, same tie rule); their gradients are scattered through the bilinear taps with float
+ * atomics, as grid_sample's backward does.  Only when every row took the stored-sample path (ERR_ARG otherwise). */
+int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                                const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
+                                const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm,
+                                int H, int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio,
+                                int drop_empty, float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows,
+                                hipStream_t stream);
+
+/* d(w_ce * loss_labels)/d(class_logits) for one layer (same arguments as s2d_class_loss_f32) -> [B][Q][2] */
+int s2d_class_loss_backward_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,
+                                float eos_coef, float w_ce, float *d_class_logits, hipStream_t stream);
+
 /* ---- keymask discovery (paths relative to /root/reference/keymask_ident) ------------------------------- */
 
 /* pred_tracks_to_binary_masks(return_mask=False), cotracker_matching.py:453-503: tracks [T][Np][2] (x,y px) ->

@@ -604,7 +604,15 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
 
 // accumulate for rows with stored samples: item = row.  The row's whole target plane is bit-packed into LDS
 // (H*W/8 bytes: 118 KB at 736x1280), the stored logits are streamed, only (u,v) is regenerated for the target taps.
-__global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p)
+// BWD = true: the same walk over the same selected points (same threshold, same tie rule), but instead of summing the loss
+// terms every point scatters d(loss)/d(logit at the point) into the row's gradient plane through the bilinear taps of its
+// sample position (float atomics on a [rows][hm*wm] buffer, as grid_sample's backward does).
+struct LossBwdArgs {
+    float *gplane;            // [rows][hm*wm], zero-initialised
+    float w_mask, w_dice;     // loss weights (weight_dict) of loss_mask / loss_dice
+};
+template <bool BWD>
+__global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p, LossBwdArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int tbits[];
     __shared__ float red[LTHREADS / 64][4];
@@ -651,6 +659,46 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         const unsigned int take = (unsigned int)p.krem[rowid];
         const float *xb = p.xbuf + (long)li * (p.n_over + p.n_rand);
         float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
+        // backward: per-row constants of d(w_mask * loss_mask + w_dice * loss_dice) / d(logit at a point)
+        float g_bce = 0.f, g_dice = 0.f, dA = 0.f, dD = 1.f;
+        float *gp = nullptr;
+        if constexpr (BWD) {
+            double num = 0.;
+            for (int bb = 0; bb < p.B; ++bb) num += (double)min(p.tgt_count[bb], p.Nmax);
+            num = fmax(num / (double)p.world_size, 1.0);
+            float a = 0.f, bsum = 0.f, c = 0.f;
+            for (int ch = 0; ch < p.chunks; ++ch) {
+                const float *qd = p.part + (rowid * p.chunks + ch) * 4;
+                a += qd[1]; bsum += qd[2]; c += qd[3];
+            }
+            dA = 2.f * a + 1.f; dD = bsum + c + 1.f;
+            g_bce = ba.w_mask / ((float)num * (float)(p.n_unc + p.n_rand));
+            g_dice = ba.w_dice / (float)num;
+            gp = ba.gplane + rowid * (long)p.hm * p.wm;
+        }
+        auto point = [&](float xv, float tt, float u, float v) {
+            if constexpr (!BWD) {
+                acc_point(xv, tt, bce, sgt, sg, ts);
+            } else {
+                const float e = __expf(-fabsf(xv));
+                const float inv = 1.f / (1.f + e);
+                const float sgm = xv >= 0.f ? inv : e * inv;
+                // d bce / dx = sigma - t;  d dice / d sigma = -(2 t D - A) / D^2,  d sigma / dx = sigma (1 - sigma)
+                const float g = g_bce * (sgm - tt) - g_dice * ((2.f * tt * dD - dA) / (dD * dD)) * sgm * (1.f - sgm);
+                const float gx = 2.f * u - 1.f, gy = 2.f * v - 1.f;                      // point_sample of the logit row
+                const float x = ((gx + 1.f) * p.wm - 1.f) * 0.5f, y = ((gy + 1.f) * p.hm - 1.f) * 0.5f;
+                const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
+                const float fx = x - x0, fy = y - y0;
+                if (y0 >= 0 && y0 < p.hm) {
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gp + y0 * p.wm + x0, g * (1.f - fx) * (1.f - fy));
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gp + y0 * p.wm + x1, g * fx * (1.f - fy));
+                }
+                if (y1 >= 0 && y1 < p.hm) {
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gp + y1 * p.wm + x0, g * (1.f - fx) * fy);
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gp + y1 * p.wm + x1, g * fx * fy);
+                }
+            }
+        };
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             const bool over = pass == 0;
@@ -665,7 +713,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                acc_point(xv, sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+                point(xv, sample_bits(tbits, p.H, p.W, u, v), u, v);
             };
             // Only ~1 in 4 oversampled points passes the threshold, scattered over the lanes: evaluating them in place
             // would run the heavy path at 25 % lane utilisation.  Each wave instead compacts its selected points (ballot
@@ -743,7 +791,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                acc_point(xb[i], sample_bits(tbits, p.H, p.W, u, v), bce, sgt, sg, ts);
+                point(xb[i], sample_bits(tbits, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
                 for (unsigned int j = threadIdx.x; j < nties; j += LTHREADS) {
@@ -775,18 +823,20 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
             }
         }
-        bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            const int j = threadIdx.x;
-            float tot = 0.f;
+        if constexpr (!BWD) {
+            bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            if (lane == 0) { red[wv][0] = bce; red[wv][1] = sgt; red[wv][2] = sg; red[wv][3] = ts; }
+            __syncthreads();
+            if (threadIdx.x < 4) {
+                const int j = threadIdx.x;
+                float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < LTHREADS / 64; ++w) tot += red[w][j];
-            p.part[(rowid * p.chunks + 0) * 4 + j] = tot;
+                for (int w = 0; w < LTHREADS / 64; ++w) tot += red[w][j];
+                p.part[(rowid * p.chunks + 0) * 4 + j] = tot;
 #pragma unroll 1
-            for (int c = 1; c < p.chunks; ++c) p.part[(rowid * p.chunks + c) * 4 + j] = 0.f;
+                for (int c = 1; c < p.chunks; ++c) p.part[(rowid * p.chunks + c) * 4 + j] = 0.f;
+            }
         }
     }
 }
@@ -851,6 +901,37 @@ __global__ void class_loss_kernel(const float *__restrict__ cls, const int *__re
     }
 }
 
+// d(w_ce * loss_labels)/d(class logits): w_i (softmax_i - onehot_i) / sum_j w_j  (criterion.py:227-251 differentiated)
+__global__ void class_loss_backward_kernel(const float *__restrict__ cls, const int *__restrict__ idx_q, const int *__restrict__ n_match,
+                                           int B, int Q, int maxm, float eos, float w_ce, float *__restrict__ dcls)
+{
+    __shared__ unsigned char matched[128];
+    __shared__ float wsum;
+    double den = 0.;
+    if (threadIdx.x == 0) {
+        for (int b = 0; b < B; ++b) den += (double)n_match[b] + (double)eos * (Q - n_match[b]);
+        wsum = (float)den;
+    }
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        if (threadIdx.x < 128) matched[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x < n_match[b]) matched[idx_q[(long)b * maxm + threadIdx.x]] = 1;
+        __syncthreads();
+        const int q = threadIdx.x;
+        if (q < Q) {
+            const float l0 = cls[((long)b * Q + q) * 2], l1 = cls[((long)b * Q + q) * 2 + 1];
+            const float mx = fmaxf(l0, l1);
+            const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+            const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+            const bool m = matched[q];
+            const float w = (m ? 1.f : eos) * w_ce / wsum;
+            dcls[((long)b * Q + q) * 2] = w * (p0 - (m ? 1.f : 0.f));
+            dcls[((long)b * Q + q) * 2 + 1] = w * (p1 - (m ? 0.f : 1.f));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -903,21 +984,20 @@ long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int h
            xrows * (long)(n_over + n_rand + 8) * 4;
 }
 
-int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
-                       const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
-                       const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
-                       int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
-                       float world_size, void *workspace, float *losses, hipStream_t stream)
+// parameter block + workspace carve-up shared by the forward and the backward entry points (same arguments, same layout)
+static int loss_setup(LossParams &p, long &rows, const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                      const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over, const float *coords_rand,
+                      uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H, int W, int Nmax, int num_points,
+                      float oversample_ratio, float importance_ratio, int drop_empty, float world_size, void *workspace)
 {
     if (Q > 128 || Nmax > 128 || ldq > 128 || ldq < Q || (ldq & 3)) return S2D_ERR_ARG;
-    LossParams p;
     p.ml = mask_logits; p.tgt = tgt; p.tgt_count = tgt_count; p.nonempty = nonempty;
     p.idx_q = idx_q; p.idx_t = idx_t; p.n_match = n_match; p.coords_over = coords_over; p.coords_rand = coords_rand;
     p.seed = seed; p.NL = NL; p.B = B; p.Q = Q; p.ldq = ldq; p.T = T; p.hm = hm; p.wm = wm; p.H = H; p.W = W; p.Nmax = Nmax;
     p.maxm = Q < Nmax ? Q : Nmax;
     point_counts(num_points, oversample_ratio, importance_ratio, p.n_over, p.n_unc, p.n_rand);
     p.drop = drop_empty; p.world_size = world_size; p.chunks = LOSS_CHUNKS;
-    const long rows = (long)NL * B * p.maxm * T;
+    rows = (long)NL * B * p.maxm * T;
     if (rows == 0) return S2D_OK;
     char *w = (char *)workspace;
     p.active = (int *)w; w += rows * 4;
@@ -936,16 +1016,14 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     // samples are kept only when the target plane fits LDS as bits and vector loads line up
     const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 140 * 1024);   // + ~13 KB of static LDS (queues, tie lists) under the 160 KB of a CU
     p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
-    if (s2d_zero_async(p.hist, (size_t)rows * 2048 * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    if (s2d_zero_async(p.tie, (size_t)rows * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
     const PartGeom pg = part_geom(hm, wm);
     if ((wm & 3) || pg.rows_per_part < 1 || pg.nparts > LOSS_CHUNKS) return S2D_ERR_ARG;
     p.chunks = pg.nparts;
-    const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 1) * wm;
-    const size_t lds_hist = lds_map + sizeof(float) * 2048;
+    return S2D_OK;
+}
+
+static int loss_attrs()
+{
     static bool attr_set = false;
     if (!attr_set) {
         const int cap = PART_BYTES + 8192 + 4096;
@@ -953,10 +1031,35 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
+    return S2D_OK;
+}
+
+int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                       const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
+                       const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                       int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
+                       float world_size, void *workspace, float *losses, hipStream_t stream)
+{
+    LossParams p;
+    long rows = 0;
+    if (int e = loss_setup(p, rows, mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand, seed, NL, B, Q, ldq,
+                           T, hm, wm, H, W, Nmax, num_points, oversample_ratio, importance_ratio, drop_empty, world_size, workspace))
+        return e;
+    if (rows == 0) return S2D_OK;
+    if (s2d_zero_async(p.hist, (size_t)rows * 2048 * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(p.tie, (size_t)rows * 4, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(row_prep_kernel, dim3(NL), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
+    const PartGeom pg = part_geom(hm, wm);
+    const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 1) * wm;
+    const size_t lds_hist = lds_map + sizeof(float) * 2048;
+    if (int e = loss_attrs()) return e;
     const dim3 g(512);      // persistent: 2 blocks per CU's worth of items in flight
     hipLaunchKernelGGL(hist_kernel<0>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<0>, dim3((unsigned)rows), dim3(256), 0, stream, p);
@@ -966,9 +1069,43 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<2>, dim3(2048), dim3(256), 0, stream, p);
     if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p);
+    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f});
     if (rows > p.xcap) hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+/* Backward of s2d_point_loss_f32 with the SAME arguments and the workspace the forward left behind (thresholds, tie
+ * state, stored samples, per-row sums): grad_rows [NL*B*maxm*T][hm*wm] receives d(w_mask*loss_mask + w_dice*loss_dice of
+ * every layer)/d(logit map of the row); rows of unmatched slots / dropped frames stay zero. */
+int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
+                                const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
+                                const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
+                                int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
+                                float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows, hipStream_t stream)
+{
+    LossParams p;
+    long rows = 0;
+    if (int e = loss_setup(p, rows, mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand, seed, NL, B, Q, ldq,
+                           T, hm, wm, H, W, Nmax, num_points, oversample_ratio, importance_ratio, drop_empty, world_size, workspace))
+        return e;
+    if (rows == 0) return S2D_OK;
+    if (p.xcap < rows) return S2D_ERR_ARG;             // only the stored-sample path has a backward (every real configuration takes it)
+    if (int e = loss_attrs()) return e;
+    if (s2d_zero_async(grad_rows, sizeof(float) * (size_t)rows * hm * wm, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p,
+                       LossBwdArgs{grad_rows, w_mask, w_dice});
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_class_loss_backward_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm, float eos_coef,
+                                float w_ce, float *d_class_logits, hipStream_t stream)
+{
+    if (Q > 128) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(class_loss_backward_kernel, dim3(1), dim3(128), 0, stream, class_logits, idx_q, n_match, B, Q, maxm, eos_coef, w_ce,
+                       d_class_logits);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

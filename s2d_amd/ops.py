@@ -353,8 +353,9 @@ def target_nonempty(tgt, count):
 
 
 def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dims, P, oversample=3.0, importance=0.75,
-               coords_over=None, coords_rand=None, seed=0, drop_empty=True, world_size=1.0):
-    """-> losses [NL,2] (loss_mask, loss_dice)"""
+               coords_over=None, coords_rand=None, seed=0, drop_empty=True, world_size=1.0, keep=False):
+    """-> losses [NL,2] (loss_mask, loss_dice); keep=True: also the context point_loss_backward needs (the arguments and the
+    workspace with the selection state the forward found)"""
     _chk(mask_logits); _chk(tgt, torch.uint8); _chk(coords_over); _chk(coords_rand)
     for t in (tgt_count, nonempty, idx_q, idx_t, n_match):
         _chk(t, torch.int32)
@@ -364,10 +365,29 @@ def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dim
     nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm, int(P), float(oversample), float(importance))
     ws = torch.empty((nbytes,), device=tgt.device, dtype=torch.uint8)
     losses = torch.zeros((NL, 2), device=tgt.device, dtype=torch.float32)
-    lib().call("s2d_point_loss_f32", mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand,
-               int(seed), NL, B, Q, mask_logits.shape[-1], T, hm, wm, H, W, Nmax, int(P), float(oversample), float(importance),
-               int(drop_empty), float(world_size), ws, losses, _stream())
-    return losses
+    args = (mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand, int(seed), NL, B, Q,
+            mask_logits.shape[-1], T, hm, wm, H, W, Nmax, int(P), float(oversample), float(importance), int(drop_empty), float(world_size), ws)
+    lib().call("s2d_point_loss_f32", *args, losses, _stream())
+    return (losses, args) if keep else losses
+
+
+def point_loss_backward(ctx, w_mask, w_dice):
+    """ctx from point_loss(keep=True) -> grad rows [NL*B*maxm*T, hm*wm]: d(w_mask*loss_mask + w_dice*loss_dice, summed over
+    layers) / d(the matched query's logit map of that (layer, clip, slot, frame))"""
+    NL, B, Q, T, hm, wm, Nmax = ctx[10], ctx[11], ctx[12], ctx[14], ctx[15], ctx[16], ctx[19]
+    rows = NL * B * min(Q, Nmax) * T
+    g = torch.empty((rows, hm * wm), device=ctx[0].device, dtype=torch.float32)
+    lib().call("s2d_point_loss_backward_f32", *ctx, float(w_mask), float(w_dice), g, _stream())
+    return g
+
+
+def class_loss_backward(class_logits, idx_q, n_match, w_ce, eos_coef=0.1):
+    """d(w_ce * loss_ce)/d(class_logits [B,Q,2])"""
+    _chk(class_logits); _chk(idx_q, torch.int32); _chk(n_match, torch.int32)
+    B, Q, _ = class_logits.shape
+    out = torch.empty_like(class_logits)
+    lib().call("s2d_class_loss_backward_f32", class_logits, idx_q, n_match, B, Q, idx_q.shape[-1], float(eos_coef), float(w_ce), out, _stream())
+    return out
 
 
 def class_loss(class_logits, idx_q, n_match, eos_coef=0.1):

@@ -350,3 +350,74 @@ def test_masked_attention_backward_vs_autograd(B, Q, K, masked):
     assert rel(dq.cpu().numpy(), qd.grad.numpy()) < 2e-5
     assert rel(dk.cpu().numpy(), kd.grad.numpy()) < 2e-5
     assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 2e-5
+
+
+def test_point_and_class_loss_backward_vs_autograd():
+    """loss_masks (criterion.py:292-356: uncertainty top-k of 3P points + P/4 uniform, BCE mean + dice) and loss_labels
+    (:227-251) differentiated: HIP gradients vs float64 autograd through torch restatements on the same injected points"""
+    import torch.nn.functional as F
+    from s2d_amd import ops
+    from s2d_amd.utils import synth
+    from tests.test_gpu_criterion import make_targets, pad_targets, pixel_major, _dev
+    P, H, W = 256, 64, 96
+    B, Q, T, h, w = 2, 16, 2, H // 4, W // 4
+    ns, seed = [3, 2], 346
+    masks = synth.smooth_logits(seed, 2, (B, Q, T), (h, w))                        # [B][Q,T,h,w]
+    tg = make_targets(seed, 100, ns, T, H, W)
+    Nmax = max(ns)
+    tgt, cnt = pad_targets(tg, Nmax, T, H, W)
+    maxm = min(Q, Nmax)
+    rng = np.random.default_rng(seed)
+    iq = np.zeros((B, maxm), np.int32); it = np.zeros((B, maxm), np.int32); nm = np.array(ns, np.int32)
+    indices = []
+    for b in range(B):
+        qi = np.sort(rng.choice(Q, ns[b], replace=False)); tj = rng.permutation(ns[b])
+        iq[b, :ns[b]], it[b, :ns[b]] = qi, tj
+        indices.append((qi, tj))
+    rows = [(b, s, t) for b in range(B) for s in range(ns[b]) for t in range(T)]
+    kept = [r for r in rows if tg[r[0]][indices[r[0]][1][r[1]], r[2]].any()]
+    R = len(kept)
+    n_unc, n_rand = int(0.75 * P), P - int(0.75 * P)
+    cov = rng.random((R, 3 * P, 2), dtype=np.float32); crd = rng.random((R, n_rand, 2), dtype=np.float32)
+    rows_l = B * maxm * T
+    cover = np.zeros((1, rows_l, 3 * P, 2), np.float32); cover[0, :R] = cov
+    crand = np.zeros((1, rows_l, n_rand, 2), np.float32); crand[0, :R] = crd
+    tgt_d, cnt_d = _dev(tgt), _dev(cnt)
+    ne = ops.target_nonempty(tgt_d, cnt_d)
+    wm_, wd_ = 5.0, 2.5
+    L, ctx = ops.point_loss(_dev(pixel_major(masks)[None]), tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P,
+                            coords_over=_dev(cover), coords_rand=_dev(crand), keep=True)
+    g = ops.point_loss_backward(ctx, wm_, wd_).cpu().numpy().reshape(B, maxm, T, h, w)
+    # torch restatement on the kept rows
+    src = torch.tensor(np.stack([masks[b][indices[b][0][s], t] for (b, s, t) in kept]), dtype=torch.float64, requires_grad=True)   # [R,h,w]
+    tt = torch.tensor(np.stack([tg[b][indices[b][1][s], t] for (b, s, t) in kept]).astype(np.float64))                            # [R,H,W]
+    ps = lambda inp, c: F.grid_sample(inp[:, None], 2.0 * c[:, :, None, :] - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False)[:, 0, :, 0]
+    cov_t, crd_t = torch.tensor(cov, dtype=torch.float64), torch.tensor(crd, dtype=torch.float64)
+    with torch.no_grad():
+        unc = -ps(src, cov_t).abs()
+        idx = unc.topk(n_unc, dim=1)[1]
+        coords = torch.cat([torch.gather(cov_t, 1, idx[..., None].expand(-1, -1, 2)), crd_t], 1)
+        labels = ps(tt, coords)
+    lg = ps(src, coords)
+    num = max(float(sum(ns)), 1.0)
+    loss_mask = F.binary_cross_entropy_with_logits(lg, labels, reduction="none").mean(1).sum() / num
+    sg = lg.sigmoid()
+    loss_dice = (1 - (2 * (sg * labels).sum(-1) + 1) / (sg.sum(-1) + labels.sum(-1) + 1)).sum() / num
+    np.testing.assert_allclose(L.cpu().numpy()[0], [float(loss_mask), float(loss_dice)], rtol=1e-4)
+    (wm_ * loss_mask + wd_ * loss_dice).backward()
+    want = np.zeros((B, maxm, T, h, w))
+    for i, (b, s, t) in enumerate(kept):
+        want[b, s, t] = src.grad[i].numpy()
+    assert rel(g, want) < 2e-5
+    dropped = [r for r in rows if r not in kept]
+    assert all(not g[r].any() for r in dropped)                                   # DropLoss rows and unmatched slots: no gradient
+
+    # loss_labels
+    cl = torch.tensor(rng.normal(0, 1, (B, Q, 2)).astype(np.float32))
+    cd = cl.double().requires_grad_(True)
+    target = torch.ones((B, Q), dtype=torch.long)
+    for b in range(B):
+        target[b, indices[b][0]] = 0
+    (2.0 * F.cross_entropy(cd.transpose(1, 2), target, torch.tensor([1.0, 0.1], dtype=torch.float64))).backward()
+    dcl = ops.class_loss_backward(cl.to(DEV), _dev(iq), _dev(nm), 2.0)
+    assert rel(dcl.cpu().numpy(), cd.grad.numpy()) < 2e-6
