@@ -70,6 +70,25 @@ def weight_grad(dy, x, out=None, beta=0.0):
     return out
 
 
+def contract(a, bt):
+    """[M,N] = a[M,K] @ bt[N,K]^T over a LONG contraction K (pixels), small M, N: the K axis is cut into slices that run as the
+    batch of one NT GEMM, partials added in a fixed order (weight_grad without its transposes)"""
+    ops._chk(a); ops._chk(bt)
+    M, K = a.shape
+    N = bt.shape[0]
+    assert bt.shape[1] == K and K % 4 == 0
+    S, chunk = _slices(K, ((M + 127) // 128) * ((N + 127) // 128))
+    chunk = min(chunk, K)
+    while K % chunk:                      # equal slices without padding the operands: the largest divisor of K that is a multiple of 4
+        chunk -= 4
+    S = K // chunk
+    part = torch.empty((S, M, N), device=a.device, dtype=torch.float32)
+    lib().call("s2d_gemm_nt_f32", a, bt, part, M, N, chunk, K, K, N, S, chunk, chunk, M * N, None, None, None, N, 0, 0, 0, 0, None, _st())
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    lib().call("s2d_reduce_slices_f32", part, S, M * N, M * N, 0.0, out, _st())
+    return out
+
+
 def bias_grad(dy, out=None, beta=0.0):
     """db [N] = column sums of dy [M,N]"""
     ops._chk(dy)

@@ -58,15 +58,42 @@ class SelfAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
 
-    def forward(self, tgt, query_pos):  # forward_post :41-51;  tgt [B,Q,C], query_pos [Q,C]
+    def forward(self, tgt, query_pos, tape=None):  # forward_post :41-51;  tgt [B,Q,C], query_pos [Q,C]
         B, Q, C = tgt.shape
         W, bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         qk_in = ops.add_bcast(tgt, query_pos)
         qk = ops.gemm_nt(qk_in.view(-1, C), W[:2 * C], bias=bi[:2 * C]).view(B, Q, 2 * C)
         v = ops.gemm_nt(tgt.view(-1, C), W[2 * C:], bias=bi[2 * C:]).view(B, Q, C)
-        a = ops.masked_attn(qk[..., :C].contiguous(), qk[..., C:], v, H=self.nhead)        # k: a column slice, read in place
+        q = qk[..., :C].contiguous()
+        a = ops.masked_attn(q, qk[..., C:], v, H=self.nhead, want_lse=tape is not None)        # k: a column slice, read in place
+        lse = None
+        if tape is not None:
+            a, lse = a
         x = ops.gemm_nt(a.view(-1, C), self.self_attn.out_proj.weight, bias=self.self_attn.out_proj.bias, res=tgt.view(-1, C))
+        if tape is not None:
+            tape.append((self, tgt, qk_in, q, qk, v, a, lse, x))
         return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+    def backward(self, saved, d_out):
+        """-> (d_tgt [B,Q,C], d_query_pos [Q,C])"""
+        from .. import backward as Bk
+        _, tgt, qk_in, q, qk, v, a, lse, x = saved
+        B, Q, C = tgt.shape
+        m = self.self_attn
+        d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
+        Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
+        d2 = d_x.view(-1, C)
+        Bk.acc(m.out_proj.weight, Bk.weight_grad(d2, a.view(-1, C))); Bk.acc(m.out_proj.bias, Bk.bias_grad(d2))
+        d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
+        dq, dk, dv = Bk.masked_attn_backward(q, qk[..., C:], v, a, lse, d_a, H=self.nhead)
+        d_qk = torch.cat([dq, dk], -1).view(-1, 2 * C)
+        W = m.in_proj_weight
+        dW = torch.cat([Bk.weight_grad(d_qk, qk_in.view(-1, C)), Bk.weight_grad(dv.view(-1, C), tgt.view(-1, C))], 0)
+        Bk.acc(m.in_proj_weight, dW)
+        Bk.acc(m.in_proj_bias, torch.cat([Bk.bias_grad(d_qk), Bk.bias_grad(dv.view(-1, C))], 0))
+        d_in = Bk.input_grad(d_qk, W[:2 * C].detach().contiguous()).view(B, Q, C)                 # d(tgt + query_pos)
+        d_tgt = Bk.input_grad(dv.view(-1, C), W[2 * C:].detach().contiguous(), res=d2).view(B, Q, C) + d_in
+        return d_tgt, Bk.sum_slices(d_in)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -76,16 +103,41 @@ class CrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
 
-    def forward(self, tgt, k, v, bits, unmasked, query_pos):  # forward_post :99-111
+    def forward(self, tgt, k, v, bits, unmasked, query_pos, tape=None):  # forward_post :99-111
         """k, v [B,K,C]: the memory already through this layer's key / value projections (column slices of the per-level
         projections the decoder makes once for the three layers that read a level, `_project_memory`)."""
         B, Q, C = tgt.shape
         W, bi = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
-        q = ops.gemm_nt(ops.add_bcast(tgt, query_pos).view(-1, C), W[:C], bias=bi[:C]).view(B, Q, C)
-        a = ops.masked_attn(q, k, v, bits, unmasked, H=self.nhead)
+        q_in = ops.add_bcast(tgt, query_pos)
+        q = ops.gemm_nt(q_in.view(-1, C), W[:C], bias=bi[:C]).view(B, Q, C)
+        a = ops.masked_attn(q, k, v, bits, unmasked, H=self.nhead, want_lse=tape is not None)
+        lse = None
+        if tape is not None:
+            a, lse = a
         x = ops.gemm_nt(a.view(-1, C), self.multihead_attn.out_proj.weight, bias=self.multihead_attn.out_proj.bias,
                         res=tgt.view(-1, C))
+        if tape is not None:
+            tape.append((self, tgt, q_in, q, k, v, bits, unmasked, a, lse, x))
         return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+    def backward(self, saved, d_out):
+        """-> (d_tgt, d_query_pos [Q,C], d_k [B,K,C], d_v [B,K,C]); the in-projection's key / value rows get their gradients
+        from the decoder's batched memory projection (`_project_memory_backward`)"""
+        from .. import backward as Bk
+        _, tgt, q_in, q, k, v, bits, unmasked, a, lse, x = saved
+        B, Q, C = tgt.shape
+        m = self.multihead_attn
+        d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
+        Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
+        d2 = d_x.view(-1, C)
+        Bk.acc(m.out_proj.weight, Bk.weight_grad(d2, a.view(-1, C))); Bk.acc(m.out_proj.bias, Bk.bias_grad(d2))
+        d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
+        dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead)
+        dq2 = dq.view(-1, C)
+        Wq = m.in_proj_weight[:C].detach().contiguous()
+        self._dWq, self._dbq = Bk.weight_grad(dq2, q_in.view(-1, C)), Bk.bias_grad(dq2)            # merged with the k / v rows later
+        d_in = Bk.input_grad(dq2, Wq).view(B, Q, C)
+        return d_in + d_x, Bk.sum_slices(d_in), dk, dv
 
 
 class FFNLayer(nn.Module):
@@ -98,11 +150,25 @@ class FFNLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt):  # forward_post :164-168
+    def forward(self, tgt, tape=None):  # forward_post :164-168
         B, Q, C = tgt.shape
         h = ops.gemm_nt(tgt.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
         x = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=tgt.view(-1, C))
+        if tape is not None:
+            tape.append((self, tgt, h, x))
         return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
+
+    def backward(self, saved, d_out):
+        from .. import backward as Bk
+        _, tgt, h, x = saved
+        B, Q, C = tgt.shape
+        d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
+        Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
+        d2 = d_x.view(-1, C)
+        Bk.acc(self.linear2.weight, Bk.weight_grad(d2, h)); Bk.acc(self.linear2.bias, Bk.bias_grad(d2))
+        d_h = Bk.relu_scale_backward(Bk.input_grad(d2, self.linear2.weight), h)
+        Bk.acc(self.linear1.weight, Bk.weight_grad(d_h, tgt.view(-1, C))); Bk.acc(self.linear1.bias, Bk.bias_grad(d_h))
+        return Bk.input_grad(d_h, self.linear1.weight, res=d2).view(B, Q, C)
 
 
 class MLP(nn.Module):
@@ -111,10 +177,24 @@ class MLP(nn.Module):
         h = [hidden_dim] * (num_layers - 1)
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
-    def forward(self, x):
+    def forward(self, x, tape=None):
+        acts = [x]
         for i, l in enumerate(self.layers):
             x = ops.gemm_nt(x, l.weight, bias=l.bias, relu=i < len(self.layers) - 1)
+            acts.append(x)
+        if tape is not None:
+            tape.append(acts)
         return x
+
+    def backward(self, acts, d):
+        from .. import backward as Bk
+        for i in reversed(range(len(self.layers))):
+            l = self.layers[i]
+            if i < len(self.layers) - 1:
+                d = Bk.relu_scale_backward(d, acts[i + 1])
+            Bk.acc(l.weight, Bk.weight_grad(d, acts[i])); Bk.acc(l.bias, Bk.bias_grad(d))
+            d = Bk.input_grad(d, l.weight)
+        return d
 
 
 class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
@@ -176,22 +256,58 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             self._kv_cache = (key, packs)
         return self._kv_cache[1]
 
-    def _project_memory(self, multi_scale, B, T, posl):
+    def _project_memory(self, multi_scale, B, T, posl, tape=None):
         """keys and values of every layer, per level [B, T*h*w, n*C] (layer i reads columns (i // 3)*C .. of level i % 3).
         K_i = (src + level_embed + pos) . Wk_i^T + bk_i as the reference forms it (:386-394, nn.MultiheadAttention);
         V_i = (src + level_embed) . Wv_i^T + bv_i = src . Wv_i^T + (level_embed . Wv_i^T + bv_i): the bracket is one row
         per level and layer, so src + level_embed is never stored."""
         C = self.hidden_dim
-        ks, vs = [], []
+        ks, vs, kins, xs = [], [], [], []
         for lvl, ((tok, (h, w)), (wk, bk, wv, bv)) in enumerate(zip(multi_scale, self._kv_packed())):
             x = tok.view(B, T * h * w, C)
             kin = ops.add_bcast(x, posl[lvl])                                               # src + level_embed + pos
             ks.append(ops.gemm_nt(kin.view(-1, C), wk, bias=bk).view(B, T * h * w, -1))
             bvf = ops.gemm_nt(self.level_embed.weight[lvl:lvl + 1].detach().contiguous(), wv, bias=bv).view(-1)
             vs.append(ops.gemm_nt(x.reshape(-1, C), wv, bias=bvf).view(B, T * h * w, -1))
+            kins.append(kin); xs.append(x)
+        if tape is not None:
+            tape.append((kins, xs))
         return ks, vs
 
-    def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm, ml_slot=None, mf_taps=None):
+    def _project_memory_backward(self, saved, d_ks, d_vs):
+        """d_ks / d_vs: per level [B, K, n*C] (zeros where a layer sent nothing).  Accumulates the key / value rows of every
+        cross-attention in-projection (together with the query rows the layers left in _dWq / _dbq) and level_embed;
+        returns the gradient of the three memory levels [B*T, h*w, C]."""
+        from .. import backward as Bk
+        kins, xs = saved
+        C = self.hidden_dim
+        packs = self._kv_packed()
+        d_mem, d_le = [], []
+        per_layer = {}
+        for lvl in range(3):
+            wk, bk, wv, bv = packs[lvl]
+            dk2, dv2 = d_ks[lvl].view(-1, d_ks[lvl].shape[-1]), d_vs[lvl].view(-1, d_vs[lvl].shape[-1])
+            kin2, x2 = kins[lvl].view(-1, C), xs[lvl].reshape(-1, C)
+            le = self.level_embed.weight[lvl:lvl + 1].detach().contiguous()
+            dWk, dbk = Bk.weight_grad(dk2, kin2), Bk.bias_grad(dk2)
+            dbv = Bk.bias_grad(dv2)                                                # also d(level_embed . Wv^T + bv)
+            dWv = Bk.weight_grad(dv2, x2) + dbv[:, None] * le                      # + outer(d bracket, level_embed)
+            d_kin = Bk.input_grad(dk2, wk)
+            d_x = Bk.input_grad(dv2, wv, res=d_kin)                                # memory enters keys and values
+            d_le.append(Bk.bias_grad(d_kin) + Bk.input_grad(dbv[None].contiguous(), wv).view(-1))
+            d_mem.append(d_x)
+            layers = [i for i in range(self.num_layers) if i % 3 == lvl]
+            for j, i in enumerate(layers):
+                per_layer[i] = (dWk[j * C:(j + 1) * C], dbk[j * C:(j + 1) * C], dWv[j * C:(j + 1) * C], dbv[j * C:(j + 1) * C])
+        for i, layer in enumerate(self.transformer_cross_attention_layers):
+            dWk, dbk, dWv, dbv = per_layer[i]
+            Bk.acc(layer.multihead_attn.in_proj_weight, torch.cat([layer._dWq, dWk, dWv], 0))
+            Bk.acc(layer.multihead_attn.in_proj_bias, torch.cat([layer._dbq, dbk, dbv], 0))
+            layer._dWq = layer._dbq = None
+        Bk.acc(self.level_embed.weight, torch.stack(d_le, 0))
+        return d_mem
+
+    def _heads(self, layer_slot, output, mf, out_cls, out_ml, target_hw, B, T, hm, wm, ml_slot=None, mf_taps=None, tape=None):
         """forward_prediction_heads :448-467 for all clips; writes slot `layer_slot` of the class buffer and slot `ml_slot`
         of the mask-logit buffer, and returns the attention-mask bits for the next layer.  With `mf_taps` (the mask
         features gathered at the four bilinear source pixels of every key of the next level) only those logits are
@@ -199,7 +315,10 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         Q, C = self.num_queries, self.hidden_dim
         d = ops.layernorm(output, self.decoder_norm.weight, self.decoder_norm.bias).view(-1, C)
         ops.gemm_nt(d, self.class_embed.weight, bias=self.class_embed.bias, out=out_cls[layer_slot].view(B * Q, -1))
-        e = self.mask_embed(d).view(B, Q, -1)
+        mlp_tape = [] if tape is not None else None
+        e = self.mask_embed(d, mlp_tape).view(B, Q, -1)
+        if tape is not None:
+            tape.append((layer_slot, output, d, mlp_tape[0], e))
         if mf_taps is not None:
             sub = ops.gemm_nt(mf_taps, e)                                  # [B, K*4, Q]
             return ops.attn_mask_bits(sub, B, Q, T, hm, wm, target_hw[0], target_hw[1], compact=True)
@@ -210,7 +329,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         return ops.attn_mask_bits(out_ml[layer_slot if ml_slot is None else ml_slot], B, Q, T, hm, wm, target_hw[0], target_hw[1])
 
     @torch.no_grad()
-    def forward(self, multi_scale, mask_features, training=True, aux_masks=True):
+    def forward(self, multi_scale, mask_features, training=True, aux_masks=True, tape=None):
         """multi_scale: 3 x (tokens [BT,h*w,C], (h,w)) from the pixel decoder (res5, res4, res3 scale);
         mask_features [BT,hm,wm,C] NHWC.  Returns MaskOutputs.
         aux_masks=False (a frozen network whose intermediate predictions are not supervised: the teacher): the mask logits
@@ -223,7 +342,9 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         dev = mask_features.device
         sizes = [s for _, s in multi_scale]
         posl = self._pos(T, sizes, dev)
-        ks, vs = self._project_memory(multi_scale, B, T, posl)
+        mem_tape = [] if tape is not None else None
+        ks, vs = self._project_memory(multi_scale, B, T, posl, mem_tape)
+        head_tape, layer_tape = ([], []) if tape is not None else (None, None)
         mf = mask_features.view(B, T * hm * wm, C)
         ldq = (Q + 3) // 4 * 4
         # slot s (the prediction after layer s-1) feeds the attention mask of layer s at level s % 3; a level whose keys
@@ -249,17 +370,80 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         def heads(s, out):
             if sparse(s):
                 return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, mf_taps=taps[s % 3])
-            return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, ml_slot=full.index(s))
+            return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, ml_slot=full.index(s), tape=head_tape)
 
         bits, unm = heads(0, output)
         for i in range(self.num_layers):
             lvl = i % 3
             c0 = (i // 3) * C
-            output = self.transformer_cross_attention_layers[i](output, ks[lvl][..., c0:c0 + C], vs[lvl][..., c0:c0 + C], bits, unm, qe)
-            output = self.transformer_self_attention_layers[i](output, qe)
-            output = self.transformer_ffn_layers[i](output)
+            output = self.transformer_cross_attention_layers[i](output, ks[lvl][..., c0:c0 + C], vs[lvl][..., c0:c0 + C], bits, unm, qe,
+                                                                layer_tape)
+            output = self.transformer_self_attention_layers[i](output, qe, layer_tape)
+            output = self.transformer_ffn_layers[i](output, layer_tape)
             bits, unm = heads(i + 1, output)
+        if tape is not None:
+            assert aux_masks, "the backward needs every layer's full mask prediction (the supervised network)"
+            tape.append((self, mem_tape[0], head_tape, layer_tape, mf, [k.shape for k in ks], (B, T, hm, wm)))
         return MaskOutputs(out_cls, out_ml, Q, T, hm, wm)
+
+    @torch.no_grad()
+    def backward(self, saved, d_cls, mask_sources):
+        """Gradients of forward (video_mask2former_transformer_decoder.py:374-467 backwards).
+        d_cls [NL,B,Q,K+1] or None: d(loss)/d(class logits); mask_sources: list of (rows [NL,B,maxm,T*hm*wm], idx_q [NL*B,maxm])
+        -- d(loss)/d(mask logit map) of the matched queries of one criterion pass (ops.point_loss_backward) and the query
+        each row belongs to; unmatched slots hold zero rows.  The attention masks are constants (detached, :465).
+        Returns (d_mask_features [B*T,hm,wm,C], [d_memory level 0..2 [B*T, h*w, C]]); parameter gradients go to .grad."""
+        from .. import backward as Bk
+        _, mem_saved, head_tape, layer_tape, mf, kshapes, (B, T, hm, wm) = saved
+        Q, C = self.num_queries, self.hidden_dim
+        NL = self.num_layers + 1
+        dev = mf.device
+        npix = T * hm * wm
+        mft = [Bk.transpose(mf[b]) for b in range(B)]                               # [C, npix] per clip
+        d_mf = [None] * B
+        d_ks = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
+        d_vs = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
+        d_qe = torch.zeros((Q, C), device=dev, dtype=torch.float32)
+
+        def heads_backward(rec):
+            slot, output, d, mlp_acts, e = rec
+            d_e = torch.zeros((B, Q, e.shape[-1]), device=dev, dtype=torch.float32)
+            for rows, idx_q in mask_sources:
+                maxm = rows.shape[2]
+                mp = (maxm + 3) // 4 * 4
+                for b in range(B):
+                    D = rows[slot, b]                                               # [maxm, npix]
+                    iq = idx_q[slot * B + b].long()
+                    d_e[b].index_add_(0, iq, Bk.contract(D, mft[b]))               # sum_pix D[q,pix] mf[pix,:]
+                    Dt = Bk.transpose(D, None)                                      # [npix, maxm]
+                    if mp != maxm:
+                        Dt = torch.nn.functional.pad(Dt, (0, mp - maxm))
+                    et = torch.zeros((e.shape[-1], mp), device=dev, dtype=torch.float32)
+                    et[:, :maxm] = e[b][iq].t()
+                    d_mf[b] = ops.gemm_nt(Dt, et, res=d_mf[b])                      # += D^T . e_sel
+            d_d = self.mask_embed.backward(mlp_acts, d_e.view(B * Q, -1))
+            if d_cls is not None:
+                dc = d_cls[slot].reshape(B * Q, -1).contiguous()
+                Bk.acc(self.class_embed.weight, Bk.weight_grad(dc, d)); Bk.acc(self.class_embed.bias, Bk.bias_grad(dc))
+                d_d = Bk.input_grad(dc, self.class_embed.weight, res=d_d)
+            d_out, dg, db = Bk.layernorm_backward(output, d_d.view(B, Q, C), self.decoder_norm.weight)
+            Bk.acc(self.decoder_norm.weight, dg); Bk.acc(self.decoder_norm.bias, db)
+            return d_out
+
+        d_output = heads_backward(head_tape[NL - 1])
+        for i in reversed(range(self.num_layers)):
+            lvl, c0 = i % 3, (i // 3) * C
+            d_output = self.transformer_ffn_layers[i].backward(layer_tape[3 * i + 2], d_output)
+            d_output, dq1 = self.transformer_self_attention_layers[i].backward(layer_tape[3 * i + 1], d_output)
+            d_output, dq2, dk, dv = self.transformer_cross_attention_layers[i].backward(layer_tape[3 * i], d_output)
+            d_qe += dq1 + dq2
+            d_ks[lvl][..., c0:c0 + C] = dk
+            d_vs[lvl][..., c0:c0 + C] = dv
+            d_output = d_output + heads_backward(head_tape[i])
+        Bk.acc(self.query_embed.weight, d_qe)
+        Bk.acc(self.query_feat.weight, Bk.sum_slices(d_output.contiguous()))
+        d_mem = self._project_memory_backward(mem_saved, d_ks, d_vs)
+        return torch.stack(d_mf, 0).view(B * T, hm, wm, C), d_mem
 
     def _tap_index(self, T, hm, wm, size, device):
         key = (T, hm, wm, tuple(size), device)

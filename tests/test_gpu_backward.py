@@ -421,3 +421,114 @@ def test_point_and_class_loss_backward_vs_autograd():
     (2.0 * F.cross_entropy(cd.transpose(1, 2), target, torch.tensor([1.0, 0.1], dtype=torch.float64))).backward()
     dcl = ops.class_loss_backward(cl.to(DEV), _dev(iq), _dev(nm), 2.0)
     assert rel(dcl.cpu().numpy(), cd.grad.numpy()) < 2e-6
+
+
+def test_video_decoder_backward_vs_autograd():
+    """VideoMultiScaleMaskedTransformerDecoder.backward (3 layers, one per memory level; masked cross-attention with the
+    forward's own detached masks, self-attention, FFN, class / mask heads incl. the mask-logit einsum, batched key / value
+    projections, query and level embeddings) against autograd through a float64 torch restatement of
+    video_mask2former_transformer_decoder.py:374-467"""
+    import torch.nn.functional as F
+    from s2d_amd.modeling import VideoMultiScaleMaskedTransformerDecoder
+    torch.manual_seed(0)
+    B, T, Q, C, H8 = 2, 2, 12, 256, 8
+    hm, wm = 16, 24
+    sizes = [(2, 3), (4, 6), (8, 12)]
+    dec = VideoMultiScaleMaskedTransformerDecoder(num_queries=Q, num_frames=T, dec_layers=3)
+    with torch.no_grad():
+        for n_, p in dec.named_parameters():
+            if p.abs().max() == 0:
+                p.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(2)
+    toks = [torch.randn((B * T, h * w, C), generator=g) for h, w in sizes]
+    mf = torch.randn((B * T, hm, wm, C), generator=g) * 0.3
+    NL, npix, maxm = 4, T * hm * wm, 3
+    rows = torch.randn((NL, B, maxm, npix), generator=g) * 0.01
+    rows[:, :, 2] = 0                                                      # an unmatched slot: zero row
+    idx_q = torch.stack([torch.randperm(Q, generator=g)[:maxm] for _ in range(NL * B)]).int()
+    d_cls = torch.randn((NL, B, Q, 2), generator=g) * 0.1
+
+    dec = dec.to(DEV)
+    tape = []
+    out = dec([(t.to(DEV), s_) for t, s_ in zip(toks, sizes)], mf.to(DEV), training=True, aux_masks=True, tape=tape)
+    d_mf, d_mem = dec.backward(tape[0], d_cls.to(DEV), [(rows.to(DEV), idx_q.to(DEV))])
+
+    # ---- torch restatement (float64), masks taken from the HIP forward (they are detached constants)
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.named_parameters()}
+    tk = [t.double().requires_grad_(True) for t in toks]
+    mfd = mf.double().requires_grad_(True)
+    posl = [p.cpu().double() for p in dec._pos(T, sizes, torch.device(DEV))]
+    le0 = dec.level_embed.weight.detach().cpu().double()
+    layer_tape = tape[0][3]
+
+    def bits_to_mask(bits, unm, K):
+        w = bits.cpu().numpy().view(np.uint32)                               # [B,K,4]
+        m = np.zeros((B, Q, K), bool)
+        for q in range(Q):
+            m[:, q, :] = (w[:, :, q >> 5] >> np.uint32(q & 31)) & 1
+        m[m.all(-1)] = False
+        return torch.from_numpy(m)
+
+    def attn(q, k, v, mask=None):
+        Bq, Qn, _ = q.shape
+        Kn = k.shape[1]
+        sc = torch.einsum("bqhd,bkhd->bhqk", q.view(Bq, Qn, H8, 32), k.view(Bq, Kn, H8, 32)) / 32 ** 0.5
+        if mask is not None:
+            sc = sc.masked_fill(mask[:, None], float("-inf"))
+        return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v.view(Bq, Kn, H8, 32)).reshape(Bq, Qn, C)
+
+    ln = lambda x, n: F.layer_norm(x, (C,), P[n + ".weight"], P[n + ".bias"])
+    lin = lambda x, n: F.linear(x, P[n + ".weight"], P[n + ".bias"])
+    mem = []
+    for lvl, (h, w) in enumerate(sizes):
+        x = tk[lvl].reshape(B, T * h * w, C)
+        le = P["level_embed.weight"][lvl]
+        mem.append((x + (posl[lvl] - le0[lvl]) + le, x + le))
+    output = P["query_feat.weight"][None].repeat(B, 1, 1)
+    qe = P["query_embed.weight"]
+    mfl = mfd.reshape(B, npix, C)
+    loss = 0.0
+
+    def heads(slot, o):
+        d = ln(o, "decoder_norm")
+        cls = lin(d, "class_embed")
+        e = d
+        for i in range(3):
+            e = lin(e, f"mask_embed.layers.{i}")
+            if i < 2:
+                e = torch.relu(e)
+        ml = torch.einsum("bpc,bqc->bpq", mfl, e)
+        l = (cls * d_cls[slot].double()).sum()
+        for b in range(B):
+            sel = ml[b][:, idx_q[slot * B + b].long()]                       # [npix, maxm]
+            l = l + (sel * rows[slot, b].double().t()).sum()
+        return l
+
+    loss = loss + heads(0, output)
+    for i in range(3):
+        pre = f"transformer_cross_attention_layers.{i}."
+        W, bi = P[pre + "multihead_attn.in_proj_weight"], P[pre + "multihead_attn.in_proj_bias"]
+        kin, vin = mem[i % 3]
+        mask = bits_to_mask(layer_tape[3 * i][6], layer_tape[3 * i][7], kin.shape[1])
+        a = attn(F.linear(output + qe, W[:C], bi[:C]), F.linear(kin, W[C:2 * C], bi[C:2 * C]), F.linear(vin, W[2 * C:], bi[2 * C:]), mask)
+        output = ln(lin(a, pre + "multihead_attn.out_proj") + output, pre + "norm")
+        pre = f"transformer_self_attention_layers.{i}."
+        W, bi = P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"]
+        qk = output + qe
+        a = attn(F.linear(qk, W[:C], bi[:C]), F.linear(qk, W[C:2 * C], bi[C:2 * C]), F.linear(output, W[2 * C:], bi[2 * C:]))
+        output = ln(lin(a, pre + "self_attn.out_proj") + output, pre + "norm")
+        pre = f"transformer_ffn_layers.{i}."
+        output = ln(lin(torch.relu(lin(output, pre + "linear1")), pre + "linear2") + output, pre + "norm")
+        loss = loss + heads(i + 1, output)
+    loss.backward()
+
+    assert rel(d_mf.cpu().numpy(), mfd.grad.numpy()) < 5e-5
+    for lvl in range(3):
+        assert rel(d_mem[lvl].view(B * T, -1, C).cpu().numpy(), tk[lvl].grad.numpy()) < 5e-5, lvl
+    bad = {}
+    for k, p in dec.named_parameters():
+        assert p.grad is not None, k
+        r = rel(p.grad.cpu().numpy(), P[k].grad.numpy())
+        if r > 1e-4:
+            bad[k] = r
+    assert not bad, bad
