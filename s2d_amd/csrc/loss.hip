@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void select_kernel(LossParams p)
     }
     __syncthreads();
     unsigned int before = csum[threadIdx.x];
+    if (k == 0 && LEVEL == 0 && threadIdx.x == 0) { p.prefix[rowid] = 0u; p.krem[rowid] = 0; }   // importance ratio 0: nothing to select
     for (int j = 0; j < per; ++j) {
         if (before < (unsigned)k && before + loc[j] >= (unsigned)k) {
             const unsigned int bin = threadIdx.x * per + j;

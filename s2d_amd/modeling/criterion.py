@@ -110,14 +110,15 @@ class VideoSetCriterion(nn.Module):
         self.seed = 0
 
     @torch.no_grad()
-    def forward(self, outputs, targets, distillation=False, coords=None):
+    def forward(self, outputs, targets, distillation=False, coords=None, keep_ctx=False):
         """-> {'loss_ce','loss_mask','loss_dice','loss_mask_i','loss_dice_i' (i = 0..NL-2)} of 0-dim tensors.
         coords (parity mode) = dict(matcher=[NL,B,P,2], over=[NL,R,3P,2], rand=[NL,R,P/4,2])."""
         out = _to_mask_outputs(outputs)
         ts = targets if isinstance(targets, TargetSet) else TargetSet.from_list([t["masks"] for t in targets], device=out.mask_logits.device)
         NL, B = out.mask_logits.shape[:2]
         c = coords or {}
-        iq, it, nm = self.matcher.match_all(out, ts, c.get("matcher"))
+        # "indices" (tests only): a fixed assignment instead of the matcher's, e.g. to difference the loss at constant matching
+        iq, it, nm = c["indices"] if "indices" in c else self.matcher.match_all(out, ts, c.get("matcher"))
         # DropLoss strategy: the last layer uses (distillation ? distillation_loss_strategy : loss_strategy); aux layers
         # always loss_strategy (criterion.py:307-308, :423).  Both are "masks-only" in every shipped config.
         drop_last = (self.distillation_loss_strategy if distillation else self.loss_strategy) == "masks-only"
@@ -126,10 +127,16 @@ class VideoSetCriterion(nn.Module):
         kw = dict(oversample=self.oversample_ratio, importance=self.importance_sample_ratio, coords_over=c.get("over"),
                   coords_rand=c.get("rand"), seed=self.seed, world_size=float(self.world_size))
         losses = {}
+        self.last_ctx = None
         if drop_last == drop_aux:
             L = ops.point_loss(out.mask_logits, ts.masks, ts.count, ts.nonempty, iq, it, nm, out.dims, self.num_points,
-                               drop_empty=drop_aux, **kw)
+                               drop_empty=drop_aux, keep=keep_ctx, **kw)
+            if keep_ctx:                                   # what the backward needs: selection state + the assignment
+                L, pl_ctx = L
+                self.last_ctx = dict(point_loss=pl_ctx, idx_q=iq, n_match=nm, maxm=iq.shape[-1])
         else:  # mixed strategies: two launches over the same buffers
+            if keep_ctx:
+                raise NotImplementedError("backward with different DropLoss strategies for the last and the auxiliary layers")
             L = ops.point_loss(out.mask_logits, ts.masks, ts.count, ts.nonempty, iq, it, nm, out.dims, self.num_points,
                                drop_empty=drop_aux, **kw)
             L2 = ops.point_loss(out.mask_logits, ts.masks, ts.count, ts.nonempty, iq, it, nm, out.dims, self.num_points,

@@ -201,6 +201,55 @@ class KDVideoMaskFormer(nn.Module):
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
         return out
 
+    @torch.no_grad()
+    def forward_backward(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None):
+        """One training iteration's device work up to the optimizer (engine/train_loop.py:709-726: forward, sum of the
+        weighted losses, backward): returns the weighted loss dict of forward_losses and leaves d(sum of losses)/d(parameter)
+        in .grad of every student parameter (accumulating, like autograd).  Every gradient is computed by the HIP kernels of
+        s2d_amd/backward.py through explicit tapes of the student's activations; the teacher and both matchers carry no
+        gradient, attention masks and sampled points are constants, as in the reference."""
+        wd = self.criterion.weight_dict
+        Hp, Wp = images.shape[1:3]
+        kd_nmax = kd_nmax or self.num_queries
+        backbone, head = self.student[0], self.student[1]
+        tb, tp, td = [], [], []
+        feats = backbone(images, tb)
+        mf, ms = head.pixel_decoder.forward_features(feats, tp)
+        student = head.predictor(ms, mf, True, True, td)
+        teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
+        tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                            self.score_threshold_distillation, self.num_predictions_distillation)
+        losses = self.criterion(student, gt_targets, False, coords_gt, keep_ctx=True)
+        ctx_gt = self.criterion.last_ctx
+        kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd, keep_ctx=True)
+        ctx_kd = self.criterion.last_ctx
+        for k, v in kd.items():
+            losses[k.replace("loss_", "kd_loss_")] = v
+        out = {k: v * wd[k] for k, v in losses.items() if k in wd}
+        # ---- backward
+        NL, B = student.class_logits.shape[:2]
+        Q, T, hm, wm = student.dims
+        d_cls = torch.zeros_like(student.class_logits)
+        sources = []
+        for ctx, pre in ((ctx_gt, ""), (ctx_kd, "kd_")):
+            w_mask, w_dice = wd.get(pre + "loss_mask", 0.0), wd.get(pre + "loss_dice", 0.0)
+            for i in range(NL - 1):
+                if wd.get(pre + f"loss_mask_{i}", w_mask) != w_mask or wd.get(pre + f"loss_dice_{i}", w_dice) != w_dice:
+                    raise NotImplementedError("per-layer loss weights that differ between decoder layers")
+            if w_mask != 0.0 or w_dice != 0.0:
+                rows = ops.point_loss_backward(ctx["point_loss"], w_mask, w_dice).view(NL, B, ctx["maxm"], T * hm * wm)
+                sources.append((rows, ctx["idx_q"]))
+            w_ce = wd.get(pre + "loss_ce", 0.0)
+            if w_ce != 0.0:
+                d_cls[NL - 1] += ops.class_loss_backward(student.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),
+                                                         ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce, self.criterion.eos_coef)
+        d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
+        grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
+        backbone.backward(tb, grads)
+        self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
+        self.last_tapes = (tb, tp, td)
+        return out
+
     def forward(self, batched_inputs):
         images = self.preprocess(batched_inputs)
         if not self.training:

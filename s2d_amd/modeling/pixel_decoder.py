@@ -313,7 +313,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         # encoder output tokens: the decoder's gradient per level (+ the FPN's into the finest level)
         parts = []
         for i, (h, w) in enumerate(shapes):
-            g = d_outs[i] if d_outs[i] is not None else torch.zeros((N, h * w, C), device=d_mf.device, dtype=torch.float32)
+            g = d_outs[i].reshape(N, h * w, C) if d_outs[i] is not None else torch.zeros((N, h * w, C), device=d_mf.device, dtype=torch.float32)
             if i == len(shapes) - 1:
                 g = g + d_up.view(N, h * w, C)
             parts.append(g)

@@ -372,9 +372,14 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
                 return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, mf_taps=taps[s % 3])
             return self._heads(s, out, mf, out_cls, out_ml, target(s), B, T, hm, wm, ml_slot=full.index(s), tape=head_tape)
 
+        # tests only: attention masks held fixed (they are detached, piecewise-constant functions of the parameters; a finite
+        # difference of the loss has to keep them constant to see the derivative the backward computes)
+        fixed = getattr(self, "_fixed_masks", None)
         bits, unm = heads(0, output)
         for i in range(self.num_layers):
             lvl = i % 3
+            if fixed is not None:
+                bits, unm = fixed[i]
             c0 = (i // 3) * C
             output = self.transformer_cross_attention_layers[i](output, ks[lvl][..., c0:c0 + C], vs[lvl][..., c0:c0 + C], bits, unm, qe,
                                                                 layer_tape)

@@ -532,3 +532,69 @@ def test_video_decoder_backward_vs_autograd():
         if r > 1e-4:
             bad[k] = r
     assert not bad, bad
+
+
+def test_whole_model_gradient_directional_derivative():
+    """KDVideoMaskFormer.forward_backward: d(weighted loss sum)/d(ALL student parameters) -- backbone, pixel decoder, decoder,
+    through the matcher-assigned point losses of the GT and the KD pass -- against central finite differences of
+    forward_losses along random directions.  The loss is only piecewise smooth in the parameters (Hungarian assignment,
+    attention-mask bits, uncertainty top-k: all detached in the reference too), so the differences are taken with those held
+    at their base values: injected sample points, injected assignment, the forward's own attention masks, and
+    IMPORTANCE_SAMPLE_RATIO 0 (every sampled point uniform; the top-k path is covered by test_point_and_class_loss_...)."""
+    from s2d_amd import ops
+    from s2d_amd.modeling import TargetSet, build_kd_model
+    from tests.parity import make_case, make_coords, seeded_load
+    seed, B, T, H0, W0, Q, P, ns, NL = 5, 2, 2, 60, 90, 16, 256, (3, 4), 4
+    model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(2.0, 5.0, 5.0), dec_layers=NL)
+    seeded_load(model.student, seed); seeded_load(model.teacher, seed + 1)
+    model = model.to(DEV)
+    model.criterion.importance_sample_ratio = 0.0
+    frames, tg = make_case(seed, B, T, H0, W0, Q, P, ns)
+    images = ops.normalize_pad(torch.from_numpy(frames).to(DEV))
+    Hp, Wp = images.shape[1:3]
+    gts = []
+    for m, ids in tg:
+        pad = np.zeros((m.shape[0], T, Hp, Wp), np.uint8)
+        pad[:, :, :H0, :W0] = m
+        gts.append(torch.from_numpy(pad[(ids != -1).any(-1)]))
+    Ngt = max(max(g_.shape[0] for g_ in gts), 1)
+    to = lambda c: {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
+    cg, ck = to(make_coords(seed + 10, NL, B, Q, Ngt, T, P)), to(make_coords(seed + 11, NL, B, Q, Q, T, P))
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    for c in (cg, ck):
+        c["rand"] = torch.rand((NL, c["rand"].shape[1], P, 2), device=DEV, generator=gen)
+    gt = TargetSet.from_list(gts, device=DEV)
+
+    def total():
+        return float(sum(model.forward_losses(images, gt, cg, ck, kd_nmax=Q).values()))
+
+    named = [(n, p) for n, p in model.student.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
+    for p in params:
+        p.grad = None
+    out = model.forward_backward(images, gt, cg, ck, kd_nmax=Q)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    # freeze what is piecewise constant: attention masks (from the tape) and the two assignments
+    lt = model.last_tapes[2][0][3]
+    model.student[1].predictor._fixed_masks = [(lt[3 * i][6], lt[3 * i][7]) for i in range(NL - 1)]
+    st, te = model.last["student"], model.last["teacher"]
+    model.criterion(st, gt, False, cg); cg["indices"] = model.criterion.last_indices
+    kdt = ops.kd_targets(te.class_logits[-1], te.mask_logits[-1], te.dims, Hp, Wp, Q, 0.75, 100)
+    model.criterion(st, TargetSet(kdt[0], kdt[1], kdt[3]), True, ck); ck["indices"] = model.criterion.last_indices
+    base = total()
+    assert abs(float(sum(out.values())) - base) < 1e-4 * abs(base)
+    groups = {"backbone": lambda n: n.startswith("0."), "pixel decoder": lambda n: n.startswith("1.pixel_decoder"),
+              "decoder": lambda n: n.startswith("1.predictor"), "everything": lambda n: True}
+    for gname, sel in groups.items():
+        dirs = [torch.randn(p.shape, device=DEV, generator=gen) * (p.detach().abs().mean() + 1e-3) if sel(n) else torch.zeros_like(p)
+                for n, p in named]
+        ana = float(sum((p.grad * d).sum() for p, d in zip(params, dirs)))
+        eps = 5e-4
+        with torch.no_grad():
+            for p, d in zip(params, dirs): p.add_(d, alpha=eps)
+            lp = total()
+            for p, d in zip(params, dirs): p.add_(d, alpha=-2 * eps)
+            lm = total()
+            for p, d in zip(params, dirs): p.add_(d, alpha=eps)
+        num = (lp - lm) / (2 * eps)
+        assert abs(ana - num) < 0.03 * max(abs(num), abs(ana)) + 0.05, (gname, ana, num, lp, lm)
