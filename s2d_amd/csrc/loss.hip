@@ -1092,7 +1092,8 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
                            T, hm, wm, H, W, Nmax, num_points, oversample_ratio, importance_ratio, drop_empty, world_size, workspace))
         return e;
     if (rows == 0) return S2D_OK;
-    if (p.xcap < rows) return S2D_ERR_ARG;             // only the stored-sample path has a backward (every real configuration takes it)
+    if (p.xcap <= 0) return S2D_ERR_ARG;               // only the stored-sample path has a backward (every real configuration takes it;
+                                                       // the caller checks that the ACTIVE rows, lcount[NL], fit xcap = min(rows, 4096))
     if (int e = loss_attrs()) return e;
     if (s2d_zero_async(grad_rows, sizeof(float) * (size_t)rows * hm * wm, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p,

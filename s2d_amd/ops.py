@@ -376,6 +376,11 @@ def point_loss_backward(ctx, w_mask, w_dice):
     layers) / d(the matched query's logit map of that (layer, clip, slot, frame))"""
     NL, B, Q, T, hm, wm, Nmax = ctx[10], ctx[11], ctx[12], ctx[14], ctx[15], ctx[16], ctx[19]
     rows = NL * B * min(Q, Nmax) * T
+    # the backward walks the rows whose point samples the forward kept (the first min(rows, 4096) ACTIVE rows); the number of
+    # active rows sits in the forward's workspace (lcount[NL], after six int32 arrays of `rows` entries): one 4-byte read back
+    active = int(ctx[-1].view(torch.int32)[rows * 6 + NL])
+    if active > min(rows, 4096):
+        raise NotImplementedError(f"{active} matched (layer, target, frame) rows in one criterion pass: the gradient path keeps 4096")
     g = torch.empty((rows, hm * wm), device=ctx[0].device, dtype=torch.float32)
     lib().call("s2d_point_loss_backward_f32", *ctx, float(w_mask), float(w_dice), g, _stream())
     return g
