@@ -104,13 +104,31 @@ def bias_grad(dy, out=None, beta=0.0):
     return out
 
 
+_WT = {}     # (data_ptr, shape) -> (W^T, version of the owning tensor, the owning tensor)
+
+
+def _transposed_weight(w, Np):
+    """W^T [K,Np] of a weight [N,K] (zero columns beyond N), cached per weight version and marked static so that the dense
+    kernels also cache its pre-split image: the dgrad GEMMs then run on the same kernels as the forward's"""
+    w = w.detach()
+    base = w._base if w._base is not None else w
+    key = (w.data_ptr(), tuple(w.shape), Np)
+    ent = _WT.get(key)
+    if ent is None or ent[1] != base._version or ent[2] is not base:
+        wt = transpose(w.contiguous())
+        if Np != w.shape[0]:
+            wt = torch.nn.functional.pad(wt, (0, Np - w.shape[0]))
+        ent = (ops.mark_static(wt), base._version, base)
+        _WT[key] = ent
+    return ent[0]
+
+
 def input_grad(dy, w, res=None):
     """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection)"""
     N = dy.shape[1]
     Np = (N + 3) // 4 * 4                                             # the GEMM wants a contraction length % 4 == 0
-    wt = transpose(w.detach().contiguous())                           # [K,N]: small, once per step
+    wt = _transposed_weight(w, Np)                                    # [K,Np]: once per weight version
     if Np != N:                                                       # e.g. the 2-way class head: zero-pad the contraction
-        wt = torch.nn.functional.pad(wt, (0, Np - N))
         dy = torch.nn.functional.pad(dy, (0, Np - N))
     return ops.gemm_nt(dy, wt, res=res)
 
