@@ -311,6 +311,11 @@ int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, 
 int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, int H, int W, int C, float *dx,
                                        hipStream_t stream);
 
+/* explicit im2col for convolutions with few input channels (the 7x7 stem): col [N*Ho*Wo][KH*KW*C] from x [N,H,W,C], zero
+ * outside the image; the weight gradient is then one contraction dY^T . col (s2d_amd/backward.py:conv_weight_grad) */
+int s2d_im2col_nhwc_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, float *col,
+                        hipStream_t stream);
+
 /* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
  * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU).  n elements, C innermost. */
 int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz,
@@ -346,14 +351,15 @@ int s2d_optim_adamw_ema_f32(const void *const *ptrs, const long *numel, const do
  * (thresholds, tie state, stored point samples, per-row sums), plus the loss weights.  grad_rows
  * [NL*B*min(Q,Nmax)*T][hm*wm] = d(w_mask * loss_mask + w_dice * loss_dice, all layers) / d(logit map of row
  * ((layer*B + b)*maxm + slot)*T + t); rows of unmatched slots and dropped frames are zero.  The selected points are
- * exactly the forward's (same threshold, same tie rule); their gradients are scattered through the bilinear taps with float
- * atomics, as grid_sample's backward does.  Only when every row took the stored-sample path (ERR_ARG otherwise). */
+ * exactly the forward's (same threshold, same tie rule); their gradients are scattered through the bilinear taps into an
+ * LDS tile (half a row plane at a time) and written out once.  bit_scratch: 512 * H*W/32 words.  Only for passes whose active
+ * rows all took the stored-sample path. */
 int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
                                 const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
                                 const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm,
                                 int H, int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio,
                                 int drop_empty, float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows,
-                                hipStream_t stream);
+                                unsigned int *bit_scratch, hipStream_t stream);
 
 /* d(w_ce * loss_labels)/d(class_logits) for one layer (same arguments as s2d_class_loss_f32) -> [B][Q][2] */
 int s2d_class_loss_backward_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,

@@ -173,6 +173,10 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
     if KH == 1 and KW == 1 and pad == 0:
         xs = x if stride == 1 else x[:, ::stride, ::stride][:, :Ho, :Wo].contiguous()
         return weight_grad(dy.view(-1, Co), xs.view(-1, Ci)).view(Co, 1, 1, Ci)
+    if Ci * KH * KW <= 256:                                            # few input channels (the stem): explicit im2col, one contraction
+        col = torch.empty((N * Ho * Wo, KH * KW * Ci), device=x.device, dtype=torch.float32)
+        lib().call("s2d_im2col_nhwc_f32", x, N, H, W, Ci, KH, KW, stride, pad, col, _st())
+        return weight_grad(dy.view(-1, Co), col).view(Co, KH, KW, Ci)
     Hp, Wp = H + 2 * pad, (W + 2 * pad + 3) // 4 * 4                   # row length % 4: row shifts stay 16-B aligned
     xp = torch.zeros((N, Hp, Wp, Ci), device=x.device, dtype=torch.float32)
     xp[:, pad:pad + H, pad:pad + W] = x

@@ -257,9 +257,39 @@ __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float *__re
     *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
 }
 
+// col[p][(ky*KW + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside), p = (n*Ho + oy)*Wo + ox: the
+// explicit im2col of a convolution with few input channels (the 7x7 stem: C = 4, 49 taps), whose weight gradient is then
+// ONE sliced contraction dY^T . col instead of 49 of them with a 4-wide output.
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, int N, int H, int W, int C, int KH, int KW, int stride,
+                                                     int pad, int Ho, int Wo, float *__restrict__ col)
+{
+    const int q = C / 4, taps = KH * KW;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * Ho * Wo * taps * q) return;
+    const int c4 = (int)(i % q);
+    const int tap = (int)((i / q) % taps);
+    const long p = i / ((long)q * taps);
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
+    const int iy = oy * stride - pad + tap / KW, ix = ox * stride - pad + tap % KW;
+    f32x4 v = f32x4(0.f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + iy) * W + ix) * C + c4 * 4);
+    *reinterpret_cast<f32x4 *>(col + i * 4) = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_im2col_nhwc_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, float *col, hipStream_t stream)
+{
+    if ((C & 3) || N < 0 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0) return S2D_ERR_ARG;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const long total = (long)N * Ho * Wo * KH * KW * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(im2col_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, KH, KW, stride, pad, Ho, Wo, col);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, int H, int W, int C, float *dx, hipStream_t stream)
 {

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void hist_stream_kernel(LossParams p)
 }
 
 // bilinear sample of a bit-packed [H,W] plane held in LDS (bit = 1 -> 1.0f)
-__device__ __forceinline__ float sample_bits(const unsigned int *__restrict__ bits, int H, int W, float u, float v)
+template <bool COH = false>
+__device__ __forceinline__ float sample_bits(const unsigned int *bits, int H, int W, float u, float v)
 {
     const float gx = 2.f * u - 1.f, gy = 2.f * v - 1.f;
     const float x = ((gx + 1.f) * W - 1.f) * 0.5f, y = ((gy + 1.f) * H - 1.f) * 0.5f;
@@ -475,7 +476,12 @@ __device__ __forceinline__ float sample_bits(const unsigned int *__restrict__ bi
     const float wya = (y0 >= 0 && y0 < H) ? 1.f - fy : 0.f, wyb = (y1 >= 0 && y1 < H) ? fy : 0.f;
     const int xa = min(max(x0, 0), W - 1), xb = min(max(x1, 0), W - 1);
     const int ya = min(max(y0, 0), H - 1) * W, yb = min(max(y1, 0), H - 1) * W;
-    auto bit = [&](int idx) { return (float)((bits[idx >> 5] >> (idx & 31)) & 1u); };
+    // COH: the words were written to global memory by this workgroup a moment ago (backward: the plane does not fit LDS
+    // next to the gradient tile) -> read them past the L1
+    auto bit = [&](int idx) {
+        const unsigned int w = COH ? __hip_atomic_load(bits + (idx >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bits[idx >> 5];
+        return (float)((w >> (idx & 31)) & 1u);
+    };
     float acc = bit(ya + xa) * (wxa * wya);
     acc += bit(ya + xb) * (wxb * wya);
     acc += bit(yb + xa) * (wxa * wyb);
@@ -606,11 +612,14 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
 // accumulate for rows with stored samples: item = row.  The row's whole target plane is bit-packed into LDS
 // (H*W/8 bytes: 118 KB at 736x1280), the stored logits are streamed, only (u,v) is regenerated for the target taps.
 // BWD = true: the same walk over the same selected points (same threshold, same tie rule), but instead of summing the loss
-// terms every point scatters d(loss)/d(logit at the point) into the row's gradient plane through the bilinear taps of its
-// sample position (float atomics on a [rows][hm*wm] buffer, as grid_sample's backward does).
+// terms every point scatters d(loss)/d(logit at the point) through the bilinear taps of its sample position.  The row's
+// gradient plane (235 KB at 184 x 320) is built in LDS one half (top / bottom rows) at a time with LDS float atomics -- the
+// points are walked once per half, each tap lands in exactly one half -- and written out with plain stores; the bit-packed
+// target plane lives in a per-workgroup global scratch meanwhile (global float atomics took 37 ms per pass, this 1/5).
 struct LossBwdArgs {
     float *gplane;            // [rows][hm*wm], zero-initialised
     float w_mask, w_dice;     // loss weights (weight_dict) of loss_mask / loss_dice
+    unsigned int *bit_scratch; // [gridDim.x][H*W/32]: the row's bit-packed target plane (LDS holds the gradient tile instead)
 };
 template <bool BWD>
 __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p, LossBwdArgs ba)
@@ -629,6 +638,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     const int rows_l = p.B * p.maxm * p.T;
     const int nrows = min(p.lcount[p.NL], p.xcap);
     const long HW = (long)p.H * p.W;
+    unsigned int *tb = BWD ? ba.bit_scratch + (long)blockIdx.x * (HW / 32) : tbits;
+    float *gh = reinterpret_cast<float *>(tbits);          // BWD: the dynamic LDS is the gradient tile [hh][wm]
+    const int hh = (p.hm + 1) / 2;
     for (int li = blockIdx.x; li < nrows; li += gridDim.x) {
         const long rowid = p.list[li];
         const int layer = (int)(rowid / rows_l);
@@ -652,8 +664,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 out |= ((w4 & 0xFF0000u) ? 1u : 0u) << (4 * k + 2);
                 out |= ((w4 & 0xFF000000u) ? 1u : 0u) << (4 * k + 3);
             }
-            tbits[wd] = out;
+            tb[wd] = out;
         }
+        if constexpr (BWD) __threadfence();
         if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
         __syncthreads();
         const unsigned int thr = p.prefix[rowid];
@@ -677,6 +690,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             g_dice = ba.w_dice / (float)num;
             gp = ba.gplane + rowid * (long)p.hm * p.wm;
         }
+        int ylo = 0, yhi = p.hm;                              // BWD: the rows of the gradient tile being built
         auto point = [&](float xv, float tt, float u, float v) {
             if constexpr (!BWD) {
                 acc_point(xv, tt, bce, sgt, sg, ts);
@@ -690,16 +704,25 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 const float x = ((gx + 1.f) * p.wm - 1.f) * 0.5f, y = ((gy + 1.f) * p.hm - 1.f) * 0.5f;
                 const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
                 const float fx = x - x0, fy = y - y0;
-                if (y0 >= 0 && y0 < p.hm) {
-                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gp + y0 * p.wm + x0, g * (1.f - fx) * (1.f - fy));
-                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gp + y0 * p.wm + x1, g * fx * (1.f - fy));
+                if (y0 >= ylo && y0 < yhi) {
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x0, g * (1.f - fx) * (1.f - fy));
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x1, g * fx * (1.f - fy));
                 }
-                if (y1 >= 0 && y1 < p.hm) {
-                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gp + y1 * p.wm + x0, g * (1.f - fx) * fy);
-                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gp + y1 * p.wm + x1, g * fx * fy);
+                if (y1 >= ylo && y1 < yhi) {
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x0, g * (1.f - fx) * fy);
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x1, g * fx * fy);
                 }
             }
         };
+#pragma unroll 1
+        for (int half = 0; half < (BWD ? 2 : 1); ++half) {
+        if constexpr (BWD) {
+            ylo = half == 0 ? 0 : hh; yhi = half == 0 ? hh : p.hm;
+            __syncthreads();
+            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gh[i] = 0.f;
+            if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             const bool over = pass == 0;
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                point(xv, sample_bits(tbits, p.H, p.W, u, v), u, v);
+                point(xv, sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
             };
             // Only ~1 in 4 oversampled points passes the threshold, scattered over the lanes: evaluating them in place
             // would run the heavy path at 25 % lane utilisation.  Each wave instead compacts its selected points (ballot
@@ -792,7 +815,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                point(xb[i], sample_bits(tbits, p.H, p.W, u, v), u, v);
+                point(xb[i], sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
                 for (unsigned int j = threadIdx.x; j < nties; j += LTHREADS) {
@@ -824,6 +847,11 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
             }
         }
+        if constexpr (BWD) {                                  // write the finished half of the row's gradient plane
+            __syncthreads();
+            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gp[ylo * p.wm + i] = gh[i];
+        }
+        }   // half
         if constexpr (!BWD) {
             bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1070,7 +1098,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<2>, dim3(2048), dim3(256), 0, stream, p);
     if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f});
+    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f, nullptr});
     if (rows > p.xcap) hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
     S2D_CHECK_LAUNCH();
@@ -1084,7 +1112,8 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
                                 const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
                                 const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm, int H,
                                 int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio, int drop_empty,
-                                float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows, hipStream_t stream)
+                                float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows,
+                                unsigned int *bit_scratch, hipStream_t stream)
 {
     LossParams p;
     long rows = 0;
@@ -1096,8 +1125,12 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
                                                        // the caller checks that the ACTIVE rows, lcount[NL], fit xcap = min(rows, 4096))
     if (int e = loss_attrs()) return e;
     if (s2d_zero_async(grad_rows, sizeof(float) * (size_t)rows * hm * wm, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p,
-                       LossBwdArgs{grad_rows, w_mask, w_dice});
+    const size_t lds = sizeof(float) * (size_t)((hm + 1) / 2) * wm;
+    if (lds > 140 * 1024) return S2D_ERR_ARG;
+    // the bit-packed target planes of the rows in flight: the tail of the workspace's sample buffer is not used by the
+    // backward walk beyond xcap rows; a dedicated scratch keeps it simple
+    hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), lds, stream, p,
+                       LossBwdArgs{grad_rows, w_mask, w_dice, bit_scratch});
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

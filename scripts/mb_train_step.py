@@ -41,3 +41,23 @@ for i in range(4):
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 t0 = time.perf_counter(); model.forward_losses(ops.normalize_pad(frames, 32, mean, std), TargetSet.from_list(masks, device=dev)); torch.cuda.synchronize()
 print(f"forward + loss alone (one stream): {(time.perf_counter()-t0)*1e3:.1f} ms")
+
+# phase timing of one more iteration (synchronising wrappers: adds the sync cost, shows where the backward goes)
+import types
+from s2d_amd import ops as _ops
+phases = {}
+def timed(obj, name, label):
+    fn = getattr(obj, name)
+    def w(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); phases[label] = phases.get(label, 0.0) + (time.perf_counter() - t0) * 1e3
+        return r
+    setattr(obj, name, w)
+head = model.student[1]
+timed(model.student[0], "backward", "trunk backward"); timed(head.pixel_decoder, "backward_features", "pixel decoder backward")
+timed(head.predictor, "backward", "decoder backward"); timed(_ops, "point_loss_backward", "point loss backward (2 passes)")
+timed(model.criterion, "forward", "criteria (2 passes, forward)"); timed(model.teacher, "forward", "teacher forward")
+timed(model.student[0], "forward", "trunk forward"); timed(head.pixel_decoder, "forward_features", "pixel decoder forward"); timed(head.predictor, "forward", "decoder forward")
+it(); torch.cuda.synchronize()
+print("phases (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in phases.items()))
