@@ -34,6 +34,32 @@ DENSE_DESC = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
               "bf16x3": "split-bf16 x3 on v_mfma_f32_32x32x16_bf16 (3 MFMA flops per algorithmic flop)"}
 
 
+def train_step_report(model, frames, masks, mean, std, dev, iters=3):
+    from s2d_amd import ops
+    from s2d_amd.modeling import TargetSet
+    from s2d_amd.optim import FullModelGradientClippingAdamW, param_groups_like_reference
+    model.overlap_teacher = model.overlap_criteria = False
+    groups = param_groups_like_reference(model.student, 1e-4, 0.05)
+    teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
+    opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
+    losses, times = [], []
+    for i in range(iters + 1):                          # iteration 0 warms allocator pools and caches
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        images = ops.normalize_pad(frames, 32, mean, std)
+        targets = TargetSet.from_list(masks, device=dev)
+        opt.zero_grad()
+        out = model.forward_backward(images, targets)
+        opt.step(inv_scale=opt.allreduce_grads(), ema_momentum=0.999)
+        tot = float(sum(out.values()))
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(round(tot, 4))
+    assert all(map(lambda v: v == v and abs(v) != float("inf"), losses)) and not opt.found_inf()
+    ms = 1000 * sum(times[1:]) / iters
+    return {"what": "one full training iteration on the same batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
+                    "(HIP gradient kernels, no autograd graph) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
+            "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(frames.shape[0] / (ms / 1000), 2), "iterations": iters,
+            "loss_per_iteration": losses, "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
 def synth_batch(rank, B, T, H0, W0, N, device):
     """seeded synthetic clips: smooth-noise frames + sparse moving ellipses, generated on the device"""
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -116,6 +142,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the extra report of one full training iteration (fwd + loss + backward + clip/AdamW/EMA, BASELINE config 4)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run everything on one stream (default: teacher forward + GT criterion on a second HIP stream; the "
@@ -285,6 +313,14 @@ def main():
                 print(f"{str(tag):44s} calls/step {n/psteps:6.1f}  ms/step {t/psteps:7.2f}  {f/t/1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config)
+        if world == 1 and not args.no_train_step:
+            # BASELINE config 4 / SURVEY.md 8d: the same batch through one FULL training iteration (forward + loss + backward
+            # of the student on the HIP gradient kernels + gradient all-reduce (identity at one rank) + full-model clip +
+            # AdamW + EMA teacher update).  An extra report after the metric's timed region; it never touches `value`.
+            try:
+                res["train_step"] = train_step_report(model, frames, masks, mean, std, dev)
+            except Exception as e:                      # the metric line must come out whatever happens here
+                res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
