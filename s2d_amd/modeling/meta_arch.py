@@ -213,12 +213,22 @@ class KDVideoMaskFormer(nn.Module):
         kd_nmax = kd_nmax or self.num_queries
         backbone, head = self.student[0], self.student[1]
         tb, tp, td = [], [], []
+        main = torch.cuda.current_stream(images.device)
+        if self.overlap_teacher:                                   # the frozen teacher's forward fills the student's launch tails
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=images.device)
+            side = self._side
+            side.wait_stream(main)
+        else:
+            side = main
+        with torch.cuda.stream(side):
+            teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
+            tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                                self.score_threshold_distillation, self.num_predictions_distillation)
         feats = backbone(images, tb)
         mf, ms = head.pixel_decoder.forward_features(feats, tp)
         student = head.predictor(ms, mf, True, True, td)
-        teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
-        tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
-                                            self.score_threshold_distillation, self.num_predictions_distillation)
+        main.wait_stream(side)
         losses = self.criterion(student, gt_targets, False, coords_gt, keep_ctx=True)
         ctx_gt = self.criterion.last_ctx
         kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd, keep_ctx=True)
