@@ -38,7 +38,10 @@ def train_step_report(model, frames, masks, mean, std, dev, iters=3):
     from s2d_amd import ops
     from s2d_amd.modeling import TargetSet
     from s2d_amd.optim import FullModelGradientClippingAdamW, param_groups_like_reference
-    model.overlap_teacher, model.overlap_criteria = True, False     # teacher forward on a second stream; criteria + backward on one
+    model.overlap_teacher = model.overlap_criteria = False          # one stream (a second one gains 2 ms here and splits the allocator's pools)
+    model.last = None
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()     # the metric's two-stream phase left its blocks in per-stream pools; start this phase from a clean pool
     groups = param_groups_like_reference(model.student, 1e-4, 0.05)
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
@@ -55,7 +58,7 @@ def train_step_report(model, frames, masks, mean, std, dev, iters=3):
     assert all(map(lambda v: v == v and abs(v) != float("inf"), losses)) and not opt.found_inf()
     ms = 1000 * sum(times[1:]) / iters
     return {"what": "one full training iteration on the same batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
-                    "(HIP gradient kernels, no autograd graph) + full-model clip + AdamW + EMA teacher update; fp32; the teacher's forward runs on a second stream",
+                    "(HIP gradient kernels, no autograd graph) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
             "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(frames.shape[0] / (ms / 1000), 2), "iterations": iters,
             "loss_per_iteration": losses, "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
