@@ -46,7 +46,11 @@ def train_step_report(model, frames, masks, mean, std, dev, iters=3):
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
     losses, times = [], []
-    for i in range(iters + 1):                          # iteration 0 warms allocator pools and caches
+    st0 = torch.cuda.memory_stats()
+    WARM = 2                                            # the caching allocator still calls hipMalloc in the second iteration
+    for i in range(iters + WARM):
+        if i == WARM:
+            st0 = torch.cuda.memory_stats()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         images = ops.normalize_pad(frames, 32, mean, std)
         targets = TargetSet.from_list(masks, device=dev)
@@ -56,11 +60,14 @@ def train_step_report(model, frames, masks, mean, std, dev, iters=3):
         tot = float(sum(out.values()))
         torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(round(tot, 4))
     assert all(map(lambda v: v == v and abs(v) != float("inf"), losses)) and not opt.found_inf()
-    ms = 1000 * sum(times[1:]) / iters
+    ms = 1000 * sum(times[WARM:]) / iters
     return {"what": "one full training iteration on the same batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
                     "(HIP gradient kernels, no autograd graph) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
-            "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(frames.shape[0] / (ms / 1000), 2), "iterations": iters,
-            "loss_per_iteration": losses, "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+            "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(frames.shape[0] / (ms / 1000), 2), "iterations": iters, "warmup_iterations": WARM,
+            "loss_per_iteration": losses, "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "ms_each": [round(1000 * t, 1) for t in times],
+            "allocator_in_timed_iterations": {k: torch.cuda.memory_stats().get(k, 0) - st0.get(k, 0) for k in
+                                              ("num_alloc_retries", "num_device_alloc", "num_device_free")}}
 
 
 def synth_batch(rank, B, T, H0, W0, N, device):
@@ -314,8 +321,6 @@ def main():
                 a = agg[tag[:5]]; a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
             for tag, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
                 print(f"{str(tag):44s} calls/step {n/psteps:6.1f}  ms/step {t/psteps:7.2f}  {f/t/1e9:7.1f} TF", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and not args.no_train_step:
             # BASELINE config 4 / SURVEY.md 8d: the same batch through one FULL training iteration (forward + loss + backward
             # of the student on the HIP gradient kernels + gradient all-reduce (identity at one rank) + full-model clip +
@@ -324,6 +329,8 @@ def main():
                 res["train_step"] = train_step_report(model, frames, masks, mean, std, dev)
             except Exception as e:                      # the metric line must come out whatever happens here
                 res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1 and not args.no_cpu_baseline:     # last: its BLAS worker threads keep the host busy for a while afterwards
+            res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
