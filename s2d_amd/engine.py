@@ -1,0 +1,26 @@
+"""The device side of `Trainer.run_step` (model_training/mask2former_video/engine/train_loop.py:690-770) for the meta-archs of
+s2d_amd.modeling: forward + loss + backward, gradient exchange, optimizer step, EMA teacher update -- the three reference
+statements `loss_dict = self.model(data)`, `self.grad_scaler.scale(losses).backward()`, `self.grad_scaler.step(self.optimizer)`
+and the EMA loop, with the data loading, copy-paste, logging and scheduling left to the trainer."""
+import math
+
+from .modeling.criterion import TargetSet
+from .modeling.meta_arch import _gt_target_list
+
+
+def run_step(model, optimizer, data, iteration=0, ema_momentum=None):
+    """one optimizer step on `data` (the mapper's list of dicts): returns the weighted loss dict (0-dim device tensors).
+    Gradient accumulation (SOLVER.ACCUM_ITER > 1, :730-746): gradients are scaled by 1 / accum_iter and the optimizer (and the
+    EMA, :761) only steps on every accum_iter-th call."""
+    images = model.preprocess(data) if hasattr(model, "preprocess") else None
+    if images is None:
+        raise TypeError("run_step needs a meta-architecture of s2d_amd.modeling")
+    Hp, Wp = images.shape[1:3]
+    targets = TargetSet.from_list(_gt_target_list(data, model.num_frames, Hp, Wp, model.device), device=model.device)
+    accum = max(int(getattr(model, "accum_iter", 1)), 1)
+    if iteration % accum == 0:
+        optimizer.zero_grad()
+    losses = model.forward_backward(images, targets, loss_scale=1.0 / accum)
+    if (iteration + 1) % accum == 0:
+        optimizer.step(inv_scale=optimizer.allreduce_grads(), ema_momentum=ema_momentum)
+    return losses

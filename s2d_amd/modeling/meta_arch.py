@@ -202,12 +202,13 @@ class KDVideoMaskFormer(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_backward(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None):
+    def forward_backward(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None, loss_scale=1.0):
         """One training iteration's device work up to the optimizer (engine/train_loop.py:709-726: forward, sum of the
         weighted losses, backward): returns the weighted loss dict of forward_losses and leaves d(sum of losses)/d(parameter)
         in .grad of every student parameter (accumulating, like autograd).  Every gradient is computed by the HIP kernels of
         s2d_amd/backward.py through explicit tapes of the student's activations; the teacher and both matchers carry no
-        gradient, attention masks and sampled points are constants, as in the reference."""
+        gradient, attention masks and sampled points are constants, as in the reference.  loss_scale multiplies the
+        gradients only (1 / ACCUM_ITER under gradient accumulation, train_loop.py:737-741)."""
         wd = self.criterion.weight_dict
         Hp, Wp = images.shape[1:3]
         kd_nmax = kd_nmax or self.num_queries
@@ -247,12 +248,12 @@ class KDVideoMaskFormer(nn.Module):
                 if wd.get(pre + f"loss_mask_{i}", w_mask) != w_mask or wd.get(pre + f"loss_dice_{i}", w_dice) != w_dice:
                     raise NotImplementedError("per-layer loss weights that differ between decoder layers")
             if w_mask != 0.0 or w_dice != 0.0:
-                rows = ops.point_loss_backward(ctx["point_loss"], w_mask, w_dice).view(NL, B, ctx["maxm"], T * hm * wm)
+                rows = ops.point_loss_backward(ctx["point_loss"], w_mask * loss_scale, w_dice * loss_scale).view(NL, B, ctx["maxm"], T * hm * wm)
                 sources.append((rows, ctx["idx_q"]))
             w_ce = wd.get(pre + "loss_ce", 0.0)
             if w_ce != 0.0:
                 d_cls[NL - 1] += ops.class_loss_backward(student.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),
-                                                         ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce, self.criterion.eos_coef)
+                                                         ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce * loss_scale, self.criterion.eos_coef)
         d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
         grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
         backbone.backward(tb, grads)
@@ -332,6 +333,37 @@ class VideoMaskFormer(nn.Module):
         out = self.sem_seg_head(self.backbone(images), True)
         losses = self.criterion(out, gt_targets, False, coords)
         wd = self.criterion.weight_dict
+        self.last = dict(outputs=out)
+        return {k: v * wd[k] for k, v in losses.items() if k in wd}
+
+    @torch.no_grad()
+    def forward_backward(self, images, gt_targets, coords=None, loss_scale=1.0):
+        """forward + loss + backward of the single network (see KDVideoMaskFormer.forward_backward): returns the weighted loss
+        dict and leaves the gradients in .grad of the backbone / head parameters"""
+        wd = self.criterion.weight_dict
+        head = self.sem_seg_head
+        tb, tp, td = [], [], []
+        feats = self.backbone(images, tb)
+        mf, ms = head.pixel_decoder.forward_features(feats, tp)
+        out = head.predictor(ms, mf, True, True, td)
+        losses = self.criterion(out, gt_targets, False, coords, keep_ctx=True)
+        ctx = self.criterion.last_ctx
+        NL, B = out.class_logits.shape[:2]
+        Q, T, hm, wm = out.dims
+        w_mask, w_dice, w_ce = wd.get("loss_mask", 0.0), wd.get("loss_dice", 0.0), wd.get("loss_ce", 0.0)
+        for i in range(NL - 1):
+            if wd.get(f"loss_mask_{i}", w_mask) != w_mask or wd.get(f"loss_dice_{i}", w_dice) != w_dice:
+                raise NotImplementedError("per-layer loss weights that differ between decoder layers")
+        sources = []
+        if w_mask != 0.0 or w_dice != 0.0:
+            rows = ops.point_loss_backward(ctx["point_loss"], w_mask * loss_scale, w_dice * loss_scale).view(NL, B, ctx["maxm"], T * hm * wm)
+            sources.append((rows, ctx["idx_q"]))
+        d_cls = torch.zeros_like(out.class_logits)
+        if w_ce != 0.0:
+            d_cls[NL - 1] = ops.class_loss_backward(out.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),
+                                                    ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce * loss_scale, self.criterion.eos_coef)
+        d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
+        self.backbone.backward(tb, head.pixel_decoder.backward_features(tp[0], d_mf, d_mem))
         self.last = dict(outputs=out)
         return {k: v * wd[k] for k, v in losses.items() if k in wd}
 

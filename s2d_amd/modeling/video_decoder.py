@@ -249,6 +249,9 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             packs = []
             for lvl in range(3):
                 ms = [mh[i] for i in range(self.num_layers) if i % 3 == lvl]
+                if not ms:                         # fewer than three layers: nobody reads this level
+                    packs.append(None)
+                    continue
                 wk = torch.cat([m.in_proj_weight.detach()[C:2 * C] for m in ms], 0).contiguous()
                 bk = torch.cat([m.in_proj_bias.detach()[C:2 * C] for m in ms], 0).contiguous()
                 wv = torch.cat([m.in_proj_weight.detach()[2 * C:] for m in ms], 0).contiguous()
@@ -264,7 +267,11 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         per level and layer, so src + level_embed is never stored."""
         C = self.hidden_dim
         ks, vs, kins, xs = [], [], [], []
-        for lvl, ((tok, (h, w)), (wk, bk, wv, bv)) in enumerate(zip(multi_scale, self._kv_packed())):
+        for lvl, ((tok, (h, w)), pack) in enumerate(zip(multi_scale, self._kv_packed())):
+            if pack is None:
+                ks.append(None); vs.append(None); kins.append(None); xs.append(None)
+                continue
+            wk, bk, wv, bv = pack
             x = tok.view(B, T * h * w, C)
             kin = ops.add_bcast(x, posl[lvl])                                               # src + level_embed + pos
             ks.append(ops.gemm_nt(kin.view(-1, C), wk, bias=bk).view(B, T * h * w, -1))
@@ -286,6 +293,10 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         d_mem, d_le = [], []
         per_layer = {}
         for lvl in range(3):
+            if packs[lvl] is None:
+                d_mem.append(None)
+                d_le.append(torch.zeros((C,), device=self.level_embed.weight.device, dtype=torch.float32))
+                continue
             wk, bk, wv, bv = packs[lvl]
             dk2, dv2 = d_ks[lvl].view(-1, d_ks[lvl].shape[-1]), d_vs[lvl].view(-1, d_vs[lvl].shape[-1])
             kin2, x2 = kins[lvl].view(-1, C), xs[lvl].reshape(-1, C)
@@ -389,7 +400,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             bits, unm = heads(i + 1, output)
         if tape is not None:
             assert aux_masks, "the backward needs every layer's full mask prediction (the supervised network)"
-            tape.append((self, mem_tape[0], head_tape, layer_tape, mf, [k.shape for k in ks], (B, T, hm, wm)))
+            tape.append((self, mem_tape[0], head_tape, layer_tape, mf, [None if k is None else k.shape for k in ks], (B, T, hm, wm)))
         return MaskOutputs(out_cls, out_ml, Q, T, hm, wm)
 
     @torch.no_grad()
@@ -407,8 +418,8 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         npix = T * hm * wm
         mft = [Bk.transpose(mf[b]) for b in range(B)]                               # [C, npix] per clip
         d_mf = [None] * B
-        d_ks = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
-        d_vs = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
+        d_ks = [None if sh is None else torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
+        d_vs = [None if sh is None else torch.zeros(sh, device=dev, dtype=torch.float32) for sh in kshapes]
         d_qe = torch.zeros((Q, C), device=dev, dtype=torch.float32)
 
         # d(mask features) does not depend on the layer walk: per clip and criterion pass, the gradient planes of ALL layers

@@ -598,3 +598,45 @@ def test_whole_model_gradient_directional_derivative():
             for p, d in zip(params, dirs): p.add_(d, alpha=eps)
         num = (lp - lm) / (2 * eps)
         assert abs(ana - num) < 0.03 * max(abs(num), abs(ana)) + 0.05, (gname, ana, num, lp, lm)
+
+
+def test_run_step_trains_both_meta_archs():
+    """engine.run_step on mapper-shaped batches: the loss goes down for KDVideoMaskFormer and VideoMaskFormer; gradient
+    accumulation steps every second call with half-scaled gradients"""
+    from s2d_amd import engine, ops
+    from s2d_amd.modeling import build_kd_model
+    from s2d_amd.modeling.meta_arch import VideoMaskFormer
+    from s2d_amd.optim import FullModelGradientClippingAdamW
+    from s2d_amd.utils import synth
+    T, H0, W0, Q = 2, 60, 90, 12
+    kd = build_kd_model(num_queries=Q, num_frames=T, num_points=256, weights=(2.0, 5.0, 5.0), dec_layers=3).to(DEV)
+    kd.train()
+    data = []
+    for b in range(2):
+        fr = synth.smooth_frames_u8(3, b, T, H0, W0)
+        m, ids = synth.ellipse_targets(3, 10 + b, 3, T, H0, W0, sparse=0.0)
+        data.append({"image": [torch.from_numpy(f) for f in fr],
+                     "instances": [{"gt_masks": torch.from_numpy(m[:, t]), "gt_ids": torch.from_numpy(ids[:, t])} for t in range(T)]})
+    opt = FullModelGradientClippingAdamW([p for p in kd.student.parameters() if p.requires_grad], lr=2e-4, clip_norm=1.0,
+                                         ema_params=list(kd.teacher.parameters()))
+    t0 = [p.detach().clone() for p in kd.teacher.parameters()]
+    first = float(sum(engine.run_step(kd, opt, data, 0, ema_momentum=0.9).values()))
+    for it in range(1, 6):
+        last = float(sum(engine.run_step(kd, opt, data, it, ema_momentum=0.9).values()))
+    assert np.isfinite(last) and not opt.found_inf()
+    assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(t0, kd.teacher.parameters()))     # EMA moved the teacher
+    # non-KD model (same student network), fixed targets: the supervised loss falls
+    vm = VideoMaskFormer(backbone=kd.student[0], sem_seg_head=kd.student[1], criterion=kd.criterion, num_queries=Q, num_frames=T).to(DEV)
+    vm.train()
+    vm.preprocess = kd.preprocess
+    opt2 = FullModelGradientClippingAdamW([p for p in vm.parameters() if p.requires_grad], lr=2e-4, clip_norm=1.0)
+    l0 = float(sum(engine.run_step(vm, opt2, data, 0).values()))
+    for it in range(1, 8):
+        l1 = float(sum(engine.run_step(vm, opt2, data, it).values()))
+    assert l1 < l0, (l0, l1)
+    vm.accum_iter = 2
+    before = [p.detach().clone() for p in vm.parameters()]
+    engine.run_step(vm, opt2, data, 0)                                   # accumulates only
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, vm.parameters()))
+    engine.run_step(vm, opt2, data, 1)                                   # steps
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, vm.parameters()))
