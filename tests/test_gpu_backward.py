@@ -223,11 +223,12 @@ def _msda_fused_torch(value, shapes, oa, M=8, P=4):
     return out.reshape(N, M, D, S).permute(0, 3, 1, 2).reshape(N, S, C)
 
 
-def test_msda_fused_backward_vs_autograd():
+@pytest.mark.parametrize("shapes,N", [([(5, 7), (10, 14), (20, 28)], 2), ([(16, 20), (32, 40), (64, 80)], 1)])
+def test_msda_fused_backward_vs_autograd(shapes, N):
+    """two pyramid sizes; offsets of several pixels, so samples also fall outside the maps (zero padding)"""
     from s2d_amd import backward, ops
-    shapes = [(5, 7), (10, 14), (20, 28)]
     S = sum(h * w for h, w in shapes)
-    N, C = 2, 256
+    C = 256
     g = torch.Generator().manual_seed(3)
     value = torch.randn((N, S, C), generator=g)
     oa = torch.cat([torch.randn((N, S, 192), generator=g) * 2.0, torch.randn((N, S, 96), generator=g)], -1)   # offsets reach outside
@@ -236,7 +237,7 @@ def test_msda_fused_backward_vs_autograd():
     out = _msda_fused_torch(vd, shapes, od)
     (out * go.double()).sum().backward()
     v_h, o_h = value.to(DEV), oa.to(DEV)
-    assert rel(ops.msda_fused_forward(v_h, shapes, o_h).cpu().numpy(), out.detach().numpy()) < 2e-6
+    assert rel(ops.msda_fused_forward(v_h, shapes, o_h).cpu().numpy(), out.detach().numpy()) < 2e-5   # fp32 sample positions on an 80-px-wide level
     dv, doa = backward.msda_fused_backward(v_h, shapes, o_h, go.to(DEV))
     assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 1e-5
     assert rel(doa.cpu().numpy(), od.grad.numpy()) < 1e-5
