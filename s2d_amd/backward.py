@@ -51,12 +51,28 @@ def _slices(M, out_tiles):
     return S, chunk
 
 
+_TN_MAX_OUT = 65536     # the TN kernel (transpose on the way into LDS) beats transposed copies + NT GEMM for outputs up to 256 x 256
+
+
+def _tn_ok(M, N, K):
+    return N % 4 == 0 and K % 4 == 0 and M * N * 4 <= 0xFFFFFF00 and M * K * 4 <= 0xFFFFFF00
+
+
 def weight_grad(dy, x, out=None, beta=0.0):
     """dW [N,K] = dy[M,N]^T @ x[M,K]  (out given: out = beta * out + dW)"""
     ops._chk(dy); ops._chk(x)
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M
+    if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # small outputs: no transposed copies, the TN kernel
+        S, chunk = _slices(M, ((N + 127) // 128) * ((K + 63) // 64))
+        part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
+        lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, _st())
+        if out is None:
+            out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+            beta = 0.0
+        lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
+        return out
     S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128))
     Mp = S * chunk
     dyt, xt = transpose(dy, Mp), transpose(x, Mp)
@@ -165,8 +181,8 @@ def conv_input_grad(dy, w, stride, pad, in_hw):
 def conv_weight_grad(dy, x, KH, KW, stride, pad):
     """dW [Cout,KH,KW,Cin] = sum over positions of dy (x) shifted x.  On the zero-padded input grid a tap is a constant
     offset of the flattened position, so with dy scattered onto that grid (zeros elsewhere) every tap is one contraction
-    dYg^T . shift(Xp): the transposed operands are made once and the KH*KW taps are NT GEMMs on shifted views of them
-    (contraction sliced and reduced in a fixed order as in weight_grad)."""
+    dYg^T . shift(Xp): the KH*KW taps are contractions on shifted views of the padded input, sliced and reduced in a fixed
+    order as in weight_grad (TN kernel for small tap matrices, transposed operands + NT GEMM for large ones)."""
     ops._chk(dy); ops._chk(x)
     N, H, W, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
@@ -183,6 +199,18 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
     dg = torch.zeros((N, Hp, Wp, Co), device=x.device, dtype=torch.float32)
     dg[:, 0:Ho * stride:stride, 0:Wo * stride:stride] = dy             # output (y,x) reads input rows y*stride + ky
     P = N * Hp * Wp
+    if Co * Ci <= _TN_MAX_OUT and _tn_ok(P, Co, Ci):                   # small tap matrices: no transposed copies
+        S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 63) // 64))
+        part = torch.empty((S, Co, Ci), device=x.device, dtype=torch.float32)
+        dw = torch.empty((Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
+        tmp = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
+        for ky in range(KH):
+            for kx in range(KW):
+                shift = ky * Wp + kx                                   # the tap: B starts `shift` grid positions later
+                lib().call("s2d_gemm_tn_f32", dg, xp.data_ptr() + shift * Ci * 4, part, Co, Ci, P, P - shift, Co, Ci, chunk, _st())
+                lib().call("s2d_reduce_slices_f32", part, S, Co * Ci, Co * Ci, 0.0, tmp, _st())
+                dw[:, ky, kx] = tmp
+        return dw
     tail = (KH - 1) * Wp + KW                                          # the farthest shift a tap applies
     S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 127) // 128))
     Pp = S * chunk

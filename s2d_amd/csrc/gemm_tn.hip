@@ -1,0 +1,152 @@
+// Weight-gradient contraction C[n][k] = sum_m A[m][n] * B[m][k] (dW = dY^T . X) in the split-fp16 x3 arithmetic of the forward
+// kernels, WITHOUT transposed copies of the operands: the row-major tiles (32 contraction rows x 128 / 64 columns) are
+// loaded with coalesced 16-B loads and transposed on their way into LDS -- two consecutive contraction rows are packed
+// into one fp16 pair, so every LDS write is a 32-bit store into the [column][k] image the MFMA fragments are read from
+// (the image of gemm_f16x3_hi_kernel: rows of [16 words hi | 16 words lo | 4 pad]).
+// The contraction (3e5 .. 4e6 rows) is cut into slices, one per blockIdx.y; slice s writes its partial [Mo][No] tile to
+// C + s * Mo * No and s2d_reduce_slices_f32 adds the slices in a fixed order (reproducible).  B may start `shift` rows later
+// than A (a convolution tap on the zero-padded grid): rows past its end read as zero.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TBK = 32, TROWW = 36;
+constexpr unsigned int TOOB = 0xFFFFFFF0u;
+
+struct TnParams {
+    const float *A, *B;
+    float *C;
+    int Mo, No;                 // output rows (columns of A), output columns (columns of B)
+    long rowsA, rowsB;          // contraction rows available in A / B (B may be shorter: shifted view)
+    long lda, ldb, chunk;
+};
+
+// hi / lo fp16 pairs of two values that are consecutive along the contraction
+__device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, unsigned int &lo)
+{
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const f32x2 f = __builtin_convertvector(h, f32x2);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - f[0]) * 2048.f, (b - f[1]) * 2048.f);
+    hi = __builtin_bit_cast(unsigned int, h);
+    lo = __builtin_bit_cast(unsigned int, l);
+}
+
+__global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
+{
+    constexpr int BM = 128, BNs = 64;
+    __shared__ __attribute__((aligned(16))) unsigned int As[BM * TROWW];
+    __shared__ __attribute__((aligned(16))) unsigned int Bs[BNs * TROWW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int tiles_n = (p.No + BNs - 1) / BNs;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BNs;
+    const long r_lo = (long)blockIdx.y * p.chunk;
+    const long r_hi = r_lo + p.chunk < p.rowsA ? r_lo + p.chunk : p.rowsA;
+    const int nk = (int)((r_hi - r_lo + TBK - 1) / TBK);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)(p.rowsA * p.lda * 4L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.B), 0, (int)(p.rowsB * p.ldb * 4L), 0x00020000);
+    // A tile: 32 rows x 128 columns; a thread takes 4 columns of the row pairs (2 ra, 2 ra + 1) and (2 ra + 16, 2 ra + 17)
+    const int ca = tid & 31, ra_ = tid >> 5;
+    // B tile: 32 rows x 64 columns; a thread takes 4 columns of the row pair (2 rb, 2 rb + 1)
+    const int cb = tid & 15, rb_ = tid >> 4;
+    const unsigned int a_col = (unsigned int)(m0 + 4 * ca), b_col = (unsigned int)(n0 + 4 * cb);
+    const unsigned int a_bad = a_col < (unsigned int)p.Mo ? 0u : TOOB, b_bad = b_col < (unsigned int)p.No ? 0u : TOOB;
+    f32x4 va[4], vb[2];
+    auto load_tile = [&](int kt) {
+        const long r = r_lo + (long)kt * TBK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long m = r + 2 * ra_ + t + 16 * i;
+                const unsigned int off = (unsigned int)((m * p.lda + a_col) * 4L) | a_bad | (m < r_hi ? 0u : TOOB);
+                va[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long m = r + 2 * rb_ + t;
+            const unsigned int off = (unsigned int)((m * p.ldb + b_col) * 4L) | b_bad | (m < r_hi && m < p.rowsB ? 0u : TOOB);
+            vb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned int hi, lo;
+                split_pair(va[2 * i][j], va[2 * i + 1][j], hi, lo);
+                unsigned int *row = &As[(4 * ca + j) * TROWW + ra_ + 8 * i];
+                row[0] = hi; row[16] = lo;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int hi, lo;
+            split_pair(vb[0][j], vb[1][j], hi, lo);
+            unsigned int *row = &Bs[(4 * cb + j) * TROWW + rb_];
+            row[0] = hi; row[16] = lo;
+        }
+    };
+    f32x16 accm[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accx[i][r] = 0.f; }
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned int *as = &As[(wm * 64 + l32) * TROWW + 4 * h];
+        const unsigned int *bs = &Bs[(wn * 32 + l32) * TROWW + 4 * h];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(bs + 8 * s);
+            const f16x8 bl = *reinterpret_cast<const f16x8 *>(bs + 16 + 8 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(as + i * 32 * TROWW + 8 * s);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(as + i * 32 * TROWW + 16 + 8 * s);
+                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i], 0, 0, 0);
+                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[i], 0, 0, 0);
+                accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float *C = p.C + (long)blockIdx.y * p.Mo * p.No;
+    const int col = n0 + wn * 32 + l32;
+    if (col >= p.No) return;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < p.Mo) C[(long)row * p.No + col] = accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f);
+        }
+}
+
+}  // namespace
+
+extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
+                               long chunk, hipStream_t stream)
+{
+    if (Mo <= 0 || No <= 0 || rowsA <= 0 || rowsB <= 0 || chunk <= 0 || (chunk & 31) || (Mo & 3) || (No & 3) || (lda & 3) || (ldb & 3) ||
+        lda < Mo || ldb < No)
+        return S2D_ERR_ARG;
+    if (rowsA * lda * 4L > 0xFFFFFF00L || rowsB * ldb * 4L > 0xFFFFFF00L) return S2D_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return S2D_ERR_ARG;
+    const long S = (rowsA + chunk - 1) / chunk;
+    if (S > 65535) return S2D_ERR_ARG;
+    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk};
+    hipLaunchKernelGGL(gemm_tn_f16x3_kernel, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
