@@ -51,7 +51,7 @@ def _slices(M, out_tiles):
     return S, chunk
 
 
-_TN_MAX_OUT = 65536     # the TN kernel (transpose on the way into LDS) beats transposed copies + NT GEMM for outputs up to 256 x 256
+_TN_MAX_OUT = int(__import__('os').environ.get('S2D_TN_MAX_OUT', 1 << 40))     # the TN kernel (transpose on the way into LDS) beats transposed copies + NT GEMM for outputs up to 256 x 256
 
 
 def _tn_ok(M, N, K):

@@ -2,7 +2,9 @@
 // kernels, WITHOUT transposed copies of the operands: the row-major tiles (32 contraction rows x 128 / 64 columns) are
 // loaded with coalesced 16-B loads and transposed on their way into LDS -- two consecutive contraction rows are packed
 // into one fp16 pair, so every LDS write is a 32-bit store into the [column][k] image the MFMA fragments are read from
-// (the image of gemm_f16x3_hi_kernel: rows of [16 words hi | 16 words lo | 4 pad]).
+// (the image of gemm_f16x3_hi_kernel: rows of [16 words hi | 16 words lo | 4 pad]); the columns a thread owns are spread
+// over LDS rows 32 apart (a permutation of the output rows, undone in the epilogue) so that the stores of a half-wave hit
+// 8 banks x 4 instead of 2 x 16.
 // The contraction (3e5 .. 4e6 rows) is cut into slices, one per blockIdx.y; slice s writes its partial [Mo][No] tile to
 // C + s * Mo * No and s2d_reduce_slices_f32 adds the slices in a fixed order (reproducible).  B may start `shift` rows later
 // than A (a convolution tap on the zero-padded grid): rows past its end read as zero.
@@ -83,14 +85,14 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
             for (int j = 0; j < 4; ++j) {
                 unsigned int hi, lo;
                 split_pair(va[2 * i][j], va[2 * i + 1][j], hi, lo);
-                unsigned int *row = &As[(4 * ca + j) * TROWW + ra_ + 8 * i];
+                unsigned int *row = &As[(32 * j + ca) * TROWW + ra_ + 8 * i];       // column 4 ca + j lives in LDS row 32 j + ca
                 row[0] = hi; row[16] = lo;
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned int hi, lo;
             split_pair(vb[0][j], vb[1][j], hi, lo);
-            unsigned int *row = &Bs[(4 * cb + j) * TROWW + rb_];
+            unsigned int *row = &Bs[(16 * j + cb) * TROWW + rb_];                    // column 4 cb + j lives in LDS row 16 j + cb
             row[0] = hi; row[16] = lo;
         }
     };
@@ -122,13 +124,16 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
         __syncthreads();
     }
     float *C = p.C + (long)blockIdx.y * p.Mo * p.No;
-    const int col = n0 + wn * 32 + l32;
+    // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
+    // (the permutation that spreads the transposing stores over the banks); undo it here
+    const int col = n0 + 4 * (l32 & 15) + 2 * wn + (l32 >> 4);
     if (col >= p.No) return;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = m0 + 4 * rr + 2 * wm + tm;
             if (row < p.Mo) C[(long)row * p.No + col] = accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f);
         }
 }
