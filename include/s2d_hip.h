@@ -280,10 +280,11 @@ int s2d_rle_strings_u8(const int *positions, const long *frame_off, int F, long 
  * A[m][n] * B[m][k]  (A [rowsA][lda] = dY, B [rowsB][ldb] = X, both row-major; Mo = columns of A used, No = columns of B
  * used; slices of `chunk` rows (multiple of 32), ceil(rowsA / chunk) of them; rows m >= rowsB of B read as zero, so B may be
  * a view that starts some rows later, e.g. a convolution tap on the padded grid).  Same split-fp16 x3 arithmetic as
- * s2d_gemm_nt_f32 mode 2.  Finish with s2d_reduce_slices_f32.  Mo, No, lda, ldb multiples of 4; A, B 16-B aligned; each
- * operand < 4 GiB. */
+ * s2d_gemm_nt_f32 mode 2.  Slice s writes its [Mo][No] tile at C_slices + s * slice_stride (0 = Mo * No; larger: several
+ * launches -- the taps of a convolution -- interleave their tiles so that one s2d_reduce_slices_f32 finishes them all).
+ * Mo, No, lda, ldb multiples of 4; A, B 16-B aligned; each operand < 4 GiB. */
 int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
-                    long chunk, hipStream_t stream);
+                    long chunk, long slice_stride, hipStream_t stream);
 
 /* out[c][r] = in[r][c]; in [R][ldi], out [C][ldo].  dW = dY^T . X runs as an NT GEMM on the transposed operands. */
 int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream);

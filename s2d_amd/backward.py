@@ -67,7 +67,7 @@ def weight_grad(dy, x, out=None, beta=0.0):
     if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # small outputs: no transposed copies, the TN kernel
         S, chunk = _slices(M, ((N + 127) // 128) * ((K + 63) // 64))
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
-        lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, _st())
+        lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, _st())
         if out is None:
             out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
             beta = 0.0
@@ -201,16 +201,16 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
     P = N * Hp * Wp
     if Co * Ci <= _TN_MAX_OUT and _tn_ok(P, Co, Ci):                   # small tap matrices: no transposed copies
         S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 63) // 64))
-        part = torch.empty((S, Co, Ci), device=x.device, dtype=torch.float32)
-        dw = torch.empty((Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
-        tmp = torch.empty((Co, Ci), device=x.device, dtype=torch.float32)
+        taps = KH * KW
+        part = torch.empty((S, taps, Co, Ci), device=x.device, dtype=torch.float32)     # the taps' partial tiles interleaved per slice
         for ky in range(KH):
             for kx in range(KW):
                 shift = ky * Wp + kx                                   # the tap: B starts `shift` grid positions later
-                lib().call("s2d_gemm_tn_f32", dg, xp.data_ptr() + shift * Ci * 4, part, Co, Ci, P, P - shift, Co, Ci, chunk, _st())
-                lib().call("s2d_reduce_slices_f32", part, S, Co * Ci, Co * Ci, 0.0, tmp, _st())
-                dw[:, ky, kx] = tmp
-        return dw
+                lib().call("s2d_gemm_tn_f32", dg, xp.data_ptr() + shift * Ci * 4, part.data_ptr() + (ky * KW + kx) * Co * Ci * 4, Co, Ci, P,
+                           P - shift, Co, Ci, chunk, taps * Co * Ci, _st())
+        dw = torch.empty((taps, Co, Ci), device=x.device, dtype=torch.float32)
+        lib().call("s2d_reduce_slices_f32", part, S, taps * Co * Ci, taps * Co * Ci, 0.0, dw, _st())    # one reduction for all taps
+        return dw.view(KH, KW, Co, Ci).permute(2, 0, 1, 3).contiguous()
     tail = (KH - 1) * Wp + KW                                          # the farthest shift a tap applies
     S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 127) // 128))
     Pp = S * chunk

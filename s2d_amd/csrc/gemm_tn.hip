@@ -6,7 +6,8 @@
 // over LDS rows 32 apart (a permutation of the output rows, undone in the epilogue) so that the stores of a half-wave hit
 // 8 banks x 4 instead of 2 x 16.
 // The contraction (3e5 .. 4e6 rows) is cut into slices, one per blockIdx.y; slice s writes its partial [Mo][No] tile to
-// C + s * Mo * No and s2d_reduce_slices_f32 adds the slices in a fixed order (reproducible).  B may start `shift` rows later
+// C + s * slice_stride and s2d_reduce_slices_f32 adds the slices in a fixed order (reproducible; the taps of a convolution
+// interleave their partial tiles, slice_stride = taps * Mo * No, so that ONE reduction finishes all of them).  B may start `shift` rows later
 // than A (a convolution tap on the zero-padded grid): rows past its end read as zero.
 #include "common.h"
 #include <stdlib.h>
@@ -26,6 +27,7 @@ struct TnParams {
     int Mo, No;                 // output rows (columns of A), output columns (columns of B)
     long rowsA, rowsB;          // contraction rows available in A / B (B may be shorter: shifted view)
     long lda, ldb, chunk;
+    long sC;                    // elements between the partial tiles of consecutive slices (>= Mo * No)
 };
 
 // hi / lo fp16 pairs of two values that are consecutive along the contraction
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
         }
         __syncthreads();
     }
-    float *C = p.C + (long)blockIdx.y * p.Mo * p.No;
+    float *C = p.C + (long)blockIdx.y * p.sC;
     // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
     // (the permutation that spreads the transposing stores over the banks); undo it here
     const int col = n0 + 4 * (l32 & 15) + 2 * wn + (l32 >> 4);
@@ -141,8 +143,10 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
 }  // namespace
 
 extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
-                               long chunk, hipStream_t stream)
+                               long chunk, long slice_stride, hipStream_t stream)
 {
+    if (slice_stride == 0) slice_stride = (long)Mo * No;
+    if (slice_stride < (long)Mo * No) return S2D_ERR_ARG;
     if (Mo <= 0 || No <= 0 || rowsA <= 0 || rowsB <= 0 || chunk <= 0 || (chunk & 31) || (Mo & 3) || (No & 3) || (lda & 3) || (ldb & 3) ||
         lda < Mo || ldb < No)
         return S2D_ERR_ARG;
@@ -150,7 +154,7 @@ extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, 
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return S2D_ERR_ARG;
     const long S = (rowsA + chunk - 1) / chunk;
     if (S > 65535) return S2D_ERR_ARG;
-    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk};
+    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk, slice_stride};
     hipLaunchKernelGGL(gemm_tn_f16x3_kernel, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
