@@ -2,9 +2,12 @@
 
 What `losses.backward()` (engine/train_loop.py:720) does for an nn.Linear / 1x1 convolution y = x W^T + b:
     dx = dy W,   dW = dy^T x,   db = sum_rows dy.
-dx is an NT GEMM against W^T.  dW contracts over the M rows (3e5..9e5): dy and x are transposed once, the contraction is
-cut into S slices that run as the batch dimension of ONE NT-GEMM launch, and the S partial products are added in a
-fixed order, so the result is reproducible.  Same split-fp16 x3 arithmetic as the forward (fp32-class accuracy)."""
+dx is an NT GEMM against W^T.  dW contracts over the M rows (3e5..4e6): the contraction is cut into S slices, the TN kernel
+(csrc/gemm_tn.hip) transposes the row-major tiles of dy and x on their way into LDS, and the S partial products are added
+in a fixed order, so the result is reproducible (shapes the TN kernel cannot take are transposed once and run as the batch
+of one NT-GEMM launch).  Same split-fp16 x3 arithmetic as the forward (fp32-class accuracy)."""
+import os
+
 import torch
 
 from . import ops
@@ -51,7 +54,7 @@ def _slices(M, out_tiles):
     return S, chunk
 
 
-_TN_MAX_OUT = int(__import__('os').environ.get('S2D_TN_MAX_OUT', 1 << 40))     # the TN kernel (transpose on the way into LDS) beats transposed copies + NT GEMM for outputs up to 256 x 256
+_TN_MAX_OUT = int(os.environ.get("S2D_TN_MAX_OUT", 1 << 40))     # experiments: larger outputs take the transposed-copy path
 
 
 def _tn_ok(M, N, K):
@@ -64,7 +67,7 @@ def weight_grad(dy, x, out=None, beta=0.0):
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M
-    if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # small outputs: no transposed copies, the TN kernel
+    if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # no transposed copies: the TN kernel
         S, chunk = _slices(M, ((N + 127) // 128) * ((K + 63) // 64))
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
         lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, _st())
@@ -199,7 +202,7 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
     dg = torch.zeros((N, Hp, Wp, Co), device=x.device, dtype=torch.float32)
     dg[:, 0:Ho * stride:stride, 0:Wo * stride:stride] = dy             # output (y,x) reads input rows y*stride + ky
     P = N * Hp * Wp
-    if Co * Ci <= _TN_MAX_OUT and _tn_ok(P, Co, Ci):                   # small tap matrices: no transposed copies
+    if Co * Ci <= _TN_MAX_OUT and _tn_ok(P, Co, Ci):                   # no transposed copies: the TN kernel
         S, chunk = _slices(P, ((Co + 127) // 128) * ((Ci + 63) // 64))
         taps = KH * KW
         part = torch.empty((S, taps, Co, Ci), device=x.device, dtype=torch.float32)     # the taps' partial tiles interleaved per slice
