@@ -3,8 +3,8 @@
 // loaded with coalesced 16-B loads and transposed on their way into LDS -- two consecutive contraction rows are packed
 // into one fp16 pair, so every LDS write is a 32-bit store into the [column][k] image the MFMA fragments are read from
 // (the image of gemm_f16x3_hi_kernel: rows of [16 words hi | 16 words lo | 4 pad]); the columns a thread owns are spread
-// over LDS rows 32 apart (a permutation of the output rows, undone in the epilogue) so that the stores of a half-wave hit
-// 8 banks x 4 instead of 2 x 16.
+// over LDS rows 32 apart (a permutation of the output rows, undone in the epilogue) and a half-wave covers 8 column groups x
+// 4 row pairs, so that its 32 stores hit 32 different banks (adjacent rows would give 2 banks x 16).
 // The contraction (3e5 .. 4e6 rows) is cut into slices, one per blockIdx.y; slice s writes its partial [Mo][No] tile to
 // C + s * slice_stride and s2d_reduce_slices_f32 adds the slices in a fixed order (reproducible; the taps of a convolution
 // interleave their partial tiles, slice_stride = taps * Mo * No, so that ONE reduction finishes all of them).  B may start `shift` rows later
@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)(p.rowsA * p.lda * 4L), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.B), 0, (int)(p.rowsB * p.ldb * 4L), 0x00020000);
     // A tile: 32 rows x 128 columns; a thread takes 4 columns of the row pairs (2 ra, 2 ra + 1) and (2 ra + 16, 2 ra + 17)
-    const int ca = tid & 31, ra_ = tid >> 5;
+    // (a half-wave = 8 column groups x 4 row pairs: its 32 transposing stores land in 32 different banks, its loads are 128-B runs)
+    const int ca = (tid & 7) | (((tid >> 5) & 3) << 3), ra_ = ((tid >> 3) & 3) | ((tid >> 7) << 2);
     // B tile: 32 rows x 64 columns; a thread takes 4 columns of the row pair (2 rb, 2 rb + 1)
-    const int cb = tid & 15, rb_ = tid >> 4;
+    const int cb = (tid & 7) | (((tid >> 5) & 1) << 3), rb_ = ((tid >> 3) & 3) | ((tid >> 6) << 2);
     const unsigned int a_col = (unsigned int)(m0 + 4 * ca), b_col = (unsigned int)(n0 + 4 * cb);
     const unsigned int a_bad = a_col < (unsigned int)p.Mo ? 0u : TOOB, b_bad = b_col < (unsigned int)p.No ? 0u : TOOB;
     f32x4 va[4], vb[2];
