@@ -327,8 +327,9 @@ int s2d_im2col_nhwc_f32(const float *x, int N, int H, int W, int C, int KH, int 
                         hipStream_t stream);
 
 /* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
- * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU).  n elements, C innermost. */
-int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz,
+ * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU); dres (may be NULL) = dy * (y > 0), the gradient of a residual
+ * added before the ReLU.  n elements, C innermost. */
+int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz, float *dres,
                                 hipStream_t stream);
 
 /* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */

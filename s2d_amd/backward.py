@@ -249,14 +249,16 @@ def layernorm_backward(x, dy, gamma, res=None, eps=1e-5):
     return dx, gb[0], gb[1]
 
 
-def relu_scale_backward(dy, y=None, scale=None):
-    """gradient through y = relu(z * scale + bias): dz = dy * (y > 0) * scale (channels innermost)"""
+def relu_scale_backward(dy, y=None, scale=None, want_res=False):
+    """gradient through y = relu(z * scale + bias [+ res]): dz = dy * (y > 0) * scale (channels innermost); want_res: also
+    dres = dy * (y > 0), from the same pass"""
     for t in (dy, y, scale):
         ops._chk(t)
     C = dy.shape[-1]
     dz = torch.empty_like(dy)
-    lib().call("s2d_relu_scale_backward_f32", dy, y, scale, dy.numel(), C, dz, _st())
-    return dz
+    dres = torch.empty_like(dy) if want_res else None
+    lib().call("s2d_relu_scale_backward_f32", dy, y, scale, dy.numel(), C, dz, dres, _st())
+    return (dz, dres) if want_res else dz
 
 
 def groupnorm_backward(x, dy, G, gamma, eps=1e-5):

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float *__
 // dz = dy * (y > 0) * scale[c]: gradient through y = relu(z * scale + bias) (the conv -> FrozenBN -> ReLU epilogue);
 // scale NULL = 1, y NULL = no ReLU.  n elements, C channels innermost, 16-B accesses.
 __global__ __launch_bounds__(256) void relu_scale_backward_kernel(const float *__restrict__ dy, const float *__restrict__ y,
-                                                                  const float *__restrict__ scale, long n4, int C4, float *__restrict__ dz)
+                                                                  const float *__restrict__ scale, long n4, int C4, float *__restrict__ dz,
+                                                                  float *__restrict__ dres)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void relu_scale_backward_kernel(const float *_
         const f32x4 v = reinterpret_cast<const f32x4 *>(y)[i];
         g[0] = v[0] > 0.f ? g[0] : 0.f; g[1] = v[1] > 0.f ? g[1] : 0.f; g[2] = v[2] > 0.f ? g[2] : 0.f; g[3] = v[3] > 0.f ? g[3] : 0.f;
     }
+    if (dres) reinterpret_cast<f32x4 *>(dres)[i] = g;                  // the residual branch sees the ReLU mask only
     if (scale) g = g * reinterpret_cast<const f32x4 *>(scale)[i % C4];
     reinterpret_cast<f32x4 *>(dz)[i] = g;
 }
@@ -324,11 +326,12 @@ int s2d_layernorm_backward_f32(const float *x, const float *res, const float *dy
     return S2D_OK;
 }
 
-int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz, hipStream_t stream)
+int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz, float *dres,
+                                hipStream_t stream)
 {
     if ((n & 3) || (C & 3) || C <= 0 || n % C) return S2D_ERR_ARG;
     if (n == 0) return S2D_OK;
-    hipLaunchKernelGGL(relu_scale_backward_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, dy, y, scale, n / 4, C / 4, dz);
+    hipLaunchKernelGGL(relu_scale_backward_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, dy, y, scale, n / 4, C / 4, dz, dres);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -69,8 +69,11 @@ class ConvBN(nn.Module):
         (dx [+ dx_res: a gradient arriving at x over another path, added in the dgrad epilogue for 1x1 kernels], dres)."""
         from .. import backward as B
         w, scale, _ = self.packed()
-        dres = B.relu_scale_backward(dy, y) if (has_res and relu) else (dy if has_res else None)
-        dz = B.relu_scale_backward(dy, y if relu else None, scale)              # d(conv output)
+        if has_res and relu:
+            dz, dres = B.relu_scale_backward(dy, y, scale, want_res=True)       # d(conv output), d(residual): one pass
+        else:
+            dres = dy if has_res else None
+            dz = B.relu_scale_backward(dy, y if relu else None, scale)
         dw = B.conv_weight_grad(dz, x, self.k, self.k, self.stride, self.pad)  # [O,kh,kw,C(4)]
         dw = dw[..., :self.weight.shape[1]].permute(0, 3, 1, 2)
         if self.weight.grad is None:
