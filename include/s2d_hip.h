@@ -51,6 +51,21 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
                     const float *res, long ldr, long strideR, int res_rows, int res_cols, int relu, const void *B_split,
                     hipStream_t stream);
 
+/* The same contraction with nn.Dropout fused into the epilogue: C = act(dropout_p(A.B^T + bias) + res) -- the three dropout
+ * sites of the pixel decoder's encoder layers in training mode (msdeformattn.py:101-125: dropout1 on the attention output,
+ * dropout2 after the FFN activation (ReLU and a non-negative mask commute), dropout3 on the FFN output; each before its
+ * residual add).  The mask is counter-based: element (row, col) of the [M,N] output is kept iff 16 bits of
+ * Philox4x32-10(counter = (row, col / 8, site, 0), key = seed) are >= round(p * 65536), kept elements are multiplied by
+ * 1 / (1 - p); the backward regenerates it (s2d_dropout_f32) instead of storing it.  Unbatched; N, ldc, ldr multiples of
+ * 8; dense mode 2 only (S2D_ERR_ARG otherwise). */
+int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
+                            const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,
+                            uint64_t seed, unsigned site, hipStream_t stream);
+
+/* y[M,N] = x * mask / (1 - p) with the mask of s2d_gemm_nt_dropout_f32 for the same (p, seed, site): the gradient of a
+ * dropout site (and the mask itself, from x = 1).  N multiple of 8; y may alias x. */
+int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, float *y, hipStream_t stream);
+
 /* Static weights can be split into their fp16 hi/lo image once (dense mode 2) instead of in every launch that reads
  * them: out = s2d_split_weights_words(N,K) 32-bit words, laid out [N][ceil(K/32)][16 words hi | 16 words lo] (the LDS
  * row image of the kernels, zero padded past K).  Pass it as B_split / w_split together with the fp32 weights (the

@@ -246,6 +246,44 @@ def encoder_layer(p, pre, src, pos, ref_pts, shapes):
     return layer_norm(src + ff, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
+    reference implementation's constants).  Pinned by Random123's published known-answer vectors (tests/test_oracle.py).
+    Arguments: uint32 arrays (broadcastable); returns four uint32 arrays."""
+    c = [np.asarray(x, np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = c
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def dropout_multipliers(M, N, p, seed, site):
+    """the [M, N] float32 multipliers (0 or 1 / (1 - p)) of the library's counter-based dropout (s2d_amd/csrc/dropout.h):
+    block (row, col // 8) draws Philox4x32-10(counter = (row, col // 8, site, 0), key = seed); element col % 8 = e takes
+    half (e & 1) of word (e >> 1) and is kept iff those 16 bits >= round(p * 65536).  Semantics of the sites: nn.Dropout
+    at mask2former/modeling/pixel_decoder/msdeformattn.py:101-125 (x * mask / (1 - p)); the mask stream itself is this
+    library's own definition (torch's is an implementation detail of its CUDA kernels), so dropout parity is
+    distributional plus exact agreement with this restatement."""
+    assert N % 8 == 0
+    thresh = min(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)), 65535)
+    if thresh == 0:
+        return np.ones((M, N), np.float32)
+    rows = np.arange(M, dtype=np.uint32)[:, None]
+    cb = np.arange(N // 8, dtype=np.uint32)[None, :]
+    r = philox4x32_10(rows, cb, np.uint32(site), np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    bits = np.empty((M, N // 8, 8), np.uint32)
+    for e in range(8):
+        w = r[e >> 1]
+        bits[..., e] = (w >> np.uint32(16)) if (e & 1) else (w & np.uint32(0xFFFF))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return np.where(bits.reshape(M, N) >= thresh, scale, np.float32(0.0)).astype(np.float32)
+
+
 def pixel_decoder(p, feats, pre="", n_layers=6):
     """MSDeformAttnPixelDecoder.forward_features, msdeformattn.py:314-358.
     feats: dict res2..res5 [BT,C,h,w].  Returns mask_features [BT,256,h2,w2], [ms0, ms1, ms2]."""

@@ -13,7 +13,10 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libs2d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize: the SLP pass packs scalar f32 arithmetic on freshly loaded values into v_pk_*_f32; that shape -- a packed
+# op as the first reader of a just-awaited dword load -- is what produced wrong values under a two-stream schedule on
+# MI355X (DESIGN.md "Streams"; scripts/isa_lint.py checks the built ISA for it), and packed f32 ops buy nothing beside MFMAs
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "-Wall", "-Wno-unused-function",
          "-I" + CSRC, "-I" + os.path.join(os.path.dirname(CSRC), "..", "include")]
 
 

@@ -109,6 +109,96 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
     }
 }
 
+
+// ---- DIAG (two-stream stale read investigation; removed once the mechanism is written down) ----------------------
+// VAR 1: the round-1 kernel that showed the stale reads (guarded 4-B tap loads); VAR 2: same + agent-scope acquire
+// (buffer_inv sc1) at kernel start; VAR 3: same + sc1 (L1-bypassing, agent-scope) loads
+template <int VAR>
+__global__ __launch_bounds__(256) void attn_mask_kernel_diag(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
+                                                             int hl, int wl, uint32_t *__restrict__ bits,
+                                                             uint32_t *__restrict__ unmasked, float *__restrict__ dbg)
+{
+    __shared__ uint32_t um[QW];
+    if (VAR == 2) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    const int b = blockIdx.y;
+    const long K = (long)T * hl * wl;
+    if (threadIdx.x < QW) um[threadIdx.x] = 0u;
+    __syncthreads();
+    const int g = threadIdx.x & 31;
+    const long key = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    uint32_t nib = 0u, valid = 0u;
+    if (key < K) {
+        const int x = (int)(key % wl), y = (int)((key / wl) % hl), t = (int)(key / ((long)wl * hl));
+        float sy = ((float)hm / hl) * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = ((float)wm / wl) * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hm - 1 ? 1 : 0), x1 = x0 + (x0 < wm - 1 ? 1 : 0);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *base = ml + ((long)b * T + t) * hm * wm * ldq;
+        const int q0 = 4 * g;
+        if (VAR == 5) {        // every lane loads (addresses of lanes beyond Q clamped to the last valid group): full quarter-waves
+            const int qc = q0 < Q ? q0 : ((Q - 1) & ~3);
+            const float *p00 = base + ((long)y0 * wm + x0) * ldq + qc, *p01 = base + ((long)y0 * wm + x1) * ldq + qc;
+            const float *p10 = base + ((long)y1 * wm + x0) * ldq + qc, *p11 = base + ((long)y1 * wm + x1) * ldq + qc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a00 = p00[j], a01 = p01[j], a10 = p10[j], a11 = p11[j];
+                const float vv = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+                if (q0 + j < Q) { valid |= 1u << j; if (vv < 0.f) nib |= 1u << j; }
+            }
+        } else
+        if (q0 < Q) {
+            float v[4];
+            const float *p00 = base + ((long)y0 * wm + x0) * ldq + q0, *p01 = base + ((long)y0 * wm + x1) * ldq + q0;
+            const float *p10 = base + ((long)y1 * wm + x0) * ldq + q0, *p11 = base + ((long)y1 * wm + x1) * ldq + q0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (q0 + j < Q) {
+                    float a00, a01, a10, a11;
+                    if (VAR == 3) {
+                        a00 = __hip_atomic_load(p00 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a01 = __hip_atomic_load(p01 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a10 = __hip_atomic_load(p10 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a11 = __hip_atomic_load(p11 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else { a00 = p00[j]; a01 = p01[j]; a10 = p10[j]; a11 = p11[j]; }
+                    if (VAR == 6) {          // the same arithmetic on single (non-packed) VALU instructions
+                        float m0, m1, m2, m3, s0, s1, t0, t1, r;
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "v"(hx), "v"(a00));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(lx), "v"(a01));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m2) : "v"(hx), "v"(a10));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m3) : "v"(lx), "v"(a11));
+                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(m0), "v"(m1));
+                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(m2), "v"(m3));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(hy), "v"(s0));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(ly), "v"(s1));
+                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t0), "v"(t1));
+                        v[j] = r;
+                    } else
+                    v[j] = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+                    valid |= 1u << j;
+                    if (v[j] < 0.f) nib |= 1u << j;
+                    if (VAR == 4 && dbg && q0 + j >= 64) {          // raw taps, the interpolated value and the lane's nibble so far: [b][key][q-64][6]
+                        float *d = dbg + ((((long)b * K + key) * 36) + (q0 + j - 64)) * 6;
+                        d[0] = a00; d[1] = a01; d[2] = a10; d[3] = a11; d[4] = v[j]; d[5] = (float)nib;
+                    }
+                }
+            }
+        }
+    }
+    uint32_t w = nib << (4 * (g & 7));
+    uint32_t open = (valid & ~nib) << (4 * (g & 7));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        w |= __shfl_xor(w, o, 64);
+        open |= __shfl_xor(open, o, 64);
+    }
+    if ((g & 7) == 0 && key < K) {
+        bits[((long)b * K + key) * QW + (g >> 3)] = w;
+        if (open) atomicOr(&um[g >> 3], open);
+    }
+    __syncthreads();
+    if (threadIdx.x < QW && um[threadIdx.x]) atomicOr(&unmasked[b * QW + threadIdx.x], um[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // split-fp16 helpers (the scheme of gemm_bf16.hip: x = h + l * 2^-11, h = fp16_rtz(x), l = fp16_rtz((x - h) * 2^11))
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -532,6 +622,19 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
     if (B == 0 || K == 0) return S2D_OK;
     if (K >= (1L << 31) - 8) return S2D_ERR_ARG;
     if (s2d_zero_async(unmasked, sizeof(uint32_t) * QW * B, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    static int diag = -1;
+    if (diag < 0) { const char *e = getenv("S2D_DIAG_ATTN_MASK"); diag = e ? atoi(e) : 0; }
+    if (diag && !compact) {
+        float *dbg = nullptr;
+        if (diag == 4) { const char *e = getenv("S2D_DIAG_DBG_PTR"); dbg = e ? reinterpret_cast<float *>(strtoull(e, nullptr, 0)) : nullptr; }
+        const dim3 gr(cdiv(K, 8), B);
+#define S2D_DIAG_LAUNCH(V) hipLaunchKernelGGL(attn_mask_kernel_diag<V>, gr, dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl, wl, bits, unmasked, dbg)
+        if (diag == 1) S2D_DIAG_LAUNCH(1); else if (diag == 2) S2D_DIAG_LAUNCH(2); else if (diag == 3) S2D_DIAG_LAUNCH(3);
+        else if (diag == 4) S2D_DIAG_LAUNCH(4); else if (diag == 5) S2D_DIAG_LAUNCH(5); else S2D_DIAG_LAUNCH(6);
+#undef S2D_DIAG_LAUNCH
+        S2D_CHECK_LAUNCH();
+        return S2D_OK;
+    }
     hipLaunchKernelGGL(attn_mask_kernel<false>, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl,
                        wl, bits, unmasked, compact);
     S2D_CHECK_LAUNCH();

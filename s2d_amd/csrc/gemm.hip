@@ -207,6 +207,26 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
     return launch(p, false, batch, stream);
 }
 
+// the same contraction with dropout fused into the epilogue (see include/s2d_hip.h; dropout.h for the mask definition)
+int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
+                            const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,
+                            uint64_t seed, unsigned site, hipStream_t stream)
+{
+    if (!(p >= 0.f) || p >= 1.f) return S2D_ERR_ARG;
+    GemmParams q{};
+    q.Bsplit = reinterpret_cast<const unsigned int *>(B_split);
+    q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K;
+    q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+    q.bias = bias; q.res = res; q.ldr = res ? ldr : N; q.relu = relu; q.res_cols = N;
+    const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
+    if (thresh == 0) return launch(q, false, 1, stream);        // p rounds to zero: the plain contraction
+    if (g_dense_mode != 2) return S2D_ERR_ARG;
+    q.drop_thresh = thresh > 65535u ? 65535u : thresh;
+    q.drop_scale = 1.0f / (1.0f - p);
+    q.drop_k0 = (unsigned)(seed & 0xFFFFFFFFull); q.drop_k1 = (unsigned)(seed >> 32); q.drop_stream = site;
+    return launch(q, false, 1, stream);
+}
+
 // NHWC convolution as implicit GEMM. x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
 // y [N,Ho,Wo,Cout] = act( conv(x,w) * scale[Cout] + bias[Cout] + res[N,Ho,Wo,Cout] )
 int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH,
@@ -236,7 +256,7 @@ extern "C" int s2d_split_weights_f16(const float *W, int N, int K, long ldw, voi
     return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream);
 }
 
-extern "C" int s2d_abi_version(void) { return 5; }
+extern "C" int s2d_abi_version(void) { return 6; }
 
 extern "C" int s2d_set_dense_mode(int mode)
 {

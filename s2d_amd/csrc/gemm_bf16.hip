@@ -13,6 +13,7 @@
 // (stride 36 words: conflict-free for ds_read_b128 fragment reads and the ds_write_b64 stores), double buffered.
 #include "common.h"
 #include "gemm_params.h"
+#include "dropout.h"
 #include <stdlib.h>
 
 namespace {
@@ -231,10 +232,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
 {
-#ifdef S2D_EXP_NOSPLIT
-    hi[0] = __float_as_uint(v[0]); hi[1] = __float_as_uint(v[1]); lo[0] = __float_as_uint(v[2]); lo[1] = __float_as_uint(v[3]);
-    return;
-#endif
     const h16x2 ha = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), hb = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
     const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
     const f32x2 ra = (a - __builtin_convertvector(ha, f32x2)) * 2048.f, rb = (b - __builtin_convertvector(hb, f32x2)) * 2048.f;
@@ -243,7 +240,7 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, u32x2 &hi, u32x2 &lo)
     lo[0] = __builtin_bit_cast(unsigned int, la); lo[1] = __builtin_bit_cast(unsigned int, lb);
 }
 
-template <bool CONV, bool PIPE, bool BSPLIT>
+template <bool CONV, bool PIPE, bool BSPLIT, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 {
     constexpr int BM = 128, RPT = 32;
@@ -540,6 +537,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                 for (int r = 0; r < 16; ++r)
                     ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] =
                         accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+        if constexpr (DROP) {
+            // dropout epilogue: a lane owns one 8-column mask block of a row (one Philox call), 8 lanes x 32 B = a 256-B row
+            // segment per instruction, 8 rows per pass.  act(drop(acc * scale + bias) + res): the mask multiplies by 0 or 1 / (1 - p).
+            const int c8 = lane & 7, rr8 = lane >> 3;
+            const int col = n0 + wn * 64 + c8 * 8;
+            if (col < p.N) {
+                f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
+                if (p.scale) { sc0 = *reinterpret_cast<const f32x4 *>(p.scale + col); sc1 = *reinterpret_cast<const f32x4 *>(p.scale + col + 4); }
+                if (p.bias) { bi0 = *reinterpret_cast<const f32x4 *>(p.bias + col); bi1 = *reinterpret_cast<const f32x4 *>(p.bias + col + 4); }
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int row = m0 + wm * 64 + it * 8 + rr8;
+                    if (row >= p.M) break;
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr8) * 68 + c8 * 8]);
+                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr8) * 68 + c8 * 8 + 4]);
+                    v0 = v0 * sc0 + bi0; v1 = v1 * sc1 + bi1;
+                    float m[8];
+                    s2d_dropout8((uint32_t)row, (uint32_t)(col >> 3), p.drop_stream, p.drop_k0, p.drop_k1, p.drop_thresh, p.drop_scale, m);
+                    v0[0] *= m[0]; v0[1] *= m[1]; v0[2] *= m[2]; v0[3] *= m[3];
+                    v1[0] *= m[4]; v1[1] *= m[5]; v1[2] *= m[6]; v1[3] *= m[7];
+                    if (res) {
+                        const float *rp = res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col;
+                        if (col < p.res_cols) v0 += *reinterpret_cast<const f32x4 *>(rp);
+                        if (col + 4 < p.res_cols) v1 += *reinterpret_cast<const f32x4 *>(rp + 4);
+                    }
+                    if (p.relu) {
+                        v0[0] = fmaxf(v0[0], 0.f); v0[1] = fmaxf(v0[1], 0.f); v0[2] = fmaxf(v0[2], 0.f); v0[3] = fmaxf(v0[3], 0.f);
+                        v1[0] = fmaxf(v1[0], 0.f); v1[1] = fmaxf(v1[1], 0.f); v1[2] = fmaxf(v1[2], 0.f); v1[3] = fmaxf(v1[3], 0.f);
+                    }
+                    *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v0;
+                    *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col + 4) = v1;
+                }
+            }
+            return;
+        }
         const int c4 = lane & 15, rr = lane >> 4;
         const int col = n0 + wn * 64 + c4 * 4;
         if (col < p.N) {
@@ -744,6 +776,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
         }
+        if (p.diag_release) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         return;
     }
     const int col = n0 + wn * 32 + l32;
@@ -774,19 +807,19 @@ int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
     return S2D_OK;
 }
 
-template <bool CONV, bool PIPE, bool BSPLIT>
+template <bool CONV, bool PIPE, bool BSPLIT, bool DROP = false>
 int launch_f16_v(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE, BSPLIT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE, BSPLIT, DROP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE, BSPLIT>), dim3(nwg, batch), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE, BSPLIT, DROP>), dim3(nwg, batch), dim3(256), lds, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -852,6 +885,9 @@ int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned in
 int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStream_t st, int f16)
 {
     GemmParams p = pin;
+    static int diag_rel = -1;
+    if (diag_rel < 0) { const char *e = getenv("S2D_DIAG_GEMM_RELEASE"); diag_rel = e ? atoi(e) : 0; }
+    p.diag_release = diag_rel;
     const long bA = conv ? (long)(p.M / ((long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 4L : ((long)(p.M - 1) * p.lda + p.K) * 4L;
     const long bB = ((long)(p.N - 1) * p.ldb + p.K) * 4L;
     if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets
@@ -859,6 +895,12 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (p.Bsplit) {
         if (!f16 || (batch > 1 && p.sB != 0) || (long)p.N * ((p.K + 31) / 32) * 128L > 0xFFFFFF00L) return S2D_ERR_ARG;
         p.kblocks = (p.K + 31) / 32;
+    }
+    if (p.drop_thresh) {
+        // fused dropout lives in the vector epilogue of the pipelined 128x128 split-fp16 kernel (the three encoder-layer
+        // GEMMs that carry it all dispatch there): 8-column mask blocks, 16-B aligned rows
+        if (!f16 || conv || ((p.N | p.ldc) & 7) || (p.res && (((p.ldr | p.res_cols) & 7)))) return S2D_ERR_ARG;
+        return p.Bsplit ? launch_f16_v<false, true, true, true>(p, batch, st) : launch_f16_v<false, true, false, true>(p, batch, st);
     }
     // 256-row tiles only when they still fill the chip
     if (f16) {

@@ -12,6 +12,7 @@ struct GemmParams {
     long ldr, sR;
     int res_rows, res_cols;   // residual row = row % res_rows (0: row); columns >= res_cols get no residual
     int relu;
+    int diag_release;         // DIAG: agent-scope release fence (buffer_wbl2 sc1) at the end of every wave (two-stream investigation)
     // implicit-GEMM convolution (A = NHWC input)
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     // byte extents of one batch slice of A and B (buffer-descriptor bounds of the split-bf16 kernel)
@@ -20,6 +21,11 @@ struct GemmParams {
     // padded past K; NULL = split on the fly
     const unsigned int *Bsplit;
     int kblocks;
+    // fused dropout of the epilogue value (after scale / bias, before the residual; commutes with the ReLU): the three
+    // nn.Dropout sites of the pixel decoder's encoder layers (msdeformattn.py:101-125).  drop_thresh 0 = off.
+    unsigned int drop_thresh;   // element kept iff its 16 random bits >= drop_thresh (= round(p * 65536))
+    float drop_scale;           // 1 / (1 - p)
+    unsigned int drop_k0, drop_k1, drop_stream;   // Philox key (the call's seed) and the stream id of this dropout site
 };
 
 

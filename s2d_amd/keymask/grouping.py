@@ -8,17 +8,11 @@ from sklearn.cluster import DBSCAN
 
 
 def get_visible_ranges(maj_vote):
-    vis = np.asarray(maj_vote).astype(bool).tolist()
-    ranges, start = [], None
-    for i, v in enumerate(vis):
-        if v and start is None:
-            start = i
-        elif not v and start is not None:
-            ranges.append((start, i - 1))
-            start = None
-    if start is not None:
-        ranges.append((start, len(vis) - 1))
-    return ranges
+    """inclusive (start, end) index pairs of the runs of ones in a 0/1 vector (identify_visibility_windows.py:65-88):
+    the rising and falling edges of the zero-padded vector, paired up"""
+    v = np.asarray(maj_vote).astype(bool).reshape(-1)
+    edges = np.flatnonzero(np.diff(np.concatenate(([0], v.view(np.int8), [0]))))
+    return [(int(a), int(b) - 1) for a, b in zip(edges[0::2], edges[1::2])]
 
 
 def get_highly_visible_rows(cluster_vis, runs, threshold=0.8):

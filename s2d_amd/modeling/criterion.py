@@ -97,7 +97,7 @@ class VideoHungarianMatcher(nn.Module):
 class VideoSetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses, num_points, oversample_ratio,
                  importance_sample_ratio, loss_strategy, reweight_distillation_loss=False,
-                 distillation_loss_strategy="masks-only", world_size=1):
+                 distillation_loss_strategy="masks-only", world_size=None):
         super().__init__()
         assert loss_strategy in ["masks-only", "full"]
         self.num_classes, self.matcher, self.weight_dict, self.eos_coef, self.losses = num_classes, matcher, weight_dict, eos_coef, losses
@@ -106,8 +106,14 @@ class VideoSetCriterion(nn.Module):
         self.register_buffer("empty_weight", empty_weight)
         self.num_points, self.oversample_ratio, self.importance_sample_ratio = num_points, oversample_ratio, importance_sample_ratio
         self.loss_strategy, self.distillation_loss_strategy = loss_strategy, distillation_loss_strategy
-        self.world_size = world_size
+        self.world_size = world_size            # None: detectron2's comm.get_world_size() at call time (criterion.py:409)
         self.seed = 0
+
+    def _world(self):
+        if self.world_size is not None:
+            return float(self.world_size)
+        import torch.distributed as dist
+        return float(dist.get_world_size()) if dist.is_available() and dist.is_initialized() else 1.0
 
     @torch.no_grad()
     def forward(self, outputs, targets, distillation=False, coords=None, keep_ctx=False):
@@ -125,7 +131,7 @@ class VideoSetCriterion(nn.Module):
         drop_aux = self.loss_strategy == "masks-only"
         self.seed += 1
         kw = dict(oversample=self.oversample_ratio, importance=self.importance_sample_ratio, coords_over=c.get("over"),
-                  coords_rand=c.get("rand"), seed=self.seed, world_size=float(self.world_size))
+                  coords_rand=c.get("rand"), seed=self.seed, world_size=self._world())
         losses = {}
         self.last_ctx = None
         if drop_last == drop_aux:

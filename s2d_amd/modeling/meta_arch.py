@@ -42,6 +42,9 @@ class MaskFormerHead(nn.Module):
 
     @classmethod
     def from_config(cls, cfg, input_shape=None):  # mask_former_head.py:87-113
+        if cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES != 1:
+            raise NotImplementedError("the class-loss and matcher kernels implement the class-agnostic S2D path "
+                                      "(SEM_SEG_HEAD.NUM_CLASSES: 1 in every shipped config; labels forced to 0, matcher.py:238-243)")
         return cls(MSDeformAttnPixelDecoder.from_config(cfg), VideoMultiScaleMaskedTransformerDecoder.from_config(
             cfg, cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM, True), cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES)
 
@@ -67,6 +70,53 @@ def _test_kwargs(mf, npred_name, eval_student=False):
     if eval_student:
         kw["eval_student"] = t.EVAL_STUDENT
     return kw
+
+
+class _HipGradBridge(torch.autograd.Function):
+    """Makes the HIP backward visible to autograd, so that the reference trainer's own statements work unchanged
+    (engine/train_loop.py:709-726: `loss_dict = self.model(data)`, `losses = sum(loss_dict.values())`,
+    `self.grad_scaler.scale(losses).backward()`), including DistributedDataParallel's gradient hooks
+    (engine/defaults.py:76-85), which hang on the parameters' AccumulateGrad nodes.
+
+    forward: identity on the stacked weighted losses; the student parameters are inputs only so that the graph reaches
+    them.  backward: returns, per parameter, the staged d(sum of losses)/d(parameter) the HIP kernels computed during the
+    forward call, times the incoming d(total)/d(loss).  The trainer differentiates a plain (scaled) sum, so every loss
+    receives the same upstream factor; anything else is refused rather than answered wrongly."""
+
+    @staticmethod
+    def forward(ctx, losses, holder, *params):
+        ctx.holder = holder
+        return losses.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        staged = ctx.holder.pop("grads", None)
+        if staged is None:
+            raise RuntimeError("the HIP gradients of this forward call were already consumed (backward twice, or a newer forward)")
+        g0 = g[0]
+        if not bool((g == g0).all()):
+            raise NotImplementedError("the losses of the HIP training forward must be reduced with equal weights (the trainer "
+                                      "sums them, train_loop.py:715); re-weight through criterion.weight_dict instead")
+        return (None, None) + tuple(gr * g0 for gr in staged)
+
+
+def _bridge_losses(model, params, run):
+    """run() = one forward_backward leaving d(sum of weighted losses)/dp in p.grad: stage those gradients (whatever the
+    caller had accumulated in .grad stays untouched) and return the loss dict as autograd-visible 0-dim tensors"""
+    saved = [p.grad for p in params]
+    for p in params:
+        p.grad = None
+    try:
+        out = run()
+        staged = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    finally:
+        for p, g in zip(params, saved):
+            p.grad = g
+    keys = list(out)
+    holder = {"grads": staged}
+    model._grad_holder = holder                    # a newer forward drops the previous call's staged gradients
+    stacked = _HipGradBridge.apply(torch.stack([out[k] for k in keys]), holder, *params)
+    return {k: stacked[i] for i, k in enumerate(keys)}
 
 
 def _frames_to_device(batched_inputs, device):
@@ -262,11 +312,19 @@ class KDVideoMaskFormer(nn.Module):
         return out
 
     def forward(self, batched_inputs):
+        """kd_video_maskformer_model.py:233-356.  Training: the weighted loss dict (:314-326).  With autograd enabled the
+        losses carry a graph to the student parameters (the backward runs on the HIP kernels inside this call and is handed
+        to autograd by _HipGradBridge), so `sum(loss_dict.values()).backward()` fills .grad as the reference trainer and
+        DistributedDataParallel expect; under torch.no_grad() only forward + loss run.  engine.run_step is the direct path
+        (same kernels, no staging copy of the gradients)."""
         images = self.preprocess(batched_inputs)
         if not self.training:
             return self.inference(images, batched_inputs)
         Hp, Wp = images.shape[1:3]
         gt = TargetSet.from_list(_gt_target_list(batched_inputs, self.num_frames, Hp, Wp, self.device), device=self.device)
+        params = [p for p in self.student.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and params:
+            return _bridge_losses(self, params, lambda: self.forward_backward(images, gt))
         return self.forward_losses(images, gt)
 
     @torch.no_grad()
@@ -377,6 +435,9 @@ class VideoMaskFormer(nn.Module):
                 return _inference(net, images, batched_inputs, self.num_predictions, self.use_nms, self.nms_threshold)
         Hp, Wp = images.shape[1:3]
         gt = TargetSet.from_list(_gt_target_list(batched_inputs, self.num_frames, Hp, Wp, self.device), device=self.device)
+        params = [p for p in list(self.backbone.parameters()) + list(self.sem_seg_head.parameters()) if p.requires_grad]
+        if torch.is_grad_enabled() and params:                          # see KDVideoMaskFormer.forward
+            return _bridge_losses(self, params, lambda: self.forward_backward(images, gt))
         return self.forward_losses(images, gt)
 
 

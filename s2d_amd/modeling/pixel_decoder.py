@@ -60,9 +60,10 @@ class MSDeformAttn(nn.Module):
             self._packed = (key, ops.mark_static(w_all), b_all, ops.mark_static(w_oa), b_oa)
         return self._packed[1:]
 
-    def forward_fused(self, src, pos, shapes, res, tape=None):
+    def forward_fused(self, src, pos, shapes, res, tape=None, dropout=None):
         """self-attention over the flattened pyramid with query = src + pos (query positions == value positions;
-        pos [S, C] is shared by all N frames).  Returns output_proj(msda(...)) + res.
+        pos [S, C] is shared by all N frames).  Returns dropout(output_proj(msda(...))) + res (dropout = (p, seed, site) or
+        None: the encoder layer's dropout1, msdeformattn.py:125, fused into the projection's epilogue).
         (src + pos) . W_oa^T = src . W_oa^T + pos . W_oa^T: the second term is one small [S, 288] product per layer and
         enters the merged projection as a row-periodic residual, so src is read once and src + pos is never stored."""
         N, S, C = src.shape
@@ -71,24 +72,25 @@ class MSDeformAttn(nn.Module):
         pos_oa = ops.gemm_nt(pos.view(S, C), w_oa, bias=b_oa)
         both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa).view(N, S, n_oa + C)
         samp = ops.msda_fused_forward(both[..., n_oa:], shapes, both[..., :n_oa], self.n_heads, self.n_points)
-        out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C))
+        out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C), dropout=dropout)
         if tape is not None:
-            tape.append((self, src, pos, shapes, both, samp))
+            tape.append((self, src, pos, shapes, both, samp, dropout))
         return out.view(N, S, C)
 
     def backward_fused(self, saved, d_out):
         """d(src) (the attention input, including the residual path res == src) and d(pos) [S,C] from d(output);
         parameter gradients accumulate into .grad.  Mirrors forward_fused step by step."""
         from .. import backward as B
-        _, src, pos, shapes, both, samp = saved
+        _, src, pos, shapes, both, samp, drop = saved
         N, S, C = src.shape
         w_all, _, w_oa, _ = self.packed()
         n_oa = w_oa.shape[0]
         n_off = self.sampling_offsets.weight.shape[0]
-        d2 = d_out.reshape(-1, C)
-        B.acc(self.output_proj.weight, B.weight_grad(d2, samp.view(-1, C)))
-        B.acc(self.output_proj.bias, B.bias_grad(d2))
-        d_samp = B.input_grad(d2, self.output_proj.weight).view(N, S, C)
+        d2 = d_out.reshape(-1, C)                                         # d(src + dropout1(proj)): the residual path takes it as is
+        dm = d2 if drop is None or drop[0] <= 0.0 else ops.dropout(d2, *drop)   # d(proj): the forward's mask, regenerated
+        B.acc(self.output_proj.weight, B.weight_grad(dm, samp.view(-1, C)))
+        B.acc(self.output_proj.bias, B.bias_grad(dm))
+        d_samp = B.input_grad(dm, self.output_proj.weight).view(N, S, C)
         d_val, d_oa = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points)
         d_both = torch.cat([d_oa, d_val], -1).view(-1, n_oa + C)
         dw = B.weight_grad(d_both, src.view(-1, C))                       # rows: offsets | logits | value
@@ -137,30 +139,42 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.dropout_p = dropout
 
     def forward(self, src, pos, shapes, tape=None):
-        """msdeformattn.py:122-131 (post-norm).  src [N,S,C], pos [S,C]."""
-        if self.dropout_p:
-            raise NotImplementedError("dropout > 0 (training noise) is not on the measured fwd+loss parity path; "
-                                      "set MODEL.MASK_FORMER.DROPOUT 0.0 (SURVEY.md Appendix C)")
+        """msdeformattn.py:116-131 (post-norm).  src [N,S,C], pos [S,C].
+        src = norm1(src + dropout1(attn));  src = norm2(src + dropout3(linear2(dropout2(relu(linear1(src))))))  (:101-125).
+        In training mode with p > 0 the three masks are counter-based (csrc/dropout.h: one Philox key per call, sites 0..2)
+        and applied in the epilogues of the three GEMMs; the backward regenerates them.  Eval mode: identity, as nn.Dropout."""
         N, S, C = src.shape
+        p = float(self.dropout_p) if self.training else 0.0
+        seed = ops.next_dropout_seed() if p > 0.0 else 0
+        d1, d2, d3 = ((p, seed, 0), (p, seed, 1), (p, seed, 2)) if p > 0.0 else (None, None, None)
         sub = [] if tape is not None else None
-        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub)
+        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1)
         s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
-        h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True)
-        x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C)).view(N, S, C)
+        h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True, dropout=d2)
+        x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C), dropout=d3).view(N, S, C)
         if tape is not None:
-            tape.append((self, sub[0], x1, s1, h, x2))
+            tape.append((self, sub[0], x1, s1, h, x2, (p, seed)))
         return ops.layernorm(x2, self.norm2.weight, self.norm2.bias)
+
+    def _drop_scale(self, p, like):
+        key = (p, like.shape[-1], like.device)
+        if getattr(self, "_ds", (None,))[0] != key:
+            self._ds = (key, torch.full((like.shape[-1],), 1.0 / (1.0 - p), device=like.device, dtype=torch.float32))
+        return self._ds[1]
 
     def backward(self, saved, d_out):
         """-> (d_src, d_pos)"""
         from .. import backward as B
-        _, attn_saved, x1, s1, h, x2 = saved
+        _, attn_saved, x1, s1, h, x2, (p, seed) = saved
         N, S, C = x1.shape
         d_x2, dg, db = B.layernorm_backward(x2, d_out.contiguous(), self.norm2.weight)
         B.acc(self.norm2.weight, dg); B.acc(self.norm2.bias, db)
-        d2 = d_x2.view(-1, C)
-        B.acc(self.linear2.weight, B.weight_grad(d2, h)); B.acc(self.linear2.bias, B.bias_grad(d2))
-        d_h = B.relu_scale_backward(B.input_grad(d2, self.linear2.weight), h)
+        d2 = d_x2.view(-1, C)                                           # d(s1 + dropout3(linear2)): the residual takes it as is
+        dm = ops.dropout(d2, p, seed, 2) if p > 0.0 else d2               # d(linear2 output)
+        B.acc(self.linear2.weight, B.weight_grad(dm, h)); B.acc(self.linear2.bias, B.bias_grad(dm))
+        # h = dropout2(relu(z)) = relu(z) * m / (1 - p): positive exactly where the unit is active AND kept, so the ReLU
+        # gate on h is the combined gate and the dropout factor is a constant per-channel scale
+        d_h = B.relu_scale_backward(B.input_grad(dm, self.linear2.weight), h, scale=self._drop_scale(p, h) if p > 0.0 else None)
         B.acc(self.linear1.weight, B.weight_grad(d_h, s1.view(-1, C))); B.acc(self.linear1.bias, B.bias_grad(d_h))
         d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
         d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)

@@ -102,12 +102,25 @@ def set_dense_mode(mode):
     _MODE = mode
 
 
-def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0):
+def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0, dropout=None):
     """out[..., M, N] = act(A[..., M, K] @ B[(...), N, K]^T * scale + bias + res).
     A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch).  res_rows > 0: res is [res_rows, ldr] and row r of the
-    output receives res[r % res_rows]; res_cols > 0: only the first res_cols columns receive it (ldr = res.shape[-1])."""
+    output receives res[r % res_rows]; res_cols > 0: only the first res_cols columns receive it (ldr = res.shape[-1]).
+    dropout = (p, seed, site): act(dropout_p(A @ B^T + bias) + res) with the counter-based mask of csrc/dropout.h fused into
+    the epilogue (2-D operands, N % 8 == 0)."""
     for t in (A, B, scale, bias, res, out):
         _chk(t)
+    if dropout is not None and dropout[0] > 0.0:
+        p, seed, site = dropout
+        assert A.dim() == 2 and B.dim() == 2 and scale is None and not res_rows and not res_cols
+        M, K = A.shape
+        N = B.shape[0]
+        if out is None:
+            out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (2 if res is not None else 1)))):
+            lib().call("s2d_gemm_nt_dropout_f32", A, B, out, M, N, K, K, K, out.shape[-1], bias, res, res.shape[-1] if res is not None else N,
+                       int(relu), _static_split(B, N, K, K), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), _stream())
+        return out
     batched = A.dim() == 3
     bs = A.shape[0] if batched else 1
     M, K = A.shape[-2:]
@@ -127,6 +140,25 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
         lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, ldr,
                    res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), Bs, _stream())
     return out
+
+
+def dropout(x, p, seed, site, out=None):
+    """x [M, N] * mask / (1 - p): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
+    _chk(x)
+    M, N = x.shape
+    y = torch.empty_like(x) if out is None else out
+    lib().call("s2d_dropout_f32", x, M, N, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), y, _stream())
+    return y
+
+
+_DROP_CALLS = [0]
+
+
+def next_dropout_seed():
+    """a fresh 64-bit Philox key per dropout-carrying forward call: torch's seed (torch.manual_seed makes runs repeatable)
+    mixed with a per-process call counter"""
+    _DROP_CALLS[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
 def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=False):

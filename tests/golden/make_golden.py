@@ -623,12 +623,52 @@ def g_idmaps():
     save("idmaps", seed=seed, frames=frames, ids=out.numpy().astype(np.int16), n_ids=np.array([int(out[t].max()) for t in range(T)]))
 
 
+def g_config():
+    """the shipped KD training configuration as the trainer resolves it: configs/imagenet_video/
+    ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml merged over its _BASE_ (yaml data, key -> value; python tuples
+    become lists).  The from_config methods of the drop-in meta-architecture are tested on exactly these keys."""
+    import json
+    import yaml
+
+    class L(yaml.SafeLoader):
+        pass
+    L.add_constructor("tag:yaml.org,2002:python/tuple", lambda l, n: list(l.construct_sequence(n)))
+    d = os.path.join(R.ROOT if hasattr(R, "ROOT") else "/root/reference", "model_training", "configs", "imagenet_video")
+
+    def fix(v):
+        if isinstance(v, dict):
+            return {k: fix(x) for k, x in v.items()}
+        if isinstance(v, str) and v.startswith("(") and v.endswith(")"):          # yacs evaluates "(360, 480)" literals
+            import ast
+            return list(ast.literal_eval(v))
+        return v
+
+    def load(name):
+        c = fix(yaml.load(open(os.path.join(d, name)), Loader=L))
+        base = c.pop("_BASE_", None)
+        if base:
+            b = load(base)
+
+            def merge(a, o):
+                for k, v in o.items():
+                    if isinstance(v, dict) and isinstance(a.get(k), dict):
+                        merge(a[k], v)
+                    else:
+                        a[k] = v
+                return a
+            c = merge(b, c)
+        return c
+    cfg = load("ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml")
+    with open(os.path.join(HERE, "kd_config.json"), "w") as f:
+        json.dump(cfg, f, indent=1, sort_keys=True)
+
+
 def main():
     assert R.available(), "/root/reference not present: goldens can only be generated in the build container"
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -243,14 +243,20 @@ def test_msda_fused_backward_vs_autograd(shapes, N):
     assert rel(doa.cpu().numpy(), od.grad.numpy()) < 1e-5
 
 
-def test_pixel_decoder_backward_vs_autograd():
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_pixel_decoder_backward_vs_autograd(p_drop):
     """MSDeformAttnPixelDecoder.backward_features (input projections + GN, 2 deformable encoder layers, FPN level with
-    upsample-add, mask_features) against autograd through a float64 torch restatement of msdeformattn.py:314-358"""
+    upsample-add, mask_features) against autograd through a float64 torch restatement of msdeformattn.py:314-358.
+    p_drop = 0.3 (the shipped MODEL.MASK_FORMER.DROPOUT): training mode, the three nn.Dropout sites of every encoder layer
+    (:101-125) active; the restatement multiplies by the oracle's restatement of the same counter-based masks (seeds read
+    from the forward's tape), so forward and every gradient must still agree."""
     import torch.nn.functional as F
+    from oracle import oracle_np as O
     from s2d_amd.modeling import MSDeformAttnPixelDecoder
     from s2d_amd import ops
     torch.manual_seed(0)
-    pd = MSDeformAttnPixelDecoder(transformer_enc_layers=2)
+    pd = MSDeformAttnPixelDecoder(transformer_enc_layers=2, transformer_dropout=p_drop)
+    pd.train()
     with torch.no_grad():
         for n_, p in pd.named_parameters():                            # zero-initialised projections would hide gradient paths
             if p.abs().max() == 0:
@@ -266,6 +272,20 @@ def test_pixel_decoder_backward_vs_autograd():
     Fd = {k: v.double().requires_grad_(True) for k, v in feats.items()}
     pe = [ops.pe_sine(0, h, w, 128, add_c=torch.zeros(256, device=DEV), device=torch.device(DEV)).cpu().double() for h, w in shapes]
 
+    pd = pd.to(DEV)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    tape = []
+    mf_h, ms = pd.forward_features({k: nhwc(v) for k, v in feats.items()}, tape)
+    S_tok = sum(h * w for h, w in shapes)
+    seeds = [rec[-1] for rec in tape[0][3]]                              # per encoder layer: (p, seed)
+    assert all(abs(p_ - p_drop) < 1e-9 for p_, _ in seeds)
+
+    def drop(x, li, site):                                               # nn.Dropout with the library's mask stream
+        if p_drop == 0.0:
+            return x
+        m = O.dropout_multipliers(N * S_tok, x.shape[-1], p_drop, seeds[li][1], site)
+        return x * torch.from_numpy(m).double().view(x.shape)
+
     srcs = []
     for idx, f in enumerate(("res5", "res4", "res3")):
         y = F.conv2d(Fd[f], P[f"input_proj.{idx}.0.weight"], P[f"input_proj.{idx}.0.bias"])
@@ -279,8 +299,8 @@ def test_pixel_decoder_backward_vs_autograd():
         lin = lambda x, n: F.linear(x, P[pre + n + ".weight"], P[pre + n + ".bias"])
         oa = torch.cat([lin(q, "self_attn.sampling_offsets"), lin(q, "self_attn.attention_weights")], -1)
         samp = _msda_fused_torch(lin(src, "self_attn.value_proj"), shapes, oa)
-        s1 = F.layer_norm(lin(samp, "self_attn.output_proj") + src, (C,), P[pre + "norm1.weight"], P[pre + "norm1.bias"])
-        x2 = lin(torch.relu(lin(s1, "linear1")), "linear2") + s1
+        s1 = F.layer_norm(drop(lin(samp, "self_attn.output_proj"), li, 0) + src, (C,), P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+        x2 = drop(lin(drop(torch.relu(lin(s1, "linear1")), li, 1), "linear2"), li, 2) + s1
         src = F.layer_norm(x2, (C,), P[pre + "norm2.weight"], P[pre + "norm2.bias"])
     outs, o = [], 0
     for (h, w) in shapes:
@@ -294,10 +314,6 @@ def test_pixel_decoder_backward_vs_autograd():
     d_outs = [torch.randn(o_.shape, generator=g) for o_ in outs]
     ((mf * d_mf.double()).sum() + sum((o_ * d.double()).sum() for o_, d in zip(outs, d_outs))).backward()
 
-    pd = pd.to(DEV)
-    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
-    tape = []
-    mf_h, ms = pd.forward_features({k: nhwc(v) for k, v in feats.items()}, tape)
     assert rel(mf_h.permute(0, 3, 1, 2).cpu().numpy(), mf.detach().numpy()) < 1e-5
     grads = pd.backward_features(tape[0], nhwc(d_mf), [d.to(DEV) for d in d_outs])
     for k in ("res2", "res3", "res4", "res5"):

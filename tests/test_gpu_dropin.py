@@ -1,0 +1,253 @@
+"""The drop-in boundary on the GPU: fused counter-based dropout (the three nn.Dropout sites of the encoder
+layers, msdeformattn.py:101-125), the autograd-visible training forward the reference trainer drives
+(engine/train_loop.py:709-726), the `MultiScaleDeformableAttention` module / `MSDeformAttnFunction` under the reference's
+call signatures (ops/functions/ms_deform_attn_func.py:32-49), the model built from the literal keys of the shipped
+ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml (tests/golden/kd_config.json), and prepare_targets (A8)."""
+import json
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle_np
+    return oracle_np
+
+
+# ------------------------------------------------------------------------------------------------ dropout
+@pytest.mark.parametrize("M,N,p,seed,site", [(1000, 256, 0.3, 0x1234567890ABCDEF, 0), (777, 1024, 0.3, 42, 1), (333, 8, 0.1, 2 ** 63 + 5, 2),
+                                              (64, 256, 0.0, 7, 0)])
+def test_dropout_mask_vs_oracle(oracle, M, N, p, seed, site):
+    """the device mask is bit-for-bit the oracle's restatement (Philox4x32-10 pinned by Random123's known answers)"""
+    from s2d_amd import ops
+    m = ops.dropout(torch.ones((M, N), device=DEV), p, seed, site).cpu().numpy()
+    np.testing.assert_array_equal(m, oracle.dropout_multipliers(M, N, p, seed, site))
+
+
+def test_dropout_statistics():
+    """p = 0.3 (the shipped MODEL.MASK_FORMER.DROPOUT): keep rate, scale, and independence between rows, columns, sites and
+    calls, at the size of one encoder-layer activation"""
+    from s2d_amd import ops
+    M, N, p = 19320 * 2, 256, 0.3
+    ones = torch.ones((M, N), device=DEV)
+    a = ops.dropout(ones, p, 1111, 0)
+    b = ops.dropout(ones, p, 1111, 1)                  # another site of the same call
+    c = ops.dropout(ones, p, 2222, 0)                  # another call
+    n = M * N
+    q = 1.0 - round(p * 65536) / 65536.0
+    sd = (q * (1 - q) / n) ** 0.5
+    for m in (a, b, c):
+        keep = (m > 0).double().mean().item()
+        assert abs(keep - q) < 5 * sd, (keep, q)
+        vals = torch.unique(m)
+        assert vals.numel() == 2 and vals[0] == 0 and abs(vals[1].item() - 1 / (1 - p)) < 1e-6
+        assert abs(m.double().mean().item() - q / (1 - p)) < 5 * sd / (1 - p)          # E[x * mask / (1-p)] = x (up to p's 16-bit rounding)
+    ka, kb, kc = (a > 0).double(), (b > 0).double(), (c > 0).double()
+    for x, y in ((ka, kb), (ka, kc), (ka[:, :-1], ka[:, 1:]), (ka[:-1], ka[1:]), (ka[:, ::8][:, :-1], ka[:, ::8][:, 1:])):
+        cov = ((x - q) * (y - q)).mean().item()
+        assert abs(cov) < 5 * q * (1 - q) / x.numel() ** 0.5, cov
+    rows, cols = ka.mean(1), ka.mean(0)                # no dead / always-on rows or columns
+    assert (rows - q).abs().max() < 6 * (q * (1 - q) / N) ** 0.5 and (cols - q).abs().max() < 6 * (q * (1 - q) / M) ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K,relu,res,static", [(1000, 256, 256, False, True, True), (5000, 1024, 256, True, False, True),
+                                                    (777, 256, 1024, False, True, True), (130, 64, 96, True, True, False)])
+def test_gemm_dropout_epilogue_bitwise(M, N, K, relu, res, static):
+    """act(dropout(A W^T + b) + res) in the GEMM epilogue == the same GEMM, then the mask applied elementwise (the three
+    encoder-layer shapes: output_proj, linear1 + ReLU, linear2)"""
+    from s2d_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn((M, K), generator=g).to(DEV)
+    W = torch.randn((N, K), generator=g).mul_(K ** -0.5).to(DEV)
+    if static:
+        W = torch.nn.Parameter(W)
+    b = torch.randn((N,), generator=g).to(DEV)
+    R = torch.randn((M, N), generator=g).to(DEV) if res else None
+    p, seed, site = 0.3, 987654321, 2
+    y = ops.gemm_nt(A, W, bias=b, res=R, relu=relu, dropout=(p, seed, site))
+    ref = ops.gemm_nt(A, W, bias=b) * ops.dropout(torch.ones((M, N), device=DEV), p, seed, site)
+    if res:
+        ref = ref + R
+    if relu:
+        ref = torch.relu(ref)
+    assert torch.equal(y, ref)
+    assert torch.equal(ops.gemm_nt(A, W, bias=b, res=R, relu=relu, dropout=(0.0, seed, site)), ops.gemm_nt(A, W, bias=b, res=R, relu=relu))
+
+
+def test_encoder_layer_eval_mode_is_identity_dropout():
+    """nn.Dropout is the identity in eval mode: a p = 0.3 layer in eval() equals the p = 0 layer bit for bit"""
+    from s2d_amd.modeling.pixel_decoder import MSDeformAttnTransformerEncoderLayer
+    from s2d_amd import ops
+    torch.manual_seed(1)
+    a = MSDeformAttnTransformerEncoderLayer(dropout=0.3).to(DEV).eval()
+    b = MSDeformAttnTransformerEncoderLayer(dropout=0.0).to(DEV).eval()
+    b.load_state_dict(a.state_dict())
+    shapes = [(4, 6), (8, 12), (16, 24)]
+    S = sum(h * w for h, w in shapes)
+    src = torch.randn((2, S, 256), device=DEV)
+    pos = torch.randn((S, 256), device=DEV)
+    shp = torch.tensor(shapes, dtype=torch.int64)
+    assert torch.equal(a(src, pos, shp), b(src, pos, shp))
+    a.train()
+    y1, y2 = a(src, pos, shp), a(src, pos, shp)                       # training mode: fresh masks per call
+    assert not torch.equal(y1, y2) and not torch.equal(y1, b(src, pos, shp))
+
+
+# ------------------------------------------------------------------------------------------------ MSDA module / function
+def test_msda_compat_module_and_function(oracle):
+    """the reference's FFI names and call signatures (ops/src/vision.cpp:18-21; ms_deform_attn_func.py:32-49), values vs the
+    goldens the reference's own core produced, and the extension's error conventions (ms_deform_attn_cuda.cu:33-57)"""
+    import s2d_amd.compat as compat
+    compat.install()
+    import MultiScaleDeformableAttention as MSDA                       # the reference's import name
+    from s2d_amd.compat.ms_deform_attn_func import MSDeformAttnFunction
+    g = golden("msda_core")
+    dev = torch.device(DEV)
+    shapes = torch.as_tensor(g["shapes"], dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    v, loc, w = (torch.from_numpy(g[k]).to(dev) for k in ("value", "loc", "w"))
+    out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 128)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=1e-5)
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, w, torch.from_numpy(g["grad_out"]).to(dev), 128)
+    vr, lr, wr = v.clone().requires_grad_(True), loc.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    o2 = MSDeformAttnFunction.apply(vr, shapes, lsi, lr, wr, 128)
+    assert torch.equal(o2, out)
+    (o2 * torch.from_numpy(g["grad_out"]).to(dev)).sum().backward()
+    for got, got2, name in ((gv, vr.grad, "grad_value"), (gl, lr.grad, "grad_loc"), (gw, wr.grad, "grad_w")):
+        ref = g[name]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+        assert torch.equal(got, got2)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.permute(0, 1, 3, 2), shapes, lsi, loc, w, 128)      # not contiguous
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.cpu(), shapes, lsi, loc, w, 128)                    # not on the device
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(torch.cat([v, v[:1]]), shapes, lsi, torch.cat([loc, loc[:1]]), torch.cat([w, w[:1]]), 2)   # 3 % 2
+
+
+# ------------------------------------------------------------------------------------------------ A8 prepare_targets
+def test_prepare_targets_product_path_vs_reference_golden():
+    """_gt_target_list + TargetSet.from_list (the product's prepare_targets, kd_video_maskformer_model.py:358-386) against the
+    reference's own output (tests/golden/prepare_targets.npz): padded bit planes, dropped never-present instance, counts,
+    and the DropLoss predicate"""
+    from s2d_amd.modeling import TargetSet
+    from s2d_amd.modeling.meta_arch import _gt_target_list
+    from s2d_amd.utils import synth
+    g = golden("prepare_targets")
+    T, H0, W0, Hp, Wp, n = (int(v) for v in g["dims"])
+    m, ids = synth.ellipse_targets(int(g["seed"]), 1, n, T, H0, W0, sparse=0.6)
+    ids[2, :] = -1
+    m[2] = 0
+    inst = [{"gt_masks": torch.from_numpy(m[:, t]).bool(), "gt_ids": torch.from_numpy(ids[:, t]),
+             "gt_classes": torch.zeros(n, dtype=torch.int64)} for t in range(T)]
+    lst = _gt_target_list([{"instances": inst}], T, Hp, Wp, torch.device(DEV))
+    want = np.unpackbits(g["masks"], axis=-1)[..., :Wp]
+    assert lst[0].shape[0] == int(g["n_out"])
+    np.testing.assert_array_equal(lst[0].cpu().numpy(), want)
+    ts = TargetSet.from_list(lst, device=DEV)
+    assert ts.count.cpu().tolist() == [int(g["n_out"])] and ts.host_counts == [int(g["n_out"])]
+    np.testing.assert_array_equal(ts.masks[0, :int(g["n_out"])].cpu().numpy(), want)
+    np.testing.assert_array_equal(ts.nonempty[0].cpu().numpy() != 0, want.reshape(want.shape[0], T, -1).any(-1))
+    # detectron2-style Instances objects (attribute access, BitMasks with .tensor) take the same path
+    objs = [NS(gt_masks=NS(tensor=i["gt_masks"]), gt_ids=i["gt_ids"], gt_classes=i["gt_classes"]) for i in inst]
+    lst2 = _gt_target_list([{"instances": objs}], T, Hp, Wp, torch.device(DEV))
+    assert torch.equal(lst2[0], lst[0])
+
+
+# ------------------------------------------------------------------------------------------------ shipped config + trainer statements
+def _ns(d):
+    return NS(**{k: _ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def _shipped_cfg():
+    return _ns(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kd_config.json"))))
+
+
+def _clip_batch(T, H0, W0, n, seed, B=1):
+    from s2d_amd.utils import synth
+    data = []
+    for b in range(B):
+        fr = synth.smooth_frames_u8(seed + b, 1, T, H0, W0)                         # [T,3,H0,W0]
+        m, ids = synth.ellipse_targets(seed + b, 2, n, T, H0, W0, sparse=0.3)
+        inst = [{"gt_masks": torch.from_numpy(m[:, t]).bool(), "gt_ids": torch.from_numpy(ids[:, t]),
+                 "gt_classes": torch.zeros(n, dtype=torch.int64)} for t in range(T)]
+        data.append({"image": [torch.from_numpy(fr[t]) for t in range(T)], "instances": inst, "height": H0, "width": W0})
+    return data
+
+
+def test_shipped_config_trains_with_the_reference_trainer_statements():
+    """KDVideoMaskFormer built by the registry from the literal keys of the shipped KD yaml (DROPOUT 0.3, 160 000 points,
+    3 frames, masks-only DropLoss) and driven by the reference trainer's own statements (train_loop.py:709-726):
+        loss_dict = model(data); losses = sum(loss_dict.values()); grad_scaler.scale(losses).backward(); optimizer.step()
+    with a stock torch optimizer.  The gradients autograd delivers are the HIP backward's, bit for bit."""
+    from s2d_amd import ops
+    from s2d_amd.modeling.meta_arch import META_ARCH_REGISTRY
+    cfg = _shipped_cfg()
+    assert cfg.MODEL.MASK_FORMER.DROPOUT == 0.3 and cfg.MODEL.META_ARCHITECTURE == "KDVideoMaskFormer"
+    torch.manual_seed(0)
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE).from_config(cfg).to(DEV)
+    model.teacher.load_state_dict(model.student.state_dict())
+    with torch.no_grad():
+        model.teacher[1].predictor.class_embed.bias.copy_(torch.tensor([2.0, -2.0]))       # some queries pass the 0.75 KD threshold
+    model.train()
+    T = cfg.INPUT.SAMPLING_FRAME_NUM
+    data = _clip_batch(T, 64, 96, 3, seed=5, B=2)
+    students = [p for p in model.student.parameters()]
+
+    def seeded():
+        torch.manual_seed(123); ops._DROP_CALLS[0] = 0
+        model.criterion.seed = 0; model.criterion.matcher.seed = 0
+
+    # the reference trainer's statements
+    opt = torch.optim.AdamW(students, lr=1e-4)
+    scale = 1024.0                                                             # a GradScaler's loss scale
+    seeded()
+    loss_dict = model(data)
+    assert len(loss_dict) == 42 and all(v.dim() == 0 and v.requires_grad for v in loss_dict.values())
+    losses = sum(loss_dict.values())
+    (losses * scale).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in students)
+    assert all(p.grad is None for p in model.teacher.parameters())
+    got = [p.grad.clone() for p in students]
+    # the direct path with the same seeds: forward_backward leaves d(sum)/dp in .grad
+    for p in students:
+        p.grad = None
+    seeded()
+    from s2d_amd.modeling import TargetSet
+    from s2d_amd.modeling.meta_arch import _gt_target_list
+    images = model.preprocess(data)
+    gt = TargetSet.from_list(_gt_target_list(data, T, images.shape[1], images.shape[2], model.device), device=model.device)
+    direct = model.forward_backward(images, gt)
+    assert all(float(direct[k]) == float(loss_dict[k]) for k in direct)
+    for p, g in zip(students, got):
+        assert torch.equal(g, p.grad * scale)
+    # an optimizer step moves the student; accumulation into existing .grad works like autograd's
+    before = [p.detach().clone() for p in students[:8]]
+    for p, g in zip(students, got):
+        p.grad = g / scale
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, students[:8]))
+    seeded()
+    keep = [p.grad.clone() for p in students[:8]]
+    sum(model(data).values()).backward()
+    for p, k in zip(students[:8], keep):
+        assert not torch.equal(p.grad, k)                                      # accumulated on top of the stale .grad
+    # unequal upstream weights are refused, not answered wrongly
+    ld = model(data)
+    with pytest.raises(NotImplementedError):
+        (ld["loss_mask"] * 2 + ld["loss_dice"]).backward()
+    # no graph, no backward work under no_grad; eval mode returns the inference dict (dropout inactive)
+    with torch.no_grad():
+        assert not any(v.requires_grad for v in model(data).values())
+    model.eval()
+    out = model(data[:1])
+    assert set(out) >= {"image_size", "pred_scores", "pred_labels", "pred_masks"}

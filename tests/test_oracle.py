@@ -402,3 +402,22 @@ def test_color_masks_to_ids_golden(oracle):
     assert out.dtype == np.int64 and out.shape == g["ids"].shape
     np.testing.assert_array_equal(out, g["ids"])
     assert [int(out[t].max()) for t in range(out.shape[0])] == g["n_ids"].tolist()
+
+
+# ------------------------------------------------------------------ counter-based dropout (the oracle's generator)
+def test_philox4x32_10_known_answers(oracle):
+    """Random123's published known-answer vectors for Philox4x32-10 (kat_vectors: zero, all-ones and pi-digit inputs) pin the
+    generator the dropout masks are drawn from (oracle and csrc/dropout.h share the definition; the device side is checked
+    against the oracle bit for bit in tests/test_gpu_dropin.py)"""
+    u = np.uint32
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = oracle.philox4x32_10(u(c[0]), u(c[1]), u(c[2]), u(c[3]), k[0], k[1])
+        assert tuple(int(x) for x in got) == want
+    m = oracle.dropout_multipliers(2000, 256, 0.3, 99, 1)
+    keep = (m > 0).mean()
+    assert abs(keep - (1 - 19661 / 65536)) < 5 * (0.21 / m.size) ** 0.5
+    assert set(np.unique(m).tolist()) == {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))}
+    assert np.array_equal(oracle.dropout_multipliers(16, 64, 0.0, 1, 0), np.ones((16, 64), np.float32))
