@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- clip-frames/s of the S2D hot path on MI355X: KDVideoMaskFormer forward + distillation loss
 (student fwd + teacher fwd + GT criterion + KD targets + KD criterion), R50 M2F-Video, T=8, 720p (736x1280 padded),
-Q=100, P=160000, 2 clips per GPU (BASELINE.json configs[3] shapes; forward+loss as BASELINE.json:metric says).
+Q=100, P=160000, 2 clips per GPU (BASELINE.json configs[3] shapes; forward+loss as BASELINE.json:metric says), encoder
+dropout 0.3 as every shipped config sets it (MODEL.MASK_FORMER.DROPOUT).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Launched by `python -m torch.distributed.run ... bench.py --gpus N ...` the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE; launched plainly with --gpus N > 1 this script starts those N ranks itself (child
+processes, before this process touches a GPU) and exits with their status.
 
 One "step" = one pass of the hot path over one batch (2 clips x 8 frames per GPU) of synthetic input that is already
 resident in HBM.  Clips are independent units: ranks shard clips, forward+loss needs no collective (scaling: weak).
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE JSON line: the metric, `roofline` (dense kernels, live HIP events), `hbm_roofline` (whole step),
+`train_step` (one full training iteration incl. the RCCL gradient all-reduce at N > 1), `keymask` (BASELINE configs[2]
+kernel set, N = 1), `cpu_baseline` (N = 1).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,38 +42,61 @@ DENSE_DESC = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
               "bf16x3": "split-bf16 x3 on v_mfma_f32_32x32x16_bf16 (3 MFMA flops per algorithmic flop)"}
 
 
-def train_step_report(model, frames, masks, mean, std, dev, iters=3):
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as children (nothing in this process has touched the GPU yet)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3):
+    """one FULL training iteration per rank on its batch: forward + loss (student + teacher, GT + KD) + the student's backward
+    on the HIP gradient kernels + SUM all-reduce of the flat gradient arena over the ranks (RCCL at N > 1; the mean is folded
+    into the optimizer's inv_scale) + full-model clip + AdamW + EMA teacher update.  Time = max over ranks."""
     from s2d_amd import ops
     from s2d_amd.modeling import TargetSet
     from s2d_amd.optim import FullModelGradientClippingAdamW, param_groups_like_reference
-    model.overlap_teacher = model.overlap_criteria = False          # one stream (a second one gains 2 ms here and splits the allocator's pools)
+    model.overlap_teacher = model.overlap_criteria = False
     model.last = None
     torch.cuda.synchronize()
-    torch.cuda.empty_cache()     # the metric's two-stream phase left its blocks in per-stream pools; start this phase from a clean pool
+    torch.cuda.empty_cache()
     groups = param_groups_like_reference(model.student, 1e-4, 0.05)
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
-    losses, times = [], []
-    st0 = torch.cuda.memory_stats()
+    losses, times, t_ar = [], [], []
     WARM = 2                                            # the caching allocator still calls hipMalloc in the second iteration
+    st0 = torch.cuda.memory_stats()
     for i in range(iters + WARM):
         if i == WARM:
             st0 = torch.cuda.memory_stats()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _fence(world)
+        t0 = time.perf_counter()
         images = ops.normalize_pad(frames, 32, mean, std)
         targets = TargetSet.from_list(masks, device=dev)
         opt.zero_grad()
         out = model.forward_backward(images, targets)
-        opt.step(inv_scale=opt.allreduce_grads(), ema_momentum=0.999)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        inv = opt.allreduce_grads()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.step(inv_scale=inv, ema_momentum=0.999)
         tot = float(sum(out.values()))
-        torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(round(tot, 4))
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0); t_ar.append(t2 - t1); losses.append(round(tot, 4))
     assert all(map(lambda v: v == v and abs(v) != float("inf"), losses)) and not opt.found_inf()
-    ms = 1000 * sum(times[WARM:]) / iters
-    return {"what": "one full training iteration on the same batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
-                    "(HIP gradient kernels, no autograd graph) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
-            "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(frames.shape[0] / (ms / 1000), 2), "iterations": iters, "warmup_iterations": WARM,
-            "loss_per_iteration": losses, "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "ms_each": [round(1000 * t, 1) for t in times],
+    ms = 1000 * _max_over_ranks(sum(times[WARM:]) / iters, world, cdev or dev)
+    ar = 1000 * _max_over_ranks(sum(t_ar[WARM:]) / iters, world, cdev or dev)
+    return {"what": "one full training iteration per rank on its batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
+                    "(HIP gradient kernels, no autograd graph) + gradient all-reduce + full-model clip + AdamW + EMA teacher update; fp32, one stream",
+            "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(world * frames.shape[0] / (ms / 1000), 2),
+            "allreduce_ms": round(ar, 2), "allreduce_bytes": int(opt.grad_arena.numel() * 4), "n_gpus": world,
+            "iterations": iters, "warmup_iterations": WARM, "loss_per_iteration_rank0": losses,
+            "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "ms_each_rank0": [round(1000 * t, 1) for t in times],
             "allocator_in_timed_iterations": {k: torch.cuda.memory_stats().get(k, 0) - st0.get(k, 0) for k in
                                               ("num_alloc_retries", "num_device_alloc", "num_device_free")}}
 
@@ -101,7 +132,10 @@ def synth_batch(rank, B, T, H0, W0, N, device):
 def calibrate_teacher(model, images, want=10):
     """random-init teachers score ~half the queries above 0.75; shift the class bias so ~`want` queries per clip pass
     the distillation threshold ('teacher class logits biased so ~10 queries pass')."""
+    was = model.teacher.training
+    model.teacher.eval()                                 # calibrate on the dropout-free forward
     out = model.teacher(images, True)
+    model.teacher.train(was)
     d = (out.class_logits[-1][..., 0] - out.class_logits[-1][..., 1]).flatten().sort(descending=True).values
     B = out.class_logits.shape[1]
     thr = float(d[min(want * B, d.numel() - 1)])
@@ -113,13 +147,14 @@ def calibrate_teacher(model, images, want=10):
 
 
 def cpu_baseline(cfg_name):
-    """the CPU oracle timed on a bounded sample of the same workload (rank 0, N=1 only)"""
+    """the CPU oracle timed on a bounded sample of the same workload (rank 0, N=1 only): one 2-frame clip at the workload's
+    resolution through the student forward (cross-frame attention over T = 2 included) and the 10-layer GT criterion"""
     from oracle import oracle_np as O
     from s2d_amd.utils import synth
     from s2d_amd.utils.seeded import seeded_state
     from tests.test_oracle import pixel_decoder_shapes, video_decoder_shapes
     B, T, H0, W0, Q, P, N = CONFIGS[cfg_name]
-    Ts = 1                                      # sample: ONE frame of one clip, student forward + GT criterion (10 layers)
+    Ts = 2
     p = seeded_state([("0." + k, s) for k, s in O.r50_param_shapes()] +
                      [("1.pixel_decoder." + k, s) for k, s in pixel_decoder_shapes()] +
                      [("1.predictor." + k, s) for k, s in video_decoder_shapes(Q)], 0)
@@ -139,10 +174,103 @@ def cpu_baseline(cfg_name):
         idx = O.matcher(logits[layer], masks[layer], tg, coords, 0.0, 5.0, 5.0)
         O.loss_masks(masks[layer], tg, idx, num_masks, P=P, rng=rng)
     dt = time.perf_counter() - t0
+    threads = 1
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
+    except Exception:
+        pass
     # the KD step also runs the teacher forward and the KD criterion: ~2x this sample's work per frame
-    return {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 frame {H0}x{W0} (T=1, Q={Q}, P={P}, N={N}): oracle student fwd + 10-layer GT criterion took {dt:.1f}s; "
-                      f"KD step = 2x (teacher fwd + KD criterion) -> frames/s = 1/(2*{dt:.1f})"}
+    return {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": threads, "kind": "port",
+            "sample": f"one {Ts}-frame clip {H0}x{W0} (Q={Q}, P={P}, N={N}): oracle student fwd + 10-layer GT criterion took {dt:.1f}s on "
+                      f"{threads} BLAS thread(s) of {os.cpu_count()} host cores (numpy; python loops single-threaded); KD step = 2x "
+                      f"(teacher fwd + KD criterion) -> frames/s = {Ts}/(2*{dt:.1f})"}
+
+
+def keymask_report(dev, cpu=True):
+    """BASELINE configs[2]: the keymask propagate-and-match kernel set (K2..K6) on a 32-frame 480p synthetic clip with 6 objects
+    and 2 500 tracked points, and the K1 local-correlation kernel on a [32,120,214,128] feature map.
+    HBM-bound integer/byte kernels: achieved GB/s of ALGORITHMIC bytes against the 8 TB/s peak, HIP events on the launch
+    stream, the oracle's CPU time on the same arrays beside it."""
+    from s2d_amd import keymask as km
+    from s2d_amd.utils import synth
+    T, H, W, Np, NOBJ = 32, 480, 854, 2500, 6
+    m, _ = synth.ellipse_targets(12, 1, NOBJ, T, H, W, sparse=0.0, rmin=30, rmax=90)
+    idm = np.zeros((T, H, W), np.int64)
+    for o in range(NOBJ):
+        idm[m[o] > 0] = o + 1
+    rng = synth.rng_for(12, 2)
+    ys, xs = np.nonzero(m[0, 0])
+    sel = rng.integers(0, len(ys), Np)
+    tracks = np.stack([np.stack([xs[sel], ys[sel]], -1).astype(np.float32) + rng.normal(0, 1, (Np, 2)).astype(np.float32) + 0.6 * t
+                       for t in range(T)])[None]
+    vis = rng.random((1, T, Np)) > 0.3
+    tr_d = torch.from_numpy(tracks).to(dev)
+    vis_d = torch.from_numpy(vis).to(dev)
+    idmap = km.IdMap(torch.from_numpy(idm))
+    Hf, Wf, C, r = H // 4, (W + 3) // 4, 128, 3
+    fmap = torch.randn((T, Hf, Wf, C), device=dev)
+    coords = (torch.rand((T, Np, 2), device=dev) * torch.tensor([Wf, Hf], device=dev)).contiguous()
+    sup = torch.randn((Np, (2 * r + 1) ** 2, C), device=dev)
+    S = (2 * r + 1) ** 2
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)       # current stream = the launch stream here
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+
+    tm = km.pred_tracks_to_binary_masks(tr_d, H, W)[0]
+    rows = {}
+    ms = timed(lambda: km.visibility_curve(vis_d))
+    rows["K2 visibility curve"] = (ms, T * Np * 1 + T * 4)
+    ms = timed(lambda: km.pred_tracks_to_binary_masks(tr_d, H, W))
+    rows["K3 tracks -> point masks"] = (ms, T * Np * 8 + T * H * W)                      # tracks read + the u8 planes written (zero fill + scatter)
+    ms = timed(lambda: km.point_id_counts(tm, idmap))
+    rows["K4-K6 point/mask counts (all frames x objects, one launch)"] = (ms, T * H * W * (1 + 8) + T * (NOBJ + 2) * 4)
+    ms = timed(lambda: km.local_correlation(fmap, coords, sup, r), reps=5)
+    rows["K1 local correlation (self-defined; parity unpinned)"] = (ms, Np * S * C * 4 + T * Np * S * S * 4 + T * Np * (2 * r + 2) ** 2 * C * 4)
+    t0 = time.perf_counter()
+    matches, allc = km.extract_mask_matches((H, W), tr_d, idmap, (0, T - 1))
+    torch.cuda.synchronize()
+    whole = 1000 * (time.perf_counter() - t0)
+    out = {"workload": f"keymask_ident propagate-and-match: {T}-frame {H}x{W} clip, {NOBJ} objects, {Np} tracked points; K1 on [{T},{Hf},{Wf},{C}] features, r={r}",
+           "kernels": {k: {"ms": round(v[0], 4), "algorithmic_MB": round(v[1] / 1e6, 2), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1),
+                           "frac_of_8TBps": round(v[1] / (v[0] * 1e-3) / 8e12, 4)} for k, v in rows.items()},
+           "extract_mask_matches_ms_incl_one_sync_and_host_loop": round(whole, 3), "n_comparisons": len(allc), "n_matches": len(matches),
+           "bound": "hbm"}
+    if cpu:
+        from oracle import oracle_np as O
+        t0 = time.perf_counter()
+        O.extract_mask_matches(tracks[0], idm, H, W, (0, T - 1))
+        O.visibility_curve(vis[0])
+        out["cpu_oracle_ms_K2_to_K6"] = round(1000 * (time.perf_counter() - t0), 1)
+    return out
+
+
+_DIST = {"on": False}
+
+
+def _fence(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(x, world, device):
+    if world <= 1:
+        return float(x)
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
 
 
 def main():
@@ -151,32 +279,56 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--dropout", type=float, default=0.3, help="encoder dropout (MODEL.MASK_FORMER.DROPOUT; 0.3 in every shipped config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
-                    help="skip the extra report of one full training iteration (fwd + loss + backward + clip/AdamW/EMA, BASELINE config 4)")
+                    help="skip the extra report of one full training iteration (fwd + loss + backward + all-reduce + clip/AdamW/EMA, BASELINE config 4)")
+    ap.add_argument("--no-keymask", action="store_true", help="skip the keymask kernel-set report (BASELINE config 3)")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run everything on one stream (default: teacher forward + GT criterion on a second HIP stream; the "
-                         "two schedules give bitwise identical losses, which this script re-checks after the timed region)")
+    ap.add_argument("--one-stream", "--no-overlap", dest="one_stream", action="store_true",
+                    help="time the one-stream schedule (default: teacher forward + GT criterion on a second HIP stream; the other "
+                         "schedule is timed after the metric and reported under `schedules`, with a bitwise comparison of the losses)")
     ap.add_argument("--dense-breakdown", action="store_true", help="print per-shape time of the dense launches to stderr")
     ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (spawn, rendezvous, barrier, max-over-ranks, one JSON line): no GPU "
+                         "work, value null")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("S2D_BENCH_BACKEND", "nccl")          # "gloo": rehearse the N > 1 control flow (CPU, or ranks sharing one GPU)
+    if args.dry_run:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        if world > 1:
+            dist.barrier()
+        dt = _max_over_ranks(time.perf_counter() - t0, world, "cpu")
+        if rank == 0:
+            print(json.dumps({"metric": "clip-frames/sec fwd+loss, R50 M2F-Video T=8 720p Q=100", "value": None, "unit": "clip-frames/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_rank_seconds": round(dt, 4)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("S2D_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N > 1 control flow on one GPU
         local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    cdev = torch.device("cpu") if world > 1 and os.environ.get("S2D_BENCH_BACKEND", "nccl") != "nccl" else None
+    cdev = torch.device("cpu") if world > 1 and backend != "nccl" else None
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -184,10 +336,9 @@ def main():
     from s2d_amd.modeling import TargetSet, build_kd_model
     ops.set_dense_mode(args.dense)
     B, T, H0, W0, Q, P, N = CONFIGS[args.config]
-    model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
-    model.train()
-    overlap = not args.no_overlap
-    model.overlap_teacher = model.overlap_criteria = overlap
+    model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0),
+                           dropout=args.dropout).to(dev)
+    model.train()            # student AND teacher in training mode, as in the reference (the teacher is never put in eval(), Appendix C)
     frames, masks = synth_batch(rank, B, T, H0, W0, N, dev)
     gt = TargetSet.from_list(masks, device=dev)
     calibrate_teacher(model, ops.normalize_pad(frames))
@@ -205,135 +356,133 @@ def main():
         model.overlap_teacher = model.overlap_criteria = two_streams
         model.criterion.seed = 12345
         model.criterion.matcher.seed = 12345
+        torch.manual_seed(777)
+        ops._DROP_CALLS[0] = 0                           # same dropout masks in both schedules
         images = ops.normalize_pad(frames, 32, mean, std)
         return torch.stack(list(model.forward_losses(images, gt).values()))
 
-    def fence():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(live):
-        for _ in range(args.warmup):
+    def timed(live, two_streams, steps, warmup):
+        model.overlap_teacher = model.overlap_criteria = two_streams
+        for _ in range(warmup):
             step()
-        fence()
+        _fence(world)
         if live:
             ops.PROFILE = []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             tot = step()
-        fence()
+        _fence(world)
         el = time.perf_counter() - t0
         pr, ops.PROFILE = ops.PROFILE, None
         return el, tot, pr
 
-    live_events = not args.no_kernel_events and not overlap
-    dt, total, prof = timed(live_events)
-    events_note = "HIP events around every dense launch inside the timed region"
-    schedule_note = "one stream"
-    if overlap:
-        # the two-stream schedule must not change a single bit of the result: same seeds, both schedules, all 42 losses
-        a = seeded_step(True)
-        b = seeded_step(False)
-        fence()
-        same = torch.equal(a, b)
-        if world > 1:                       # all ranks take the same branch (the fallback re-times with barriers)
-            import torch.distributed as dist
-            flag = torch.tensor([1 if same else 0], device=cdev or dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            same = bool(flag.item())
-        if same:
-            schedule_note = "two streams; losses re-checked bitwise against the one-stream schedule after the timed region"
-            model.overlap_teacher = model.overlap_criteria = True
-        else:
-            print("bench.py: two-stream losses differ from the one-stream losses -> timing the one-stream schedule instead",
-                  file=sys.stderr)
-            overlap = False
-            model.overlap_teacher = model.overlap_criteria = False
-            live_events = not args.no_kernel_events
-            dt, total, prof = timed(live_events)
-            schedule_note = "one stream (the two-stream schedule failed the bitwise re-check on this machine)"
-    if not args.no_kernel_events and not live_events:
-        # In the timed region the two networks' launches share the GPU on two streams, so an event pair around one launch
-        # brackets other kernels' work too.  The per-launch durations for the roofline come from one extra step, after
-        # the timed region, with everything on one stream (the same launches, isolated); --no-overlap times them live.
-        model.overlap_teacher = model.overlap_criteria = False
-        ops.PROFILE = []
-        step()
-        fence()
-        prof, ops.PROFILE = ops.PROFILE, None
-        model.overlap_teacher = model.overlap_criteria = True
-        events_note = ("HIP events around every dense launch of one extra single-stream step after the timed region "
-                       "(the timed region runs the two networks on two HIP streams; --no-overlap times them live)")
+    two = not args.one_stream
+    live_events = not args.no_kernel_events and not two
+    dt, total, prof = timed(live_events, two, args.steps, args.warmup)
+    dt = _max_over_ranks(dt, world, cdev or dev)
+    assert bool(torch.isfinite(total)), "non-finite loss"
+    # the other schedule, timed the same way after the metric, and a bitwise comparison of all 42 losses between the two
+    # schedules on the same seeds (every kernel is deterministic, so the schedule must not change a bit)
+    dt_other, _, prof_other = timed(not args.no_kernel_events and two, not two, max(args.steps // 2, 2), 1)
+    dt_other = _max_over_ranks(dt_other, world, cdev or dev)
+    a = seeded_step(True)
+    b = seeded_step(False)
+    _fence(world)
+    same = torch.equal(a, b)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=cdev or dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    assert bool(torch.isfinite(total)), "non-finite loss"
+        flag = torch.tensor([1 if same else 0], device=cdev or dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item())
+    if prof is None or not prof:
+        prof = prof_other                                 # dense-launch durations come from the one-stream steps (isolated launches)
+        prof_steps = max(args.steps // 2, 2)
+        events_note = ("HIP events around every dense launch of the one-stream steps timed right after the metric (in the two-stream "
+                       "schedule an event pair would bracket the other stream's kernels too)")
+    else:
+        prof_steps = args.steps
+        events_note = "HIP events around every dense launch inside the timed region"
+    model.overlap_teacher = model.overlap_criteria = two
 
     if rank == 0:
         frames_per_step = world * B * T
+        other_ms = 1000 * dt_other / max(args.steps // 2, 2)
         res = {"metric": "clip-frames/sec fwd+loss, R50 M2F-Video T=8 720p Q=100", "value": round(frames_per_step * args.steps / dt, 3),
                "unit": "clip-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.dense == "f32" else f"f32 ({args.dense} MFMA for dense contractions)", "data": "synthetic",
                "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
-                                      f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip",
+                                      f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip, encoder dropout {args.dropout}",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
-                          "streams": 2 if overlap else 1, "schedule": schedule_note,
+                          "streams": 2 if two else 1, "encoder_dropout": args.dropout,
                           "teacher_intermediate_masks": "full maps" if model.teacher_aux_masks else
                           "only at the pixels its own attention masks read (no loss reads them; final prediction bit-identical)",
-                          "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()}}
+                          "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()},
+               "schedules": {"timed": "two streams (teacher forward + GT criterion on a second HIP stream)" if two else "one stream",
+                             "other_ms_per_step": round(other_ms, 3), "other": "one stream" if two else "two streams",
+                             "losses_bitwise_equal_between_schedules": bool(same)}}
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)
             fl = sum(f for _, _, f, *_ in prof)
             n = len(prof)
-            psteps = args.steps if live_events else 1
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dense]
-            # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (profiles/r1_pmc_traffic.json, fetch corrected x2 as MI355X_MICROARCH.md prescribes); null if absent
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-            if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
-                traffic = json.load(open(tp))["per_kernel_family"]["gemm"]["per_launch_bytes_corrected"]
+            # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            # (scripts/pmc_traffic.py; fetch corrected x2 as MI355X_MICROARCH.md prescribes), stamped with the commit it was taken at
+            traffic, traffic_src = None, None
+            for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                tp = os.path.join(ROOT, "profiles", name)
+                if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
+                    j = json.load(open(tp))
+                    traffic = j["per_kernel_family"]["gemm"]["per_launch_bytes_corrected"]
+                    traffic_src = f"profiles/{name}, measured at commit {j.get('commit', 'unrecorded (round 1)')} by scripts/pmc_traffic.py (not in this run)"
+                    break
             passes = 1 if args.dense == "f32" else 3
             res["roofline"] = {"bound": "mfma", "kernel": "dense NT GEMM / implicit-GEMM conv: " + DENSE_DESC[args.dense],
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": traffic,
+                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": int(sum(t[-1] for *_, t in prof) / n),
                                "mfma_flops_per_algorithmic_flop": passes, "mfma_pipe_frac": round(passes * ach / peak, 4),
                                "achieved_vs_fp32_mfma_peak_157.3": round(ach / 157.3, 4),
-                               "launches_per_step": n // psteps, "avg_launch_us": round(1000 * ms / n, 2),
-                               "kernel_ms_per_step": round(ms / psteps, 2),
-                               "algorithmic_gflop_per_step": round(fl / psteps / 1e9, 1), "measured": events_note}
+                               "launches_per_step": n // prof_steps, "avg_launch_us": round(1000 * ms / n, 2),
+                               "kernel_ms_per_step": round(ms / prof_steps, 2),
+                               "algorithmic_gflop_per_step": round(fl / prof_steps / 1e9, 1), "measured": events_note,
+                               "parity_note": "R50 trunk and K1 are parity-unpinned (detectron2 / co-tracker absent from the reference tree)"}
         # the north star states its target against the whole-step HBM roofline: 19.0 GB algorithmic per clip-frame
         #  at 8 TB/s
         if args.config == "c4":
             res["hbm_roofline"] = {"algorithmic_GB_per_frame": 19.0, "peak_TBps": 8.0,
-                                   "frac": round(res["value"] * 19.0 / 8000.0, 4), "target_frac": 0.4}
+                                   "frac": round(res["value"] / world * 19.0 / 8000.0, 4), "target_frac": 0.4}
         if prof and args.dense_breakdown:
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
             for s_, e_, f_, tag in prof:
-                a = agg[tag[:5]]; a[0] += 1; a[1] += s_.elapsed_time(e_); a[2] += f_
-            for tag, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
-                print(f"{str(tag):44s} calls/step {n/psteps:6.1f}  ms/step {t/psteps:7.2f}  {f/t/1e9:7.1f} TF", file=sys.stderr)
-        if world == 1 and not args.no_train_step:
-            # BASELINE config 4 / SURVEY.md 8d: the same batch through one FULL training iteration (forward + loss + backward
-            # of the student on the HIP gradient kernels + gradient all-reduce (identity at one rank) + full-model clip +
-            # AdamW + EMA teacher update).  An extra report after the metric's timed region; it never touches `value`.
+                a_ = agg[tag[:5]]; a_[0] += 1; a_[1] += s_.elapsed_time(e_); a_[2] += f_
+            for tag, (n_, t_, f_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+                print(f"{str(tag):44s} calls/step {n_/prof_steps:6.1f}  ms/step {t_/prof_steps:7.2f}  {f_/t_/1e9:7.1f} TF", file=sys.stderr)
+    else:
+        res = None
+    if not args.no_train_step:
+        # BASELINE config 4 / SURVEY.md 8d: the same batch through one FULL training iteration on every rank, gradient all-reduce
+        # included.  An extra report after the metric's timed region; it never touches `value`.
+        try:
+            ts = train_step_report(model, frames, masks, mean, std, dev, world, cdev)
+        except Exception as e:                      # the metric line must come out whatever happens here
+            ts = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            res["train_step"] = ts
+    if rank == 0:
+        if world == 1 and not args.no_keymask:
             try:
-                res["train_step"] = train_step_report(model, frames, masks, mean, std, dev)
-            except Exception as e:                      # the metric line must come out whatever happens here
-                res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                res["keymask"] = keymask_report(dev, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                res["keymask"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:     # last: its BLAS worker threads keep the host busy for a while afterwards
             res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -27,8 +27,7 @@ constexpr int LSTR = 36;         // LDS row stride (floats)
 
 // ------------------------------------------------------------------------------------------------
 // attention-mask builder: 32 lanes per key, lane g owns queries 4g..4g+3
-// COHERENT: system-scope loads of the mask logits (diagnostic variant used to pin down the two-stream stale-read
-// hazard described in DESIGN.md section 6; the shipped launch uses plain loads)
+// COHERENT: system-scope loads of the mask logits (a round-1 diagnostic form; the shipped launch uses plain 16-B loads)
 template <bool COHERENT>
 __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
                                                         int hl, int wl, uint32_t *__restrict__ bits,
@@ -110,16 +109,18 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(const float *__restrict_
 }
 
 
-// ---- DIAG (two-stream stale read investigation; removed once the mechanism is written down) ----------------------
-// VAR 1: the round-1 kernel that showed the stale reads (guarded 4-B tap loads); VAR 2: same + agent-scope acquire
-// (buffer_inv sc1) at kernel start; VAR 3: same + sc1 (L1-bypassing, agent-scope) loads
-template <int VAR>
-__global__ __launch_bounds__(256) void attn_mask_kernel_diag(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
-                                                             int hl, int wl, uint32_t *__restrict__ bits,
-                                                             uint32_t *__restrict__ unmasked, float *__restrict__ dbg)
+// ---- regression variant ------------------------------------------------------------------------
+// Round 1's form of the kernel above (guarded 4-B tap loads, the four taps of a query consumed together).  Under the
+// compiler's SLP vectorisation its arithmetic became v_pk_mul_f32 issued straight behind `s_waitcnt vmcnt(0)`, with the
+// youngest global_load_dword's register as a source, and on MI355X that packed op computed with 0 in lanes 48..63 whenever
+// a second HIP stream kept the CUs busy (profiles/r2_two_stream_diagnosis/, DESIGN.md "Streams").  The library is now
+// built without SLP / loop vectorisation and scripts/isa_lint.py rejects the shape; this source stays, selected by
+// S2D_ATTN_MASK_DWORD_TAPS=1, so that tests/test_gpu_fullsize.py can run the two-stream schedule on it.
+__global__ __launch_bounds__(256) void attn_mask_kernel_dword_taps(const float *__restrict__ ml, int ldq, int Q, int T, int hm, int wm,
+                                                                   int hl, int wl, uint32_t *__restrict__ bits,
+                                                                   uint32_t *__restrict__ unmasked)
 {
     __shared__ uint32_t um[QW];
-    if (VAR == 2) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     const int b = blockIdx.y;
     const long K = (long)T * hl * wl;
     if (threadIdx.x < QW) um[threadIdx.x] = 0u;
@@ -135,17 +136,6 @@ __global__ __launch_bounds__(256) void attn_mask_kernel_diag(const float *__rest
         const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
         const float *base = ml + ((long)b * T + t) * hm * wm * ldq;
         const int q0 = 4 * g;
-        if (VAR == 5) {        // every lane loads (addresses of lanes beyond Q clamped to the last valid group): full quarter-waves
-            const int qc = q0 < Q ? q0 : ((Q - 1) & ~3);
-            const float *p00 = base + ((long)y0 * wm + x0) * ldq + qc, *p01 = base + ((long)y0 * wm + x1) * ldq + qc;
-            const float *p10 = base + ((long)y1 * wm + x0) * ldq + qc, *p11 = base + ((long)y1 * wm + x1) * ldq + qc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a00 = p00[j], a01 = p01[j], a10 = p10[j], a11 = p11[j];
-                const float vv = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
-                if (q0 + j < Q) { valid |= 1u << j; if (vv < 0.f) nib |= 1u << j; }
-            }
-        } else
         if (q0 < Q) {
             float v[4];
             const float *p00 = base + ((long)y0 * wm + x0) * ldq + q0, *p01 = base + ((long)y0 * wm + x1) * ldq + q0;
@@ -153,33 +143,10 @@ __global__ __launch_bounds__(256) void attn_mask_kernel_diag(const float *__rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (q0 + j < Q) {
-                    float a00, a01, a10, a11;
-                    if (VAR == 3) {
-                        a00 = __hip_atomic_load(p00 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a01 = __hip_atomic_load(p01 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a10 = __hip_atomic_load(p10 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a11 = __hip_atomic_load(p11 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else { a00 = p00[j]; a01 = p01[j]; a10 = p10[j]; a11 = p11[j]; }
-                    if (VAR == 6) {          // the same arithmetic on single (non-packed) VALU instructions
-                        float m0, m1, m2, m3, s0, s1, t0, t1, r;
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "v"(hx), "v"(a00));
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(lx), "v"(a01));
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m2) : "v"(hx), "v"(a10));
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m3) : "v"(lx), "v"(a11));
-                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(m0), "v"(m1));
-                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(m2), "v"(m3));
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(hy), "v"(s0));
-                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(ly), "v"(s1));
-                        asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t0), "v"(t1));
-                        v[j] = r;
-                    } else
+                    const float a00 = p00[j], a01 = p01[j], a10 = p10[j], a11 = p11[j];
                     v[j] = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
                     valid |= 1u << j;
                     if (v[j] < 0.f) nib |= 1u << j;
-                    if (VAR == 4 && dbg && q0 + j >= 64) {          // raw taps, the interpolated value and the lane's nibble so far: [b][key][q-64][6]
-                        float *d = dbg + ((((long)b * K + key) * 36) + (q0 + j - 64)) * 6;
-                        d[0] = a00; d[1] = a01; d[2] = a10; d[3] = a11; d[4] = v[j]; d[5] = (float)nib;
-                    }
                 }
             }
         }
@@ -622,16 +589,11 @@ int s2d_attn_mask_bits(const float *mask_logits, int ldq, int B, int Q, int T, i
     if (B == 0 || K == 0) return S2D_OK;
     if (K >= (1L << 31) - 8) return S2D_ERR_ARG;
     if (s2d_zero_async(unmasked, sizeof(uint32_t) * QW * B, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    static int diag = -1;
-    if (diag < 0) { const char *e = getenv("S2D_DIAG_ATTN_MASK"); diag = e ? atoi(e) : 0; }
-    if (diag && !compact) {
-        float *dbg = nullptr;
-        if (diag == 4) { const char *e = getenv("S2D_DIAG_DBG_PTR"); dbg = e ? reinterpret_cast<float *>(strtoull(e, nullptr, 0)) : nullptr; }
-        const dim3 gr(cdiv(K, 8), B);
-#define S2D_DIAG_LAUNCH(V) hipLaunchKernelGGL(attn_mask_kernel_diag<V>, gr, dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl, wl, bits, unmasked, dbg)
-        if (diag == 1) S2D_DIAG_LAUNCH(1); else if (diag == 2) S2D_DIAG_LAUNCH(2); else if (diag == 3) S2D_DIAG_LAUNCH(3);
-        else if (diag == 4) S2D_DIAG_LAUNCH(4); else if (diag == 5) S2D_DIAG_LAUNCH(5); else S2D_DIAG_LAUNCH(6);
-#undef S2D_DIAG_LAUNCH
+    static int dword_taps = -1;
+    if (dword_taps < 0) { const char *e = getenv("S2D_ATTN_MASK_DWORD_TAPS"); dword_taps = e ? atoi(e) : 0; }
+    if (dword_taps && !compact) {          // regression variant (tests only), see attn_mask_kernel_dword_taps
+        hipLaunchKernelGGL(attn_mask_kernel_dword_taps, dim3(cdiv(K, 8), B), dim3(256), 0, stream, mask_logits, ldq, Q, T, hm, wm, hl, wl,
+                           bits, unmasked);
         S2D_CHECK_LAUNCH();
         return S2D_OK;
     }

@@ -776,7 +776,6 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
         }
-        if (p.diag_release) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         return;
     }
     const int col = n0 + wn * 32 + l32;
@@ -885,9 +884,6 @@ int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned in
 int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStream_t st, int f16)
 {
     GemmParams p = pin;
-    static int diag_rel = -1;
-    if (diag_rel < 0) { const char *e = getenv("S2D_DIAG_GEMM_RELEASE"); diag_rel = e ? atoi(e) : 0; }
-    p.diag_release = diag_rel;
     const long bA = conv ? (long)(p.M / ((long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 4L : ((long)(p.M - 1) * p.lda + p.K) * 4L;
     const long bB = ((long)(p.N - 1) * p.ldb + p.K) * 4L;
     if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets

@@ -12,7 +12,6 @@ struct GemmParams {
     long ldr, sR;
     int res_rows, res_cols;   // residual row = row % res_rows (0: row); columns >= res_cols get no residual
     int relu;
-    int diag_release;         // DIAG: agent-scope release fence (buffer_wbl2 sc1) at the end of every wave (two-stream investigation)
     // implicit-GEMM convolution (A = NHWC input)
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     // byte extents of one batch slice of A and B (buffer-descriptor bounds of the split-bf16 kernel)

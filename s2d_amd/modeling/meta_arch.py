@@ -442,13 +442,13 @@ class VideoMaskFormer(nn.Module):
 
 
 def build_kd_model(num_queries=100, num_frames=8, num_points=160000, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0),
-                   dec_layers=10, seed=0, teacher_bias=None):
+                   dec_layers=10, seed=0, teacher_bias=None, dropout=0.0):
     """Construct KDVideoMaskFormer with the shipped hyper-parameters
     (configs/imagenet_video/ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml) without a yacs config."""
     torch.manual_seed(seed)
 
     def head():
-        return MaskFormerHead(MSDeformAttnPixelDecoder(),
+        return MaskFormerHead(MSDeformAttnPixelDecoder(transformer_dropout=dropout),
                               VideoMultiScaleMaskedTransformerDecoder(num_queries=num_queries, num_frames=num_frames,
                                                                       dec_layers=dec_layers - 1))
     sb, sh = ResNet50(), head()

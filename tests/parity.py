@@ -94,7 +94,7 @@ def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4)
     st = model.last["student"]
     hip = dict(losses={k: float(v) for k, v in losses.items()}, kd_counts=model.last["kd_count"].cpu().tolist(),
                s_logits=st.class_logits.cpu().numpy(), s_masks=torch.stack([st.pred_masks(i) for i in range(NL)]).cpu().numpy(),
-               model=model)
+               model=model, inputs=(images, gts, to(cg)), idx_gt=None)
     ref = None
     if oracle is not None:
         ref = run_oracle(oracle, ps, pt, frames, tg, T, Q, P, cg, ck, model.criterion.weight_dict, weights, NL)

@@ -111,3 +111,18 @@ def test_meta_archs_build_from_config_through_the_registry():
     vm = META_ARCH_REGISTRY.get("VideoMaskFormer").from_config(cfg)
     assert len(vm.criterion.weight_dict) == 3 * 10 and (vm.use_nms, vm.num_predictions) == (True, 10)
     assert set(kd.student[1].state_dict()) == {k.replace("sem_seg_head.", "") for k in vm.state_dict() if k.startswith("sem_seg_head.")}
+
+
+def test_isa_lint_no_packed_op_behind_a_dword_load_wait():
+    """every kernel of the library, disassembled for gfx950 with the build's flags: no v_pk_* instruction directly behind an
+    s_waitcnt vmcnt that reads the register of a one-dword load (the shape that computed wrong values under the two-stream
+    schedule, DESIGN.md "Streams"); the lint itself flags a hand-written instance of the shape"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "scripts", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = ("k:\n global_load_dword v20, v[4:5], off\n global_load_dword v21, v[6:7], off\n s_waitcnt vmcnt(0)\n"
+           " v_pk_mul_f32 v[28:29], v[12:13], v[20:21]\n s_endpgm\n")
+    ok = bad.replace(" s_waitcnt vmcnt(0)\n", " s_waitcnt vmcnt(0)\n v_mov_b32_e32 v21, v21\n v_mov_b32_e32 v20, v20\n")
+    assert len(lint.lint_text(bad, "t")) == 1 and lint.lint_text(ok, "t") == []
+    assert lint.main([]) == 0

@@ -125,7 +125,7 @@ def test_msda_compat_module_and_function(oracle):
     for got, got2, name in ((gv, vr.grad, "grad_value"), (gl, lr.grad, "grad_loc"), (gw, wr.grad, "grad_w")):
         ref = g[name]
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
-        assert torch.equal(got, got2)
+        np.testing.assert_allclose(got2.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())   # (grad_value: float atomics, not bitwise)
     with pytest.raises(RuntimeError):
         MSDA.ms_deform_attn_forward(v.permute(0, 1, 3, 2), shapes, lsi, loc, w, 128)      # not contiguous
     with pytest.raises(RuntimeError):
@@ -188,7 +188,7 @@ def test_shipped_config_trains_with_the_reference_trainer_statements():
     """KDVideoMaskFormer built by the registry from the literal keys of the shipped KD yaml (DROPOUT 0.3, 160 000 points,
     3 frames, masks-only DropLoss) and driven by the reference trainer's own statements (train_loop.py:709-726):
         loss_dict = model(data); losses = sum(loss_dict.values()); grad_scaler.scale(losses).backward(); optimizer.step()
-    with a stock torch optimizer.  The gradients autograd delivers are the HIP backward's, bit for bit."""
+    with a stock torch optimizer.  The gradients autograd delivers are the HIP backward's."""
     from s2d_amd import ops
     from s2d_amd.modeling.meta_arch import META_ARCH_REGISTRY
     cfg = _shipped_cfg()
@@ -228,8 +228,9 @@ def test_shipped_config_trains_with_the_reference_trainer_statements():
     gt = TargetSet.from_list(_gt_target_list(data, T, images.shape[1], images.shape[2], model.device), device=model.device)
     direct = model.forward_backward(images, gt)
     assert all(float(direct[k]) == float(loss_dict[k]) for k in direct)
-    for p, g in zip(students, got):
-        assert torch.equal(g, p.grad * scale)
+    for p, g in zip(students, got):                                            # (float atomics in two backward kernels: not bitwise run to run)
+        ref = p.grad * scale
+        assert float((g - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-12
     # an optimizer step moves the student; accumulation into existing .grad works like autograd's
     before = [p.detach().clone() for p in students[:8]]
     for p, g in zip(students, got):

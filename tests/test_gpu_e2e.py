@@ -38,3 +38,35 @@ def test_kd_forward_loss_config1_plumbing(oracle):
     from tests.parity import run_case
     hip, ref = run_case(oracle, seed=4, B=1, T=1, H0=256, W0=256, Q=10, P=1024, ns=(3,))
     _check(hip, ref, 1, 10)
+
+
+def test_config2_480p_two_frames_q100_both_meta_archs(oracle):
+    """BASELINE configs[1]: one 2-frame 480p clip (480x854 -> 480x864), R50 Mask2Former-Video, 100 queries, P = 12 544,
+    forward + VideoSetCriterion -- for KDVideoMaskFormer (student + teacher, GT + KD pass) and for the plain VideoMaskFormer
+    the config's metric is quoted on (video_maskformer_model.py:224-241: one network, one criterion pass), HIP vs the oracle
+    with injected points: logits 1e-3, Hungarian indices bit-exact, losses 1e-3"""
+    import torch
+    from s2d_amd.modeling import TargetSet, VideoMaskFormer, VideoSetCriterion
+    from tests.parity import run_case
+    hip, ref = run_case(oracle, seed=5, B=1, T=2, H0=480, W0=854, Q=100, P=12544, ns=(10,))
+    assert hip["s_masks"].shape[-2:] == (120, 216)
+    _check(hip, ref, 1, 10)
+    kd = hip["model"]
+    images, gts, cg = hip["inputs"]
+    wd = {k: v for k, v in kd.criterion.weight_dict.items() if not k.startswith("kd_")}
+    crit = VideoSetCriterion(1, matcher=kd.criterion.matcher, weight_dict=wd, eos_coef=0.1, losses=["labels", "masks"], num_points=12544,
+                             oversample_ratio=3.0, importance_sample_ratio=0.75, loss_strategy="masks-only")
+    vm = VideoMaskFormer(backbone=kd.student[0], sem_seg_head=kd.student[1], criterion=crit, num_queries=100, num_frames=2).to(images.device)
+    vm.train()
+    losses = vm.forward_losses(images, TargetSet.from_list(gts, device=images.device), cg)
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(k for k in ref["losses"] if not k.startswith("kd_")) and len(losses) == 21
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(ref["losses"][k]), rtol=1e-3, atol=1e-6, err_msg=k)
+    iq, it, nm = (x.cpu().numpy() for x in crit.last_indices)
+    order = [9] + list(range(9))
+    for li, layer in enumerate(order):
+        ri, rj = ref["idx_gt"][li][0]
+        assert nm[layer] == len(ri)
+        np.testing.assert_array_equal(iq[layer, :len(ri)], ri)
+        np.testing.assert_array_equal(it[layer, :len(ri)], rj)

@@ -5,6 +5,8 @@ import socket
 import torch
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
@@ -104,3 +106,25 @@ def test_param_groups_follow_reference_rules():
     assert not any(id(p) in by_id for p in model.teacher.parameters())        # frozen teacher
     assert abs(ema_momentum_schedule(0, 0.99, 0.9999, 1000) - 0.99) < 1e-12
     assert abs(ema_momentum_schedule(1000, 0.99, 0.9999, 1000) - 0.9999) < 1e-12
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts the two ranks itself (torch.distributed.run children), they
+    rendezvous on 127.0.0.1 over gloo, and rank 0 prints ONE JSON line with n_gpus == 2 (--dry-run: the control flow only, no
+    GPU work -- this container has no GPU; tests/test_gpu_fullsize.py runs the real two-rank step on the GPU box)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, S2D_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["value"] is None and j["steps"] == 3
+    # a launcher-provided world that contradicts --gpus is refused, not silently accepted
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
