@@ -55,16 +55,17 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
  * sites of the pixel decoder's encoder layers in training mode (msdeformattn.py:101-125: dropout1 on the attention output,
  * dropout2 after the FFN activation (ReLU and a non-negative mask commute), dropout3 on the FFN output; each before its
  * residual add).  The mask is counter-based: element (row, col) of the [M,N] output is kept iff 16 bits of
- * Philox4x32-10(counter = (row, col / 8, site, 0), key = seed) are >= round(p * 65536), kept elements are multiplied by
+ * Philox4x32-10(counter = (row0 + row, col / 8, site, 0), key = seed) are >= round(p * 65536) (row0: the mask row of output
+ * row 0, for a launch over a row range of a larger activation), kept elements are multiplied by
  * 1 / (1 - p); the backward regenerates it (s2d_dropout_f32) instead of storing it.  Unbatched; N, ldc, ldr multiples of
  * 8; dense mode 2 only (S2D_ERR_ARG otherwise). */
 int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                             const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,
-                            uint64_t seed, unsigned site, hipStream_t stream);
+                            uint64_t seed, unsigned site, unsigned row0, hipStream_t stream);
 
 /* y[M,N] = x * mask / (1 - p) with the mask of s2d_gemm_nt_dropout_f32 for the same (p, seed, site): the gradient of a
  * dropout site (and the mask itself, from x = 1).  N multiple of 8; y may alias x. */
-int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, float *y, hipStream_t stream);
+int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, unsigned row0, float *y, hipStream_t stream);
 
 /* Static weights can be split into their fp16 hi/lo image once (dense mode 2) instead of in every launch that reads
  * them: out = s2d_split_weights_words(N,K) 32-bit words, laid out [N][ceil(K/32)][16 words hi | 16 words lo] (the LDS
@@ -98,6 +99,16 @@ int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const 
                           const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
                           int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
                           hipStream_t stream);
+
+/* The same gradients without float atomics, bitwise reproducible (what the training step uses): the sampling graph is
+ * inverted once per call -- samples keyed by their bilinear cell, histogram + prefix sum, stable radix sort -- and every
+ * grad_value row is then written once by a gather over the four cells that touch its pixel; grad_loc / grad_attn are
+ * query-owned.  workspace: s2d_msda_backward_workspace_bytes(...) bytes of device memory.  Lq, M, L, P as above; D == 32. */
+long s2d_msda_backward_workspace_bytes(const int64_t *shapes_host, int N, int M, int L, int Lq, int P);
+int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                                 const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                                 int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
+                                 long workspace_bytes, hipStream_t stream);
 
 /* Fused pixel-decoder form: also does softmax over L*P and loc = ref + off/(W_l,H_l)
  * (ops/modules/ms_deform_attn.py:101-109) with the query's own pixel centre as reference point
@@ -403,6 +414,13 @@ int s2d_tracks_to_masks_u8(const float *tracks, int T, int Np, int H, int W, uin
  * host in double exactly as the reference's python float division.  idmap int64 [T][Hi][Wi] (:176-209). */
 int s2d_point_id_counts(const uint8_t *point_masks, const int64_t *idmap, int T, int H, int W, int Hi, int Wi, int max_id,
                         int *counts, int *total, hipStream_t stream);
+
+/* get_segmentation_mask (keymask_ident/keymask_utils.py:37-67 == cotracker_matching.py:176-209) for a list of K (frame, object)
+ * candidates: out u8 [K][H][W] = (idmap[frames[k]] == objs[k]) * 255, objs[k] == -1 selecting every non-background id.  frames /
+ * objs are DEVICE int32 arrays (frame indices are not range-checked here: the caller built them from the same id map).  The
+ * masks the cluster / group PNG trees hold (keymask_utils.py:100-126, cotracker_matching.py:402-431). */
+int s2d_idmap_select_masks_u8(const int64_t *idmap, int T, int H, int W, const int *frames, const int *objs, int K, uint8_t *out,
+                              hipStream_t stream);
 
 /* presence[t][id] = id occurs in frame t (torch.unique at :680); u8 [T][max_id+1]. */
 int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_id, uint8_t *presence, hipStream_t stream);

@@ -7,7 +7,7 @@
 namespace {
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ x, long M, int N, uint32_t thresh, float scale,
-                                                      uint32_t k0, uint32_t k1, uint32_t site, float *__restrict__ y)
+                                                      uint32_t k0, uint32_t k1, uint32_t site, uint32_t row0, float *__restrict__ y)
 {
     const int nb = N >> 3;                                   // 8-column mask blocks per row
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
     const f32x4 a = *reinterpret_cast<const f32x4 *>(x + row * N + cb * 8);
     const f32x4 b = *reinterpret_cast<const f32x4 *>(x + row * N + cb * 8 + 4);
     float m[8];
-    s2d_dropout8((uint32_t)row, (uint32_t)cb, site, k0, k1, thresh, scale, m);
+    s2d_dropout8((uint32_t)row + row0, (uint32_t)cb, site, k0, k1, thresh, scale, m);
     const f32x4 ya = {a[0] * m[0], a[1] * m[1], a[2] * m[2], a[3] * m[3]};
     const f32x4 yb = {b[0] * m[4], b[1] * m[5], b[2] * m[6], b[3] * m[7]};
     *reinterpret_cast<f32x4 *>(y + row * N + cb * 8) = ya;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
 
 }  // namespace
 
-extern "C" int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, float *y, hipStream_t stream)
+extern "C" int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, unsigned row0, float *y, hipStream_t stream)
 {
     if (!(p >= 0.f) || p >= 1.f || M < 0 || N <= 0 || (N & 7) || M >= (1L << 32)) return S2D_ERR_ARG;
     if (M == 0) return S2D_OK;
@@ -35,7 +35,7 @@ extern "C" int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t 
     const float scale = thresh ? 1.0f / (1.0f - p) : 1.0f;
     const long n = M * (N >> 3);
     hipLaunchKernelGGL(dropout_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, M, N, thresh, scale,
-                       (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32), site, y);
+                       (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32), site, row0, y);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -210,7 +210,7 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
 // the same contraction with dropout fused into the epilogue (see include/s2d_hip.h; dropout.h for the mask definition)
 int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                             const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,
-                            uint64_t seed, unsigned site, hipStream_t stream)
+                            uint64_t seed, unsigned site, unsigned row0, hipStream_t stream)
 {
     if (!(p >= 0.f) || p >= 1.f) return S2D_ERR_ARG;
     GemmParams q{};
@@ -223,7 +223,7 @@ int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int
     if (g_dense_mode != 2) return S2D_ERR_ARG;
     q.drop_thresh = thresh > 65535u ? 65535u : thresh;
     q.drop_scale = 1.0f / (1.0f - p);
-    q.drop_k0 = (unsigned)(seed & 0xFFFFFFFFull); q.drop_k1 = (unsigned)(seed >> 32); q.drop_stream = site;
+    q.drop_k0 = (unsigned)(seed & 0xFFFFFFFFull); q.drop_k1 = (unsigned)(seed >> 32); q.drop_stream = site; q.drop_row0 = row0;
     return launch(q, false, 1, stream);
 }
 

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                     f32x4 v1 = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr8) * 68 + c8 * 8 + 4]);
                     v0 = v0 * sc0 + bi0; v1 = v1 * sc1 + bi1;
                     float m[8];
-                    s2d_dropout8((uint32_t)row, (uint32_t)(col >> 3), p.drop_stream, p.drop_k0, p.drop_k1, p.drop_thresh, p.drop_scale, m);
+                    s2d_dropout8((uint32_t)row + p.drop_row0, (uint32_t)(col >> 3), p.drop_stream, p.drop_k0, p.drop_k1, p.drop_thresh, p.drop_scale, m);
                     v0[0] *= m[0]; v0[1] *= m[1]; v0[2] *= m[2]; v0[3] *= m[3];
                     v1[0] *= m[4]; v1[1] *= m[5]; v1[2] *= m[6]; v1[3] *= m[7];
                     if (res) {

@@ -25,6 +25,7 @@ struct GemmParams {
     unsigned int drop_thresh;   // element kept iff its 16 random bits >= drop_thresh (= round(p * 65536))
     float drop_scale;           // 1 / (1 - p)
     unsigned int drop_k0, drop_k1, drop_stream;   // Philox key (the call's seed) and the stream id of this dropout site
+    unsigned int drop_row0;     // mask row of output row 0 (a launch over rows [r0, r1) of a larger activation passes r0)
 };
 
 

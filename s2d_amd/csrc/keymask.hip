@@ -218,6 +218,35 @@ __global__ __launch_bounds__(256) void idmap_apply_kernel(const uint8_t *__restr
     }
 }
 
+
+// K4 for a whole list of (frame, object) candidates at once (get_segmentation_mask, keymask_utils.py:37-67 /
+// cotracker_matching.py:176-209): out[k] = (idmap[frame_k] == obj_k) * 255, obj_k == -1 selects every non-background id.
+// One launch and one device-to-host copy per video instead of one of each per written PNG.
+__global__ __launch_bounds__(256) void select_masks_kernel(const int64_t *__restrict__ idmap, long HW, const int *__restrict__ frames,
+                                                           const int *__restrict__ objs, uint8_t *__restrict__ out)
+{
+    const int k = blockIdx.y;
+    const int64_t *src = idmap + (long)frames[k] * HW;
+    const long o = objs[k];
+    uint8_t *dst = out + (long)k * HW;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < HW; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= HW && (HW & 7) == 0) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t v = src[i + j];
+                w |= (uint64_t)((o < 0 ? v != 0 : v == o) ? 0xFFu : 0u) << (8 * j);
+            }
+            *reinterpret_cast<uint64_t *>(dst + i) = w;
+        } else {
+            for (long j = i; j < HW && j < i + 8; ++j) {
+                const int64_t v = src[j];
+                dst[j] = (o < 0 ? v != 0 : v == o) ? 255 : 0;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -270,6 +299,19 @@ int s2d_idmap_presence_u8(const int64_t *idmap, int T, int Hi, int Wi, int max_i
     if (s2d_zero_async(presence, (size_t)T * (max_id + 1), stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(id_presence_kernel, dim3(32, T), dim3(256), sizeof(int) * (max_id + 1), stream, idmap, (long)Hi * Wi, max_id,
                        presence);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_idmap_select_masks_u8(const int64_t *idmap, int T, int H, int W, const int *frames, const int *objs, int K, uint8_t *out,
+                              hipStream_t stream)
+{
+    if (T <= 0 || H <= 0 || W <= 0 || K < 0) return S2D_ERR_ARG;
+    if (K == 0) return S2D_OK;
+    const long HW = (long)H * W;
+    int gx = cdiv(HW, 256 * 8);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(select_masks_kernel, dim3(gx, K), dim3(256), 0, stream, idmap, HW, frames, objs, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

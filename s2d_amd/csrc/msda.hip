@@ -230,6 +230,185 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
     }
 }
 
+
+// ---- atomic-free backward (semantics of ms_deform_im2col_cuda.cuh:306-408) ------------------------
+// grad_value[n, s, m, :] = sum over the samples (q, l, p) whose bilinear cell has pixel s as one of its four corners of
+// corner_weight * attn * grad_out[n, q, m, :].  The reference (and s2d_msda_backward_f32) scatters these with float atomics:
+// 4 corners x 32 channels x 30 M samples = 3.8 G atomics per encoder layer at config c4, the chip's atomic ceiling (10.8 ms),
+// and the sum order -- hence the bits -- changes from run to run.  Here the sampling graph is inverted once per call instead:
+//   1. every sample is keyed by the bilinear cell (head, level, floor(y), floor(x)) it falls in; a histogram of the keys
+//      (integer atomics: order-free) and its prefix sum give every cell's segment;
+//   2. a stable radix sort (rocPRIM) of (cell key, sample id) pairs lists each cell's samples in ascending sample id;
+//   3. a gather kernel owns one grad_value row (n, s, m, 32 channels) per half-wave, walks the four cells that have pixel s
+//      as a corner, and adds weight * grad_out rows in that fixed order -- one 128-B store per row, no atomics, bitwise
+//      reproducible.
+// grad_loc / grad_attn stay query-owned (msda_bwd_loc_kernel): no scatter there.
+struct Cells {
+    int base[MAX_L];      // first cell index of level l inside one (frame, head)
+    int tot;              // cells per (frame, head): sum over levels of (H + 1) * (W + 1)  (floor(y) in [-1, H-1], floor(x) in [-1, W-1])
+};
+
+__global__ __launch_bounds__(256) void msda_cell_key_kernel(const float *__restrict__ loc, Levels lv, Cells cl, unsigned int per_n, int M, int L,
+                                                            int P, unsigned int kmax, unsigned int *__restrict__ keys,
+                                                            unsigned int *__restrict__ vals)
+{
+    const unsigned int n = blockIdx.y;
+    const unsigned int w = blockIdx.x * 256u + threadIdx.x;          // sample index inside frame n: (q * M + m) * LP + lp
+    if (w >= per_n) return;
+    const unsigned int LP = (unsigned int)(L * P);
+    const unsigned int lp = w % LP, qm = w / LP, m = qm % (unsigned int)M;
+    const int l = (int)(lp / (unsigned int)P);
+    const int H = lv.H[l], W = lv.W[l];
+    const unsigned int v = n * per_n + w;
+    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2L * v);
+    const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+    unsigned int key = kmax;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {      // cuh:293 / :367
+        const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im);
+        key = (n * (unsigned int)M + m) * (unsigned int)cl.tot + (unsigned int)(cl.base[l] + (h0 + 1) * (W + 1) + (w0 + 1));
+    }
+    keys[v] = key;
+    vals[v] = v;
+}
+
+// After the sort: segment starts of every cell (off[k] = first sorted position whose key >= k, filled at the key changes -- no
+// histogram, no scattered atomics) and one 16-B record per sorted sample {loc.x, loc.y, attention weight, grad_out row}, so
+// that the gather reads a sample with one coalesced load instead of three dependent ones.
+struct __attribute__((aligned(16))) SampleRec {
+    float lx, ly, a;
+    unsigned int row;
+};
+
+__global__ __launch_bounds__(256) void msda_cell_bounds_kernel(const unsigned int *__restrict__ skeys, const unsigned int *__restrict__ svals,
+                                                               const float *__restrict__ loc, const float *__restrict__ aw, unsigned int nsamp,
+                                                               unsigned int kmax, unsigned int LP, int *__restrict__ off,
+                                                               SampleRec *__restrict__ rec)
+{
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i > nsamp) return;
+    const long kprev = i ? (long)skeys[i - 1] : -1L;
+    const long k = i < nsamp ? (long)skeys[i] : (long)kmax + 1;       // position nsamp closes every remaining segment (off[.. kmax + 1])
+    for (long kk = kprev + 1; kk <= k && kk <= (long)kmax + 1; ++kk) off[kk] = (int)i;
+    if (i < nsamp) {
+        const unsigned int v = svals[i];
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2L * v);
+        SampleRec r;
+        r.lx = xy.x; r.ly = xy.y; r.a = aw[v]; r.row = v / LP;
+        rec[i] = r;
+    }
+}
+
+// one grad_value row (n, s, m, 32 channels) per 8-lane group (16 B per lane): a wave = the 8 heads of one pixel.  A batch of
+// 8 records is prepared by the group's lanes, then its 8 grad_out rows are loaded together (all in flight) and added in record
+// order; slots beyond the segment carry weight 0 (row 0), which leaves the sum's bits unchanged.
+__global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__restrict__ gout, const SampleRec *__restrict__ rec,
+                                                             const int *__restrict__ off, Levels lv, Cells cl, long ntgt, int S, int M, int L,
+                                                             float *__restrict__ gvalue)
+{
+    constexpr int D = 32;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t = item >> 3;                                       // target row (n, s, m)
+    const int c = (int)(item & 7);
+    if (t >= ntgt) return;                                          // whole 8-lane groups leave together
+    const int m = (int)(t % M);
+    const int s = (int)((t / M) % S);
+    const long n = t / M / S;
+    int l = 0;
+    while (l + 1 < L && s >= lv.start[l + 1]) ++l;
+    const int H = lv.H[l], W = lv.W[l];
+    const int pix = s - (int)lv.start[l];
+    const int y = pix / W, x = pix - y * W;
+    const long kbase = (n * M + m) * (long)cl.tot + cl.base[l];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dy = 1 - (k >> 1), dx = 1 - (k & 1);             // pixel s is corner (h0 + dy, w0 + dx) of cell (h0, w0) = (y - dy, x - dx)
+        const int h0 = y - dy, w0 = x - dx;
+        const long key = kbase + (long)(h0 + 1) * (W + 1) + (w0 + 1);
+        const int beg = off[key], end = off[key + 1];
+        for (int i = beg; i < end; i += 8) {
+            const int idx = i + c;
+            float wgt = 0.f;
+            int grow = 0;
+            if (idx < end) {                                        // lane c prepares record i + c
+                const SampleRec r = rec[idx];
+                const float lh = (r.ly * H - 0.5f) - (float)h0, lw = (r.lx * W - 0.5f) - (float)w0;
+                wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw) * r.a;
+                grow = (int)r.row;
+            }
+            float wj[8];
+            f32x4 g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wj[j] = __shfl(wgt, j, 8);
+                const unsigned int rj = (unsigned int)__shfl(grow, j, 8);
+                g[j] = *reinterpret_cast<const f32x4 *>(gout + (long)rj * D + c * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += wj[j] * g[j];        // fixed order: ascending sample id inside the cell
+        }
+    }
+    *reinterpret_cast<f32x4 *>(gvalue + t * D + c * 4) = acc;
+}
+
+// grad_sampling_loc / grad_attn_weight of the backward, query-owned (cuh:119-163 without the grad_value scatter): the forward's
+// geometry -- a wave = one query's 8 heads x 8 lanes x 4 channels, every corner a 16-B load -- with the channel sums reduced
+// over the 8 lanes of a head
+__global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restrict__ value, Levels lv, const float *__restrict__ loc,
+                                                           const float *__restrict__ aw, const float *__restrict__ gout, int S, int M, int L,
+                                                           int Lq, int P, int blk_per_n, float *__restrict__ gloc, float *__restrict__ gaw)
+{
+    constexpr int D = 32;
+    const int n = blockIdx.y;
+    const int bid = xcd_band(blockIdx.x, blk_per_n);
+    const long item = (long)bid * 256 + threadIdx.x;
+    if (item >= (long)Lq * M * 8) return;                           // whole 8-lane groups leave together
+    const int c = (int)(item & 7);
+    const int m = (int)((item >> 3) % M);
+    const int q = (int)((item >> 3) / M);
+    const long qm = ((long)n * Lq + q) * M + m;
+    const f32x4 tg = *reinterpret_cast<const f32x4 *>(gout + qm * D + c * 4);
+    const long rowstride = (long)M * D;
+    for (int l = 0; l < L; ++l) {
+        const int H = lv.H[l], W = lv.W[l];
+        const float *vb = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * 4;
+        for (int p = 0; p < P; ++p) {
+            const long wi = (qm * L + l) * P + p;
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * wi);
+            const float a = aw[wi];
+            const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+            float gw = 0.f, gx = 0.f, gy = 0.f;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+                const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+                f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+                if (h0 >= 0 && w0 >= 0) v1 = *reinterpret_cast<const f32x4 *>(vb + ((long)h0 * W + w0) * rowstride);
+                if (h0 >= 0 && w1 <= W - 1) v2 = *reinterpret_cast<const f32x4 *>(vb + ((long)h0 * W + w1) * rowstride);
+                if (h1 <= H - 1 && w0 >= 0) v3 = *reinterpret_cast<const f32x4 *>(vb + ((long)h1 * W + w0) * rowstride);
+                if (h1 <= H - 1 && w1 <= W - 1) v4 = *reinterpret_cast<const f32x4 *>(vb + ((long)h1 * W + w1) * rowstride);
+                const float d1 = tg[0] * v1[0] + tg[1] * v1[1] + tg[2] * v1[2] + tg[3] * v1[3];
+                const float d2 = tg[0] * v2[0] + tg[1] * v2[1] + tg[2] * v2[2] + tg[3] * v2[3];
+                const float d3 = tg[0] * v3[0] + tg[1] * v3[1] + tg[2] * v3[2] + tg[3] * v3[3];
+                const float d4 = tg[0] * v4[0] + tg[1] * v4[1] + tg[2] * v4[2] + tg[3] * v4[3];
+                gw = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;          // cuh:150-155 summed over this lane's channels
+                gx = (float)W * a * (hh * (d2 - d1) + lh * (d4 - d3));                     // d/dx: W * sum_d tg_d * a * grad_w_weight
+                gy = (float)H * a * (hw * (d3 - d1) + lw * (d4 - d2));
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {                       // the head's 8 lanes
+                gw += __shfl_xor(gw, o, 8);
+                gx += __shfl_xor(gx, o, 8);
+                gy += __shfl_xor(gy, o, 8);
+            }
+            if (c == 0) {
+                gaw[wi] = gw;
+                gloc[2 * wi] = gx;
+                gloc[2 * wi + 1] = gy;
+            }
+        }
+    }
+}
+
 int fill_levels(Levels &lv, const int64_t *shapes, const int64_t *lsi, int L, long S)
 {
     if (L < 1 || L > MAX_L) return S2D_ERR_ARG;
@@ -378,6 +557,83 @@ int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const 
     const long items = (long)Lq * M * D;
     hipLaunchKernelGGL(msda_bwd_kernel, dim3(cdiv(items, 256), N), dim3(256), 0, stream, value, lv, loc, attn_w,
                        grad_out, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+
+// Workspace of the atomic-free backward: four u32 arrays of one entry per sample (sort ping-pong), the 16-B sample records, the
+// cell offsets, and rocPRIM's temporaries.
+static size_t sorted_ws_layout(long nsamp, long ncell, size_t *o_keys, size_t *o_vals, size_t *o_rec, size_t *o_off, size_t *o_tmp, size_t *tmp_bytes)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    o_keys[0] = o; o = al(o + (size_t)nsamp * 4);
+    o_keys[1] = o; o = al(o + (size_t)nsamp * 4);
+    o_vals[0] = o; o = al(o + (size_t)nsamp * 4);
+    o_vals[1] = o; o = al(o + (size_t)nsamp * 4);
+    *o_rec = o; o = al(o + (size_t)nsamp * 16);
+    *o_off = o; o = al(o + (size_t)(ncell + 2) * 4);
+    *o_tmp = o;
+    *tmp_bytes = (size_t)(4 * nsamp + (1L << 20)) * 4;
+    return o + *tmp_bytes;
+}
+
+static int fill_cells(Cells &cl, const Levels &lv, int L)
+{
+    long tot = 0;
+    for (int l = 0; l < L; ++l) {
+        cl.base[l] = (int)tot;
+        tot += (long)(lv.H[l] + 1) * (lv.W[l] + 1);
+    }
+    if (tot >= (1L << 31)) return S2D_ERR_ARG;
+    cl.tot = (int)tot;
+    return S2D_OK;
+}
+
+long s2d_msda_backward_workspace_bytes(const int64_t *shapes_host, int N, int M, int L, int Lq, int P)
+{
+    long tot = 0;
+    for (int l = 0; l < L; ++l) tot += (shapes_host[2 * l] + 1) * (shapes_host[2 * l + 1] + 1);
+    size_t a[2], b[2], c, d, e, tb;
+    return (long)sorted_ws_layout((long)N * Lq * M * L * P, (long)N * M * tot, a, b, &c, &d, &e, &tb);
+}
+
+int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                                 const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                                 int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
+                                 long workspace_bytes, hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
+    Cells cl;
+    if (int e = fill_cells(cl, lv, L)) return e;
+    if (D != 32 || !workspace) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    const long nsamp = (long)N * Lq * M * L * P, ncell = (long)N * M * cl.tot;
+    if (nsamp >= (1L << 32) - 1 || ncell >= (1L << 32) - 1) return S2D_ERR_ARG;
+    size_t ok[2], ov[2], orec, oo, ot, tb;
+    if ((long)sorted_ws_layout(nsamp, ncell, ok, ov, &orec, &oo, &ot, &tb) > workspace_bytes) return S2D_ERR_ARG;
+    char *ws = reinterpret_cast<char *>(workspace);
+    unsigned int *keys_in = (unsigned int *)(ws + ok[0]), *keys_out = (unsigned int *)(ws + ok[1]);
+    unsigned int *vals_in = (unsigned int *)(ws + ov[0]), *vals_out = (unsigned int *)(ws + ov[1]);
+    SampleRec *rec = (SampleRec *)(ws + orec);
+    int *off = (int *)(ws + oo);
+    const unsigned int per_n = (unsigned int)((long)Lq * M * L * P);
+    hipLaunchKernelGGL(msda_cell_key_kernel, dim3(cdiv(per_n, 256), N), dim3(256), 0, stream, loc, lv, cl, per_n, M, L, P, (unsigned int)ncell,
+                       keys_in, vals_in);
+    S2D_CHECK_LAUNCH();
+    int bits = 1;
+    while ((1L << bits) <= ncell) ++bits;                    // keys 0 .. ncell (ncell = "outside every map")
+    if (int e = s2d_radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, (size_t)nsamp, bits, ws + ot, tb, stream)) return e;
+    hipLaunchKernelGGL(msda_cell_bounds_kernel, dim3(cdiv(nsamp + 1, 256)), dim3(256), 0, stream, keys_out, vals_out, loc, attn_w,
+                       (unsigned int)nsamp, (unsigned int)ncell, (unsigned int)(L * P), off, rec);
+    const long ntgt = (long)N * S * M;
+    hipLaunchKernelGGL(msda_bwd_value_kernel, dim3(cdiv(ntgt * 8, 256)), dim3(256), 0, stream, grad_out, rec, off, lv, cl, ntgt, S, M, L,
+                       grad_value);
+    const int nb = cdiv((long)Lq * M * 8, 256);
+    hipLaunchKernelGGL(msda_bwd_loc_kernel, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, grad_out, S, M, L, Lq, P, nb, grad_loc,
+                       grad_attn_w);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

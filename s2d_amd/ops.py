@@ -106,12 +106,13 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     """out[..., M, N] = act(A[..., M, K] @ B[(...), N, K]^T * scale + bias + res).
     A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch).  res_rows > 0: res is [res_rows, ldr] and row r of the
     output receives res[r % res_rows]; res_cols > 0: only the first res_cols columns receive it (ldr = res.shape[-1]).
-    dropout = (p, seed, site): act(dropout_p(A @ B^T + bias) + res) with the counter-based mask of csrc/dropout.h fused into
+    dropout = (p, seed, site[, row0]): act(dropout_p(A @ B^T + bias) + res) with the counter-based mask of csrc/dropout.h fused into
     the epilogue (2-D operands, N % 8 == 0)."""
     for t in (A, B, scale, bias, res, out):
         _chk(t)
     if dropout is not None and dropout[0] > 0.0:
-        p, seed, site = dropout
+        p, seed, site = dropout[:3]
+        row0 = dropout[3] if len(dropout) > 3 else 0
         assert A.dim() == 2 and B.dim() == 2 and scale is None and not res_rows and not res_cols
         M, K = A.shape
         N = B.shape[0]
@@ -119,7 +120,7 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
             out = torch.empty((M, N), device=A.device, dtype=torch.float32)
         with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (2 if res is not None else 1)))):
             lib().call("s2d_gemm_nt_dropout_f32", A, B, out, M, N, K, K, K, out.shape[-1], bias, res, res.shape[-1] if res is not None else N,
-                       int(relu), _static_split(B, N, K, K), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), _stream())
+                       int(relu), _static_split(B, N, K, K), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), int(row0), _stream())
         return out
     batched = A.dim() == 3
     bs = A.shape[0] if batched else 1
@@ -142,12 +143,12 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     return out
 
 
-def dropout(x, p, seed, site, out=None):
+def dropout(x, p, seed, site, row0=0, out=None):
     """x [M, N] * mask / (1 - p): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
     _chk(x)
     M, N = x.shape
     y = torch.empty_like(x) if out is None else out
-    lib().call("s2d_dropout_f32", x, M, N, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), y, _stream())
+    lib().call("s2d_dropout_f32", x, M, N, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), int(row0), y, _stream())
     return y
 
 
@@ -200,14 +201,21 @@ def msda_forward(value, shapes, level_start, loc, attn_w):
     return out
 
 
-def msda_backward(value, shapes, level_start, loc, attn_w, grad_out):
+def msda_backward(value, shapes, level_start, loc, attn_w, grad_out, atomics=False):
+    """gradients of msda_forward.  Default: the atomic-free, bitwise reproducible form (sampling graph inverted by a stable sort,
+    grad_value rows gathered); atomics=True: the reference's scatter with float atomics (s2d_msda_backward_f32, needs no workspace)"""
     for t in (value, loc, attn_w, grad_out):
         _chk(t)
     N, S, M, D = value.shape
     Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
     sh, ls = _host_i64(shapes), _host_i64(level_start)
     gv, gl, gw = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn_w)
-    lib().call("s2d_msda_backward_f32", value, sh, ls, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw, _stream())
+    if atomics:
+        lib().call("s2d_msda_backward_f32", value, sh, ls, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw, _stream())
+        return gv, gl, gw
+    nb = lib().call("s2d_msda_backward_workspace_bytes", sh, N, M, L, Lq, P)
+    ws = torch.empty((nb,), device=value.device, dtype=torch.uint8)
+    lib().call("s2d_msda_backward_sorted_f32", value, sh, ls, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw, ws, nb, _stream())
     return gv, gl, gw
 
 

@@ -623,6 +623,77 @@ def g_idmaps():
     save("idmaps", seed=seed, frames=frames, ids=out.numpy().astype(np.int16), n_ids=np.array([int(out[t].max()) for t in range(T)]))
 
 
+from formats_case import formats_case as _formats_case, tree as _tree  # noqa: E402
+
+
+def g_formats():
+    """On-disk formats either side of keymask discovery, written by the reference's own functions into temporary directories:
+    keymask_utils.save_segmentation_masks (:70-126), cotracker_matching.save_temporal_group_masks (:402-431),
+    annotations.write_annotation_for_video (:8-139), merge_ytvis_jsons.main (:24-96).  The fixture holds the resulting file
+    lists, PNG pixels and JSON documents.  Third-party names absent from the image are stood in for by name: imageio (imported,
+    unused on this path) and pycocotools.mask, whose encode / area / toBbox are served by the oracle's restatement of maskApi.c
+    (so the RLE strings inside the annotation JSON are the oracle's: parity unpinned, as everywhere for that format)."""
+    import json
+    import tempfile
+    import types
+    from PIL import Image
+    from oracle import oracle_np as O
+    R.install()
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    pm = types.ModuleType("pycocotools.mask")
+
+    def encode(arr):                                                   # [H,W,F] Fortran uint8 -> list of RLE dicts
+        return [dict(size=[arr.shape[0], arr.shape[1]], counts=O.rle_encode(np.ascontiguousarray(arr[..., f]))[0]["counts"]) for f in range(arr.shape[2])]
+    pm.encode = encode
+    pm.area = lambda r: O.rle_area_bbox(O.rle_decode(r))[0]
+    pm.toBbox = lambda r: np.asarray(O.rle_area_bbox(O.rle_decode(r))[1], np.float64)
+    pk = types.ModuleType("pycocotools"); pk.mask = pm
+    sys.modules["pycocotools"], sys.modules["pycocotools.mask"] = pk, pm
+    ku, cm, an, mg = R.ref("keymask_utils"), R.ref("cotracker_matching"), R.ref("annotations"), R.ref("merge_ytvis_jsons")
+    c = _formats_case()
+    T, H, W = c["T"], c["H"], c["W"]
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        lbls = torch.from_numpy(c["ids"])
+        vdir = ku.save_segmentation_masks(torch.zeros(T, 3, H, W), torch.zeros(T, 3, H, W), lbls, {"visibility": c["visibility"]}, os.path.join(d, "masks"))
+        files, arrays = _tree(os.path.join(d, "masks"))
+        out["seg_files"], out["seg_video_dir"] = files, os.path.relpath(vdir, d)
+        seg_arrays = arrays
+        # cluster_masks for the grouping step: per cluster the list of {'frame_id','mask_id','mask'} (what load_cluster_masks builds)
+        cluster_masks = []
+        for cid in range(2):
+            lst = []
+            for rel, a in sorted(arrays.items()):
+                m = __import__("re").match(rf"vid_0007/cluster_{cid}/cluster{cid}_frame(\d+)_mask(-?\d+)\.png", rel)
+                if m:
+                    lst.append({"frame_id": int(m.group(1)), "mask_id": int(m.group(2)), "mask": a})
+            cluster_masks.append(lst)
+        gpath = os.path.join(d, "masks", "vid_0007")
+        os.makedirs(os.path.join(gpath, "cluster_0", "group_9"))        # a stale group directory must disappear
+        cm.save_temporal_group_masks(c["groupings"], cluster_masks, gpath)
+        files2, arrays2 = _tree(gpath)
+        out["group_files"] = files2
+        json.dump(c["one2x"], open(os.path.join(gpath, "video_one2x_data.json"), "w"))
+        vpath = os.path.join(d, "frames", "vid_0007")
+        os.makedirs(vpath)
+        for t in range(T):
+            Image.fromarray(np.zeros((H, W, 3), np.uint8)).save(os.path.join(vpath, f"{t:05d}.jpg"))
+        an.write_annotation_for_video(vpath, gpath, os.path.join(d, "ann"), c["visibility"])
+        out["annotation"] = json.load(open(os.path.join(d, "ann", "vid_0007.json")))
+        src = os.path.join(d, "per_video")
+        os.makedirs(src)
+        for i, doc in enumerate(c["merge_inputs"]):
+            json.dump(doc, open(os.path.join(src, f"video_{i:02d}.json"), "w"))
+        for name, thr in (("merged_all", -1.0), ("merged_filtered", 0.5)):
+            mg.main(src, os.path.join(d, name + ".json"), thr)
+            out[name] = json.load(open(os.path.join(d, name + ".json")))
+        np.savez_compressed(os.path.join(HERE, "formats_png.npz"), **{"seg/" + k: v for k, v in seg_arrays.items()},
+                            **{"grp/" + k: v for k, v in arrays2.items()})
+    with open(os.path.join(HERE, "formats.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("  wrote formats.json, formats_png.npz")
+
+
 def g_config():
     """the shipped KD training configuration as the trainer resolves it: configs/imagenet_video/
     ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml merged over its _BASE_ (yaml data, key -> value; python tuples
@@ -668,7 +739,7 @@ def main():
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

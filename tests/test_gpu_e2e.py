@@ -6,6 +6,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+TIES = []
+
+
+def _same_assignment(iq, it, ri, rj, C):
+    """Hungarian indices bit-exact -- except a PROVEN tie: when the two assignments differ, the oracle's own float64 cost of
+    ours must equal its optimum to within fp32 cost rounding (2e-6 of the largest entry per matched pair).  Random-init
+    teachers emit near-duplicate masks for different queries, whose columns of C then differ by less than the rounding of
+    either implementation's sums; such a case is recorded in TIES, not hidden."""
+    if np.array_equal(iq, ri) and np.array_equal(it, rj):
+        return
+    C = C.astype(np.float64)
+    ours, best = C[iq, it].sum(), C[ri, rj].sum()
+    assert sorted(it.tolist()) == sorted(rj.tolist()) and len(set(iq.tolist())) == len(iq)
+    assert abs(ours - best) <= 2e-6 * np.abs(C).max() * len(ri), (ours, best, iq, it, ri, rj)
+    TIES.append((float(ours - best), int((it != rj).sum() + (iq != ri).sum())))
+
+
 def _check(hip, ref, B, NL):
     # mask logits and class logits of all 10 prediction heads: 1e-3 relative (north star)
     for k in ("s_logits", "s_masks"):
@@ -19,8 +36,7 @@ def _check(hip, ref, B, NL):
             ri, rj = ref["idx_kd"][li][b]
             prob = layer * B + b
             assert nm[prob] == len(ri)
-            np.testing.assert_array_equal(iq[prob, :len(ri)], ri)      # Hungarian indices bit-exact
-            np.testing.assert_array_equal(it[prob, :len(ri)], rj)
+            _same_assignment(iq[prob, :len(ri)], it[prob, :len(ri)], ri, rj, ref["cost_kd"][li][b])
     assert sorted(hip["losses"]) == sorted(ref["losses"])
     for k, v in ref["losses"].items():
         np.testing.assert_allclose(hip["losses"][k], float(v), rtol=1e-3, atol=1e-6, err_msg=k)
@@ -48,7 +64,8 @@ def test_config2_480p_two_frames_q100_both_meta_archs(oracle):
     import torch
     from s2d_amd.modeling import TargetSet, VideoMaskFormer, VideoSetCriterion
     from tests.parity import run_case
-    hip, ref = run_case(oracle, seed=5, B=1, T=2, H0=480, W0=854, Q=100, P=12544, ns=(10,))
+    hip, ref = run_case(oracle, seed=5, B=1, T=2, H0=480, W0=854, Q=100, P=12544, ns=(10,), kd_want=10)
+    assert 5 <= hip["kd_counts"][0] <= 15
     assert hip["s_masks"].shape[-2:] == (120, 216)
     _check(hip, ref, 1, 10)
     kd = hip["model"]
@@ -68,5 +85,6 @@ def test_config2_480p_two_frames_q100_both_meta_archs(oracle):
     for li, layer in enumerate(order):
         ri, rj = ref["idx_gt"][li][0]
         assert nm[layer] == len(ri)
-        np.testing.assert_array_equal(iq[layer, :len(ri)], ri)
+        np.testing.assert_array_equal(iq[layer, :len(ri)], ri)          # ground-truth targets are distinct objects: no ties
         np.testing.assert_array_equal(it[layer, :len(ri)], rj)
+    print("config 2: proven near-tie assignments (cost difference, differing entries):", TIES)
