@@ -451,6 +451,37 @@ int s2d_prof_event_record(long ev, hipStream_t stream);
 int s2d_prof_event_elapsed(long ev_start, long ev_end, double *out_ms_host);
 int s2d_prof_event_destroy(long ev);
 
+/* ---- data-side step before the hot path: clip augmentation and video copy-paste on the device ---------- */
+
+/* The dataset mapper's augmentation chain (data_video/dataset_mapper.py:306-404 with augmentation.py:116-168: crop,
+ * resize-shortest-edge, flip, brightness, contrast, rotation) as one resampling pass per frame.  frames u8 [T][3][H0][W0] ->
+ * out u8 [T][3][H1][W1].  aug_frames_dev: DEVICE array of T records of 16 floats
+ *   {a11, a12, a13, a21, a22, a23,  cx, cy, cw, ch,  bright, contrast, cmean, 0, 0, 0}:
+ * output pixel centre (x + .5, y + .5) -> source point A . (x + .5, y + .5, 1); read only inside the crop rectangle
+ * (outside: 0, the rotation fill; taps clamped to it); bilinear -> round -> brightness (img * w, clip, truncate) ->
+ * contrast ((1 - w) * cmean + w * img, clip, truncate), the BlendTransform arithmetic.  cmean < 0: filled in by the call with
+ * the crop's mean x bright (what RandomContrast measures).  detectron2 (absent from the reference tree) runs one image pass
+ * per transform; the single-pass composition is this library's definition: parity unpinned. */
+int s2d_aug_warp_frames_u8(const uint8_t *frames, int T, int H0, int W0, void *aug_frames_dev, int H1, int W1, uint8_t *out,
+                           hipStream_t stream);
+/* instance masks u8 [N][T][H0][W0] (0 / non-0) -> u8 [N][T][H1][W1] (0 / 1) under the same per-frame maps, nearest source
+ * pixel (apply_segmentation). */
+int s2d_aug_warp_masks_u8(const uint8_t *masks, int N, int T, int H0, int W0, const void *aug_frames_dev, int H1, int W1, uint8_t *out,
+                          hipStream_t stream);
+
+/* Video copy-paste, engine/train_loop.py:441-560: K source masks [K][Hs][Ws] and their frame [3][Hs][Ws] are resized to
+ * (h_new, w_new) per target frame with F.interpolate(bilinear, align_corners=False) (image .byte(), masks .bool()), placed at
+ * (h_shift, w_shift) and composited over the target clip: out_frames u8 [T][3][H][W]; out_masks u8 [N+K][T][H][W] = the N
+ * target masks minus the pasted area, then the K pasted masks (all zero for copies with keep[k] == 0).  paste_frames_dev:
+ * DEVICE int32 [T][4] = {h_new, w_new, h_shift, w_shift}; keep_dev: DEVICE u8 [K].
+ * s2d_copy_paste_overlap: counts[k][n] = |pasted copy k AND target n| and area[n] = |target n| on frame 0, the integers behind
+ * the "intersection over target area < 0.5" rule that decides keep (:515-527). */
+int s2d_copy_paste_overlap(const uint8_t *tgt_masks, int N, int T, int H, int W, const uint8_t *src_masks, int K, int Hs, int Ws, int h_new,
+                           int w_new, int h_shift, int w_shift, int *counts, int *area, hipStream_t stream);
+int s2d_copy_paste_u8(const uint8_t *tgt_frames, const uint8_t *tgt_masks, int N, int T, int H, int W, const uint8_t *src_frame,
+                      const uint8_t *src_masks, int K, int Hs, int Ws, const int *paste_frames_dev, const uint8_t *keep_dev,
+                      uint8_t *out_frames, uint8_t *out_masks, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -821,3 +821,60 @@ def rle_area_bbox(mask):
         return 0, [0.0, 0.0, 0.0, 0.0]
     ys, xs = np.nonzero(m)
     return int(m.sum()), [float(xs.min()), float(ys.min()), float(xs.max() - xs.min() + 1), float(ys.max() - ys.min() + 1)]
+
+
+# --------------------------------------------------------------------------- data-side step
+def aug_warp_frames(frames, params, out_hw):
+    """restatement of s2d_aug_warp_frames_u8 (the single-pass composition of the mapper's augmentation list,
+    data_video/augmentation.py:116-168 over detectron2 / fvcore transforms: parity unpinned, see csrc/augment.hip).
+    frames u8 [T,3,H0,W0], params f32 [T,16] -> u8 [T,3,H1,W1].  float32 arithmetic in the kernel's operation order."""
+    f32 = np.float32
+    T, _, H0, W0 = frames.shape
+    H1, W1 = out_hw
+    out = np.zeros((T, 3, H1, W1), np.uint8)
+    px = (np.arange(W1, dtype=f32) + f32(0.5))[None, :]
+    py = (np.arange(H1, dtype=f32) + f32(0.5))[:, None]
+    for t in range(T):
+        a11, a12, a13, a21, a22, a23, cx, cy, cw, ch, bright, contrast, cmean = (f32(v) for v in params[t, :13])
+        sx = a11 * px + a12 * py + a13
+        sy = a21 * px + a22 * py + a23
+        inside = (sx >= cx) & (sy >= cy) & (sx < cx + cw) & (sy < cy + ch)
+        fx, fy = sx - f32(0.5), sy - f32(0.5)
+        x0f, y0f = np.floor(fx), np.floor(fy)
+        lx, ly = fx - x0f, fy - y0f
+        xl, xh, yl, yh = int(cx), int(cx + cw) - 1, int(cy), int(cy + ch) - 1
+        x0 = np.clip(x0f.astype(np.int64), xl, xh); x1 = np.clip(x0f.astype(np.int64) + 1, xl, xh)
+        y0 = np.clip(y0f.astype(np.int64), yl, yh); y1 = np.clip(y0f.astype(np.int64) + 1, yl, yh)
+        if cmean < 0:
+            crop = frames[t, :, yl:yh + 1, xl:xh + 1].astype(np.float64)
+            cmean = f32(f32(crop.sum() / crop.size) * bright)
+        one = f32(1.0)
+        for c in range(3):
+            p = frames[t, c].astype(f32)
+            v = (one - ly) * ((one - lx) * p[y0, x0] + lx * p[y0, x1]) + ly * ((one - lx) * p[y1, x0] + lx * p[y1, x1])
+            q = np.rint(v).astype(f32)
+            if bright != 1:
+                q = np.trunc(np.clip(bright * q, f32(0), f32(255)))
+            if contrast != 1:
+                q = np.trunc(np.clip((one - contrast) * cmean + contrast * q, f32(0), f32(255)))
+            out[t, c] = np.where(inside, q, 0).astype(np.uint8)
+    return out
+
+
+def aug_warp_masks(masks, params, out_hw):
+    """masks u8 [N,T,H0,W0] -> u8 [N,T,H1,W1] (0/1): nearest source pixel under the same per-frame maps"""
+    f32 = np.float32
+    N, T, H0, W0 = masks.shape
+    H1, W1 = out_hw
+    out = np.zeros((N, T, H1, W1), np.uint8)
+    px = (np.arange(W1, dtype=f32) + f32(0.5))[None, :]
+    py = (np.arange(H1, dtype=f32) + f32(0.5))[:, None]
+    for t in range(T):
+        a11, a12, a13, a21, a22, a23, cx, cy, cw, ch = (f32(v) for v in params[t, :10])
+        sx = a11 * px + a12 * py + a13
+        sy = a21 * px + a22 * py + a23
+        inside = (sx >= cx) & (sy >= cy) & (sx < cx + cw) & (sy < cy + ch)
+        iy = np.clip(np.floor(sy).astype(np.int64), 0, H0 - 1); ix = np.clip(np.floor(sx).astype(np.int64), 0, W0 - 1)
+        for n in range(N):
+            out[n, t] = np.where(inside, masks[n, t][iy, ix] != 0, 0)
+    return out

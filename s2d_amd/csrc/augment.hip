@@ -1,0 +1,239 @@
+// Data-side step before the hot path, on the device: the clip augmentation of the dataset mapper
+// (model_training/mask2former_video/data_video/dataset_mapper.py:306-404 with the augmentation list of
+// augmentation.py:116-168: crop, resize-shortest-edge, flip, brightness, contrast, rotation) as ONE resampling pass per
+// frame, and the video copy-paste of the trainer (engine/train_loop.py:377-590).  HBM-bound byte kernels, no MFMA.
+//
+// The reference runs these on the host through detectron2 / fvcore / PIL / cv2 transforms, one image pass per transform;
+// detectron2 is not in the reference tree, so the geometric + photometric chain here follows the published semantics of those
+// transforms composed into a single inverse affine map per frame (parity unpinned for that part).  The copy-paste
+// arithmetic in the reference is plain torch (F.interpolate + compositing) and is followed exactly.
+#include "common.h"
+
+namespace {
+
+// One frame's augmentation: output pixel centre (x + 0.5, y + 0.5) -> source point (sx, sy) = A . (x + 0.5, y + 0.5, 1).
+// The source is read inside the crop rectangle [cx, cx + cw) x [cy, cy + ch) only: points outside it give 0 (rotation
+// fill), taps are clamped to it (edge replication, as a resize of the cropped image would).
+struct AugFrame {
+    float a11, a12, a13, a21, a22, a23;
+    float cx, cy, cw, ch;
+    float bright;      // RandomBrightness: img * w                      (1 = off)
+    float contrast;    // RandomContrast:  (1 - w) * mean + w * img      (1 = off)
+    float cmean;       // the mean the contrast blend pulls towards (filled by aug_crop_mean_kernel when < 0)
+    float pad0, pad1, pad2;
+};
+
+__global__ __launch_bounds__(256) void aug_crop_mean_kernel(const uint8_t *__restrict__ src, int H0, int W0, AugFrame *__restrict__ fr)
+{
+    // mean over the 3 channels of the crop rectangle of frame blockIdx.x, times the brightness weight: what image.mean() is
+    // when RandomContrast draws its transform (after crop, resize, flip and brightness)
+    __shared__ double part[256];
+    const int t = blockIdx.x;
+    AugFrame f = fr[t];
+    const int x0 = (int)f.cx, y0 = (int)f.cy, w = (int)f.cw, h = (int)f.ch;
+    double s = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const uint8_t *p = src + ((long)t * 3 + c) * H0 * W0;
+        for (long i = threadIdx.x; i < (long)w * h; i += 256) s += p[(long)(y0 + i / w) * W0 + x0 + i % w];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && f.cmean < 0.f) fr[t].cmean = (float)(part[0] / (3.0 * w * h)) * f.bright;
+}
+
+__device__ __forceinline__ float trunc_u8(float v) { return truncf(fminf(fmaxf(v, 0.f), 255.f)); }
+
+__global__ __launch_bounds__(256) void aug_warp_frames_kernel(const uint8_t *__restrict__ src, int H0, int W0, const AugFrame *__restrict__ fr,
+                                                              int H1, int W1, uint8_t *__restrict__ out)
+{
+    const int t = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W1) return;
+    const AugFrame f = fr[t];
+    const float px = x + 0.5f, py = y + 0.5f;
+    const float sx = f.a11 * px + f.a12 * py + f.a13, sy = f.a21 * px + f.a22 * py + f.a23;
+    uint8_t r[3] = {0, 0, 0};
+    if (sx >= f.cx && sy >= f.cy && sx < f.cx + f.cw && sy < f.cy + f.ch) {
+        const float fx = sx - 0.5f, fy = sy - 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const float lx = fx - x0f, ly = fy - y0f;
+        const int xl = (int)f.cx, xh = (int)(f.cx + f.cw) - 1, yl = (int)f.cy, yh = (int)(f.cy + f.ch) - 1;
+        const int x0 = min(max((int)x0f, xl), xh), x1 = min(max((int)x0f + 1, xl), xh);
+        const int y0 = min(max((int)y0f, yl), yh), y1 = min(max((int)y0f + 1, yl), yh);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t *p = src + ((long)t * 3 + c) * H0 * W0;
+            const float v = (1.f - ly) * ((1.f - lx) * p[(long)y0 * W0 + x0] + lx * p[(long)y0 * W0 + x1]) +
+                            ly * ((1.f - lx) * p[(long)y1 * W0 + x0] + lx * p[(long)y1 * W0 + x1]);
+            float q = rintf(v);                                               // the resampled uint8 image
+            if (f.bright != 1.f) q = trunc_u8(f.bright * q);                  // BlendTransform: clip, astype(uint8)
+            if (f.contrast != 1.f) q = trunc_u8((1.f - f.contrast) * f.cmean + f.contrast * q);
+            r[c] = (uint8_t)q;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(((long)t * 3 + c) * H1 + y) * W1 + x] = r[c];
+}
+
+// masks [N][T][H0][W0] (0 / non-0) -> [N][T][H1][W1] (0 / 1): nearest source pixel under the same map (apply_segmentation)
+__global__ __launch_bounds__(256) void aug_warp_masks_kernel(const uint8_t *__restrict__ src, int T, int H0, int W0,
+                                                             const AugFrame *__restrict__ fr, int H1, int W1, uint8_t *__restrict__ out)
+{
+    const int nt = blockIdx.z, t = nt % T, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W1) return;
+    const AugFrame f = fr[t];
+    const float px = x + 0.5f, py = y + 0.5f;
+    const float sx = f.a11 * px + f.a12 * py + f.a13, sy = f.a21 * px + f.a22 * py + f.a23;
+    uint8_t r = 0;
+    if (sx >= f.cx && sy >= f.cy && sx < f.cx + f.cw && sy < f.cy + f.ch)
+        r = src[((long)nt * H0 + (int)floorf(sy)) * W0 + (int)floorf(sx)] != 0;
+    out[((long)nt * H1 + y) * W1 + x] = r;
+}
+
+// ---- video copy-paste (engine/train_loop.py:441-560) ---------------------------------------------------------------
+// Per target frame f: the K copied source masks and the source frame are resized to (h_new, w_new) with
+// F.interpolate(bilinear, align_corners=False) -- image `.byte()` (truncation), masks `.bool()` (non-zero) -- and placed at
+// (h_shift, w_shift) of an empty canvas (:470-500); alpha = any kept copied mask (:540); the composite takes the source
+// pixel under alpha (:546); every target mask loses alpha (:541); the copied masks become new instances (:548).
+struct PasteFrame { int h_new, w_new, h_shift, w_shift; };
+
+__device__ __forceinline__ void bilin_taps(int dst, int in_size, int out_size, int &i0, int &i1, float &l1)
+{
+    float s = ((float)in_size / out_size) * (dst + 0.5f) - 0.5f;         // ATen area_pixel_compute_source_index, align_corners=False
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - i0;
+}
+
+__global__ __launch_bounds__(256) void copy_paste_kernel(const uint8_t *__restrict__ tgt_frames, const uint8_t *__restrict__ tgt_masks, int N, int T,
+                                                         int H, int W, const uint8_t *__restrict__ src_frame, const uint8_t *__restrict__ src_masks,
+                                                         int K, int Hs, int Ws, const PasteFrame *__restrict__ pf, const uint8_t *__restrict__ keep,
+                                                         uint8_t *__restrict__ out_frames, uint8_t *__restrict__ out_masks)
+{
+    const int t = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const PasteFrame p = pf[t];
+    const int yy = y - p.h_shift, xx = x - p.w_shift;
+    const bool in = yy >= 0 && xx >= 0 && yy < p.h_new && xx < p.w_new;
+    int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+    float ly = 0.f, lx = 0.f;
+    if (in) {
+        bilin_taps(yy, Hs, p.h_new, y0, y1, ly);
+        bilin_taps(xx, Ws, p.w_new, x0, x1, lx);
+    }
+    bool alpha = false;
+    for (int k = 0; k < K; ++k) {
+        bool m = false;
+        if (in) {
+            const uint8_t *s = src_masks + (long)k * Hs * Ws;
+            const float v = (1.f - ly) * ((1.f - lx) * (s[(long)y0 * Ws + x0] != 0) + lx * (s[(long)y0 * Ws + x1] != 0)) +
+                            ly * ((1.f - lx) * (s[(long)y1 * Ws + x0] != 0) + lx * (s[(long)y1 * Ws + x1] != 0));
+            m = v != 0.f;                                                    // .bool()
+        }
+        out_masks[(((long)(N + k) * T + t) * H + y) * W + x] = m && keep[k];
+        alpha = alpha || (m && keep[k]);
+    }
+    for (int n = 0; n < N; ++n) {
+        const long i = (((long)n * T + t) * H + y) * W + x;
+        out_masks[i] = alpha ? 0 : (tgt_masks[i] != 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long i = (((long)t * 3 + c) * H + y) * W + x;
+        uint8_t v = tgt_frames[i];
+        if (alpha) {
+            const uint8_t *s = src_frame + (long)c * Hs * Ws;
+            const float f = (1.f - ly) * ((1.f - lx) * s[(long)y0 * Ws + x0] + lx * s[(long)y0 * Ws + x1]) +
+                            ly * ((1.f - lx) * s[(long)y1 * Ws + x0] + lx * s[(long)y1 * Ws + x1]);
+            v = (uint8_t)f;                                                  // .byte(): truncation
+        }
+        out_frames[i] = v;
+    }
+}
+
+// counts[k][n] = #(pasted copy k of frame 0 AND target mask n of frame 0), area[n] = #target mask n: the "ioy" test of :515-527
+__global__ __launch_bounds__(256) void copy_paste_overlap_kernel(const uint8_t *__restrict__ tgt_masks, int N, int T, int H, int W,
+                                                                 const uint8_t *__restrict__ src_masks, int K, int Hs, int Ws, PasteFrame p,
+                                                                 int *__restrict__ counts, int *__restrict__ area)
+{
+    const int k = blockIdx.x, n = blockIdx.y;
+    const uint8_t *tm = tgt_masks + ((long)n * T) * H * W;                   // frame 0
+    const uint8_t *s = src_masks + (long)k * Hs * Ws;
+    int c = 0, a = 0;
+    for (long i = threadIdx.x; i < (long)H * W; i += 256) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const bool tv = tm[i] != 0;
+        a += tv;
+        const int yy = y - p.h_shift, xx = x - p.w_shift;
+        if (tv && yy >= 0 && xx >= 0 && yy < p.h_new && xx < p.w_new) {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilin_taps(yy, Hs, p.h_new, y0, y1, ly);
+            bilin_taps(xx, Ws, p.w_new, x0, x1, lx);
+            const float v = (1.f - ly) * ((1.f - lx) * (s[(long)y0 * Ws + x0] != 0) + lx * (s[(long)y0 * Ws + x1] != 0)) +
+                            ly * ((1.f - lx) * (s[(long)y1 * Ws + x0] != 0) + lx * (s[(long)y1 * Ws + x1] != 0));
+            c += v != 0.f;
+        }
+    }
+    __shared__ int sc[256], sa[256];
+    sc[threadIdx.x] = c; sa[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sc[threadIdx.x] += sc[threadIdx.x + o]; sa[threadIdx.x] += sa[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counts[k * N + n] = sc[0]; if (k == 0) area[n] = sa[0]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2d_aug_warp_frames_u8(const uint8_t *frames, int T, int H0, int W0, void *aug_frames_dev, int H1, int W1, uint8_t *out,
+                           hipStream_t stream)
+{
+    if (T <= 0 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0 || H1 > 65535) return S2D_ERR_ARG;
+    AugFrame *fr = reinterpret_cast<AugFrame *>(aug_frames_dev);
+    hipLaunchKernelGGL(aug_crop_mean_kernel, dim3(T), dim3(256), 0, stream, frames, H0, W0, fr);
+    hipLaunchKernelGGL(aug_warp_frames_kernel, dim3(cdiv(W1, 256), H1, T), dim3(256), 0, stream, frames, H0, W0, fr, H1, W1, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_aug_warp_masks_u8(const uint8_t *masks, int N, int T, int H0, int W0, const void *aug_frames_dev, int H1, int W1, uint8_t *out,
+                          hipStream_t stream)
+{
+    if (N < 0 || T <= 0 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0 || H1 > 65535 || (long)N * T > 65535) return S2D_ERR_ARG;
+    if (N == 0) return S2D_OK;
+    hipLaunchKernelGGL(aug_warp_masks_kernel, dim3(cdiv(W1, 256), H1, N * T), dim3(256), 0, stream, masks, T, H0, W0,
+                       reinterpret_cast<const AugFrame *>(aug_frames_dev), H1, W1, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_copy_paste_overlap(const uint8_t *tgt_masks, int N, int T, int H, int W, const uint8_t *src_masks, int K, int Hs, int Ws, int h_new,
+                           int w_new, int h_shift, int w_shift, int *counts, int *area, hipStream_t stream)
+{
+    if (N <= 0 || K <= 0 || T <= 0 || h_new <= 0 || w_new <= 0) return S2D_ERR_ARG;
+    PasteFrame p{h_new, w_new, h_shift, w_shift};
+    hipLaunchKernelGGL(copy_paste_overlap_kernel, dim3(K, N), dim3(256), 0, stream, tgt_masks, N, T, H, W, src_masks, K, Hs, Ws, p, counts, area);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_copy_paste_u8(const uint8_t *tgt_frames, const uint8_t *tgt_masks, int N, int T, int H, int W, const uint8_t *src_frame,
+                      const uint8_t *src_masks, int K, int Hs, int Ws, const int *paste_frames_dev, const uint8_t *keep_dev,
+                      uint8_t *out_frames, uint8_t *out_masks, hipStream_t stream)
+{
+    if (N < 0 || K <= 0 || T <= 0 || H <= 0 || W <= 0 || H > 65535) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(copy_paste_kernel, dim3(cdiv(W, 256), H, T), dim3(256), 0, stream, tgt_frames, tgt_masks, N, T, H, W, src_frame, src_masks, K,
+                       Hs, Ws, reinterpret_cast<const PasteFrame *>(paste_frames_dev), keep_dev, out_frames, out_masks);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+}  // extern "C"

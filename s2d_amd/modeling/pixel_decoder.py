@@ -128,11 +128,6 @@ class MSDeformAttn(nn.Module):
         return ops.gemm_nt(out.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias).view(N, Lq, C)
 
 
-import os as _os
-
-FFN_CHUNK_ROWS = int(_os.environ.get("S2D_FFN_CHUNK_ROWS", "0"))      # experiment knob, see MSDeformAttnTransformerEncoderLayer.forward
-
-
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, n_levels=3, n_heads=8, n_points=4):
         super().__init__()
@@ -155,20 +150,6 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         sub = [] if tape is not None else None
         x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1)
         s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
-        ck = FFN_CHUNK_ROWS if tape is None else 0
-        if ck and N * S > ck:
-            # forward-only path: the 1024-wide hidden activation of a row chunk is consumed by linear2 right after linear1 wrote
-            # it, into the same scratch buffer every time, so it lives in the 256 MB Infinity Cache instead of making a round
-            # trip through HBM (1.27 GB written + read per layer at config c4).  Same kernels, same arithmetic, same result.
-            s1f = s1.view(-1, C)
-            x2f = torch.empty_like(s1f)
-            hbuf = torch.empty((ck, self.linear1.out_features), device=src.device, dtype=torch.float32)
-            for r0 in range(0, N * S, ck):
-                r1 = min(r0 + ck, N * S)
-                hh = ops.gemm_nt(s1f[r0:r1], self.linear1.weight, bias=self.linear1.bias, relu=True, out=hbuf[:r1 - r0],
-                                 dropout=d2 + (r0,) if d2 else None)
-                ops.gemm_nt(hh, self.linear2.weight, bias=self.linear2.bias, res=s1f[r0:r1], out=x2f[r0:r1], dropout=d3 + (r0,) if d3 else None)
-            return ops.layernorm(x2f.view(N, S, C), self.norm2.weight, self.norm2.bias)
         h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True, dropout=d2)
         x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C), dropout=d3).view(N, S, C)
         if tape is not None:

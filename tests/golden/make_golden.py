@@ -694,6 +694,96 @@ def g_formats():
     print("  wrote formats.json, formats_png.npz")
 
 
+def _sampling_cases():
+    """video annotation skeletons (only the ids per frame matter) for the frame-selection goldens"""
+    rng = np.random.default_rng(17)
+    cases = []
+    for L in (12, 30, 7, 3):
+        annos = []
+        for t in range(L):
+            present = [i for i in range(4) if rng.random() < (0.75 if L != 7 else 0.3)]
+            annos.append([{"id": i} for i in present])
+        cases.append((L, annos))
+    return cases
+
+
+def g_sampling():
+    """dataset_mapper.py:223-289 dense_frame_selection / random_frame_selection and augmentation.py:51-75 (the size rule of
+    ResizeShortestEdge) called on the reference's own classes.  detectron2 / fvcore names the two files import are stood in for
+    by name only (none of them is touched by these methods)."""
+    import json
+    import random
+    import types
+    R.install()
+
+    class _Aug:
+        def _init(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+
+        def _rand_range(self, low=1.0, high=None, size=None):
+            if high is None:
+                low, high = 0, low
+            return np.random.uniform(low, high, size)
+
+    class _Tf:
+        def __init__(self, *a, **k):
+            self.args = a
+
+        def _set_attributes(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+
+        @classmethod
+        def register_type(cls, *a, **k):
+            pass
+    T = types.ModuleType("detectron2.data.transforms"); T.Augmentation = _Aug; T.Transform = _Tf; T.AugmentationList = list
+    T.RandomCrop = T.RandomBrightness = T.RandomContrast = T.RandomSaturation = T.RandomRotation = T.ResizeShortestEdge = _Tf
+    dd = sys.modules["detectron2.data"]; dd.transforms = T; dd.detection_utils = types.ModuleType("detectron2.data.detection_utils")
+    sys.modules["detectron2.data.transforms"], sys.modules["detectron2.data.detection_utils"] = T, dd.detection_utils
+    st = sys.modules["detectron2.structures"]; st.BoxMode = object
+    ft = types.ModuleType("fvcore.transforms"); ftt = types.ModuleType("fvcore.transforms.transform")
+    for n in ("BlendTransform", "TransformList", "HFlipTransform", "NoOpTransform", "VFlipTransform", "CropTransform", "Transform"):
+        setattr(ft, n, _Tf); setattr(ftt, n, _Tf)
+    ft.transform = ftt
+    sys.modules["fvcore.transforms"], sys.modules["fvcore.transforms.transform"] = ft, ftt
+    del sys.modules["mask2former_video.data_video.dataset_mapper"]          # the shim's name-only stand-in: load the real file here
+    dm = R.ref("mask2former_video.data_video.dataset_mapper")
+    au = R.ref("mask2former_video.data_video.augmentation")
+    out = {"dense": [], "random": [], "resize": []}
+    for ci, (L, annos) in enumerate(_sampling_cases()):
+        for n, fr, shuffle in ((3, 5, False), (2, 2, True), (5, 20, False)):
+            self_ = types.SimpleNamespace(sampling_frame_num=n, sampling_frame_range=fr, sampling_frame_shuffle=shuffle)
+            for seed in range(6):
+                random.seed(seed); np.random.seed(seed)
+                sel = dm.YTVISDatasetMapper.dense_frame_selection(self_, annos, L)
+                out["dense"].append({"case": ci, "n": n, "range": fr, "shuffle": shuffle, "seed": seed, "sel": [int(v) for v in sel]})
+                if L > 2 * fr or n - 1 <= L:
+                    random.seed(seed); np.random.seed(seed)
+                    try:
+                        sel = dm.YTVISDatasetMapper.random_frame_selection(self_, L)
+                        out["random"].append({"L": L, "n": n, "range": fr, "shuffle": shuffle, "seed": seed, "sel": [int(v) for v in sel]})
+                    except ValueError:
+                        pass
+    for style, sizes in (("choice_by_clip", (360, 480)), ("range", (320, 640)), ("choice", (288, 320, 352))):
+        for (h, w) in ((720, 1280), (480, 854), (1080, 608)):
+            for max_size in (10 ** 9, 768):
+                r = au.ResizeShortestEdge(sizes, max_size, style, clip_frame_cnt=3 if "by_clip" in style else 1)
+                np.random.seed(7)
+                got = []
+                for _ in range(6):
+                    tr = r.get_transform(np.zeros((h, w, 3), np.uint8))
+                    got.append([int(tr.new_h), int(tr.new_w)])
+                out["resize"].append({"style": style, "sizes": list(sizes), "hw": [h, w], "max_size": max_size, "new_hw": got})
+    with open(os.path.join(HERE, "sampling.json"), "w") as f:
+        json.dump(out, f)
+    print("  wrote sampling.json:", {k: len(v) for k, v in out.items()})
+
+
 def g_config():
     """the shipped KD training configuration as the trainer resolves it: configs/imagenet_video/
     ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml merged over its _BASE_ (yaml data, key -> value; python tuples
@@ -739,7 +829,7 @@ def main():
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats, g_sampling):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)
