@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--one-stream", "--no-overlap", dest="one_stream", action="store_true",
                     help="time the one-stream schedule (default: teacher forward + GT criterion on a second HIP stream; the other "
                          "schedule is timed after the metric and reported under `schedules`, with a bitwise comparison of the losses)")
+    ap.add_argument("--no-other-schedule", action="store_true",
+                    help="profiling runs: time only the chosen schedule (no second timing pass, no bitwise comparison), so that a kernel "
+                         "trace of the process holds one schedule's launches")
     ap.add_argument("--dense-breakdown", action="store_true", help="print per-shape time of the dense launches to stderr")
     ap.add_argument("--dense", default="f16x3", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the dense contractions (all three are fp32-in/fp32-out)")
@@ -383,17 +386,19 @@ def main():
     assert bool(torch.isfinite(total)), "non-finite loss"
     # the other schedule, timed the same way after the metric, and a bitwise comparison of all 42 losses between the two
     # schedules on the same seeds (every kernel is deterministic, so the schedule must not change a bit)
-    dt_other, _, prof_other = timed(not args.no_kernel_events and two, not two, max(args.steps // 2, 2), 1)
-    dt_other = _max_over_ranks(dt_other, world, cdev or dev)
-    a = seeded_step(True)
-    b = seeded_step(False)
-    _fence(world)
-    same = torch.equal(a, b)
-    if world > 1:
-        import torch.distributed as dist
-        flag = torch.tensor([1 if same else 0], device=cdev or dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        same = bool(flag.item())
+    dt_other, prof_other, same = float("nan"), None, None
+    if not args.no_other_schedule:
+        dt_other, _, prof_other = timed(not args.no_kernel_events and two, not two, max(args.steps // 2, 2), 1)
+        dt_other = _max_over_ranks(dt_other, world, cdev or dev)
+        a = seeded_step(True)
+        b = seeded_step(False)
+        _fence(world)
+        same = torch.equal(a, b)
+        if world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if same else 0], device=cdev or dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item())
     if prof is None or not prof:
         prof = prof_other                                 # dense-launch durations come from the one-stream steps (isolated launches)
         prof_steps = max(args.steps // 2, 2)
@@ -419,8 +424,9 @@ def main():
                           "only at the pixels its own attention masks read (no loss reads them; final prediction bit-identical)",
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()},
                "schedules": {"timed": "two streams (teacher forward + GT criterion on a second HIP stream)" if two else "one stream",
-                             "other_ms_per_step": round(other_ms, 3), "other": "one stream" if two else "two streams",
-                             "losses_bitwise_equal_between_schedules": bool(same)}}
+                             "other_ms_per_step": None if args.no_other_schedule else round(other_ms, 3),
+                             "other": "one stream" if two else "two streams",
+                             "losses_bitwise_equal_between_schedules": None if same is None else bool(same)}}
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)
             fl = sum(f for _, _, f, *_ in prof)

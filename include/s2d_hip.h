@@ -271,6 +271,11 @@ int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm,
                        int ow, const int *query, int K, float *workspace, uint8_t *masks, uint32_t *bits,
                        hipStream_t stream);
 
+/* byte mask planes u8 [K][n] (0 / non-0) -> bit words [K][ceil(n/32)] in the layout above: feeds s2d_mask_pair_counts_u64 for
+ * masks that exist as bytes -- the distillation pseudo targets under MODEL.MASK_FORMER.DISTILLATION_NMS
+ * (kd_video_maskformer_model.py:484-520). */
+int s2d_pack_mask_bits_u8(const uint8_t *masks, int K, long n, uint32_t *bits, hipStream_t stream);
+
 /* inter[i][j] = sum(mask_i & mask_j) for all pairs of K bit-packed masks (diagonal = areas; sum(mask_i | mask_j) =
  * inter[i][i] + inter[j][j] - inter[i][j]): everything the greedy mask-NMS of :552-583 reads, in one launch instead
  * of two full-tensor reductions and a host sync per pair.  inter [K][K] (zeroed here). */

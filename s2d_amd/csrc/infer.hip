@@ -239,6 +239,20 @@ __global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t *__restr
     }
 }
 
+
+// u8 mask planes [K][n] (0 / non-0) -> bit words [K][ceil(n / 32)] (flat index i -> word i / 32, bit i % 32; tail bits zero):
+// the input format of pair_count_kernel, for masks that exist as byte planes (the KD pseudo targets, DISTILLATION_NMS)
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ masks, long n, long words, uint32_t *__restrict__ bits)
+{
+    const int k = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;                  // element index; a wave covers two words
+    const bool v = i < n && masks[(long)k * n + i] != 0;
+    const unsigned long long b = __ballot(v);
+    const int lane = threadIdx.x & 63;
+    const long w = i >> 5;
+    if ((lane & 31) == 0 && w < words) bits[(long)k * words + w] = (uint32_t)(lane ? (b >> 32) : (b & 0xFFFFFFFFull));
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +289,17 @@ int s2d_infer_masks_u8(const float *mask_logits, int ldq, int T, int hm, int wm,
     const long nthreads = (p.words * 32 + 3) / 4;       // whole words: the tail lanes write the zero padding bits
     if (p.same) hipLaunchKernelGGL(infer_resize_kernel<true>, dim3(cdiv(nthreads, 256), K), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(infer_resize_kernel<false>, dim3(cdiv(nthreads, 256), K), dim3(256), 0, stream, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_pack_mask_bits_u8(const uint8_t *masks, int K, long n, uint32_t *bits, hipStream_t stream)
+{
+    if (K < 0 || n <= 0) return S2D_ERR_ARG;
+    if (K == 0) return S2D_OK;
+    const long words = (n + 31) / 32;
+    if ((words * 32 + 255) / 256 >= (1L << 31)) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3(cdiv(words * 32, 256), K), dim3(256), 0, stream, masks, n, words, bits);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -152,7 +152,7 @@ class KDVideoMaskFormer(nn.Module):
     def __init__(self, *, student_backbone, student_sem_seg_head, teacher_backbone, teacher_sem_seg_head, criterion,
                  num_queries, num_frames, size_divisibility=32, pixel_mean=ops.PIXEL_MEAN, pixel_std=ops.PIXEL_STD,
                  num_predictions_distillation=100, score_threshold_distillation=0.75, accum_iter=1, eval_student=False,
-                 use_nms=False, nms_threshold=0.75, num_predictions_inference=10):
+                 use_nms=False, nms_threshold=0.75, num_predictions_inference=10, distillation_nms=False):
         super().__init__()
         self.student = _Net(student_backbone, student_sem_seg_head)
         self.teacher = _Net(teacher_backbone, teacher_sem_seg_head)
@@ -166,6 +166,7 @@ class KDVideoMaskFormer(nn.Module):
         self.score_threshold_distillation = score_threshold_distillation
         self.accum_iter, self.eval_student = accum_iter, eval_student
         self.use_nms, self.nms_threshold, self.num_predictions_inference = use_nms, nms_threshold, num_predictions_inference
+        self.distillation_nms = distillation_nms          # MODEL.MASK_FORMER.DISTILLATION_NMS (off in every shipped config)
         # Optional two-stream schedule of forward_losses (teacher forward / GT criterion on a second HIP stream): ~8 % faster
         # and bitwise identical to the one-stream schedule (bench.py re-checks that on every run; DESIGN.md section 5,
         # "Streams", has the history of why the default here stays one stream).
@@ -201,6 +202,7 @@ class KDVideoMaskFormer(nn.Module):
                    size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
                    num_predictions_distillation=mf.NUM_PREDICTIONS_DISTILLATION,
                    score_threshold_distillation=mf.SCORE_THRESHOLD_DISTILLATION, accum_iter=cfg.SOLVER.ACCUM_ITER,
+                   distillation_nms=bool(getattr(mf, "DISTILLATION_NMS", False)),
                    **_test_kwargs(mf, "num_predictions_inference", eval_student=True))
 
     @property
@@ -211,6 +213,30 @@ class KDVideoMaskFormer(nn.Module):
         frames = _frames_to_device(batched_inputs, self.device)
         return ops.normalize_pad(frames, self.size_divisibility, self.pixel_mean.flatten().cpu().numpy(),
                                  self.pixel_std.flatten().cpu().numpy())
+
+    def _kd_nms(self, tgt, cnt, ne, kept=None):
+        """the optional mask-NMS of prepare_distillation_targets (kd_video_maskformer_model.py:484-520): greedy over the
+        pseudo targets of a clip, a later candidate dropped when its IoU with a kept one exceeds nms_threshold (all pseudo
+        labels are the single class).  Pair counts on the device (bit-packed planes, one launch per clip), the greedy walk on
+        the K x K integers on the host -- this branch synchronises, the default path does not.  Candidate order: ascending
+        query index (the reference walks them in torch.topk(sorted=False) order, which is implementation-defined)."""
+        from .postprocess import greedy_mask_nms
+        counts = cnt.cpu().tolist()
+        for b, k in enumerate(counts):
+            if k < 2:
+                continue
+            inter = ops.mask_pair_counts(ops.pack_mask_bits(tgt[b, :k].contiguous())).cpu().numpy()
+            keep = greedy_mask_nms(inter, [0] * k, self.nms_threshold)
+            if len(keep) < k:
+                sel = torch.as_tensor(keep, device=tgt.device, dtype=torch.long)
+                tgt[b, :len(keep)] = tgt[b, sel]
+                ne[b, :len(keep)] = ne[b, sel]
+                if kept is not None:
+                    kept[b, :len(keep)] = kept[b, sel]
+                tgt[b, len(keep):k] = 0
+                ne[b, len(keep):k] = 0
+                cnt[b] = len(keep)
+        return tgt, cnt, ne
 
     @torch.no_grad()
     def forward_losses(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None):
@@ -232,6 +258,8 @@ class KDVideoMaskFormer(nn.Module):
             teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
             tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
                                                 self.score_threshold_distillation, self.num_predictions_distillation)
+            if self.distillation_nms:
+                tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
         student = self.student(images, True)
         if self.overlap_teacher and self.overlap_criteria:
             side.wait_stream(main)        # student outputs ready
@@ -276,6 +304,8 @@ class KDVideoMaskFormer(nn.Module):
             teacher = self.teacher(images, True, aux_masks=self.teacher_aux_masks)
             tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
                                                 self.score_threshold_distillation, self.num_predictions_distillation)
+            if self.distillation_nms:
+                tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
         feats = backbone(images, tb)
         mf, ms = head.pixel_decoder.forward_features(feats, tp)
         student = head.predictor(ms, mf, True, True, td)

@@ -474,6 +474,17 @@ def infer_masks(mask_logits, dims, padded, img_size, out_size, query, want_bits=
     return masks, bits
 
 
+def pack_mask_bits(masks):
+    """u8 masks [K, ...] (0 / non-0) -> int32 bit words [K, ceil(n/32)], the layout mask_pair_counts reads"""
+    _chk(masks, torch.uint8)
+    K = masks.shape[0]
+    n = masks[0].numel() if K else 0
+    bits = torch.empty((K, (n + 31) // 32), device=masks.device, dtype=torch.int32)
+    if K:
+        lib().call("s2d_pack_mask_bits_u8", masks, K, n, bits, _stream())
+    return bits
+
+
 def mask_pair_counts(bits):
     """bit-packed masks [K,words] -> int64 [K,K] intersection counts (diagonal = areas)"""
     _chk(bits, torch.int32)

@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE -o run -- python3 bench.py ... (same)
-    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH gpurun_out/pmc_WRITE profiles/r1_pmc_traffic.json
+    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH gpurun_out/pmc_WRITE profiles/r2_pmc_traffic.json 3.5 <commit>
 
 Counter unit is KB.  FETCH_SIZE is doubled for the "corrected" figures (MI355X_MICROARCH.md: it under-reports wide
 coalesced reads 2x on gfx950); WRITE_SIZE is used as is.  Launch counts include everything bench.py runs: the loss-free
@@ -11,6 +11,7 @@ re-check steps of the bitwise comparison: 5.5 step-equivalents (3.5 with --no-ov
 import collections, csv, glob, json, sys
 
 STEP_EQUIV = float(sys.argv[4]) if len(sys.argv) > 4 else 5.5
+COMMIT = sys.argv[5] if len(sys.argv) > 5 else "unrecorded"
 
 
 def family(name):
@@ -34,7 +35,8 @@ def load(d, counter):
 
 fetch, n = load(sys.argv[1], "FETCH_SIZE")
 write, _ = load(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events (separate passes)",
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --one-stream --no-other-schedule --no-cpu-baseline "
+                  "--no-train-step --no-keymask --no-kernel-events (separate passes)", "commit": COMMIT, "step_equivalents": STEP_EQUIV,
        "note": __doc__.split("\n\n")[-1].replace("\n", " "), "per_kernel_family": {}}
 tot_raw = tot_cor = 0.0
 for fam in sorted(fetch, key=lambda k: -fetch[k]):

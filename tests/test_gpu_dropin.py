@@ -252,3 +252,70 @@ def test_shipped_config_trains_with_the_reference_trainer_statements():
     model.eval()
     out = model(data[:1])
     assert set(out) >= {"image_size", "pred_scores", "pred_labels", "pred_masks"}
+
+
+def test_distillation_nms_branch_vs_oracle(oracle):
+    """MODEL.MASK_FORMER.DISTILLATION_NMS (kd_video_maskformer_model.py:484-520): duplicated / heavily overlapping pseudo
+    targets are dropped greedily at IoU > NMS_THRESH, the survivors compacted in order, counts and DropLoss flags following;
+    the keep set equals the oracle's mask_nms (pinned by the reference's inference goldens)"""
+    from s2d_amd import ops
+    from s2d_amd.modeling import build_kd_model
+    T, H, W = 2, 32, 64
+    yy, xx = np.mgrid[0:H, 0:W]
+    disc = lambda cy, cx, r: ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r)
+    planes = np.stack([np.stack([disc(16, 20, 9)] * T), np.stack([disc(16, 20, 9)] * T), np.stack([disc(16, 44, 8)] * T),
+                       np.stack([disc(16, 21, 9)] * T), np.stack([disc(10, 44, 3)] * T)]).astype(np.uint8)       # 1 duplicates 0, 3 overlaps 0
+    tgt = torch.zeros((2, 6, T, H, W), dtype=torch.uint8, device=DEV)
+    tgt[0, :5] = torch.from_numpy(planes).to(DEV)
+    tgt[1, :2] = torch.from_numpy(planes[[2, 4]]).to(DEV)
+    cnt = torch.tensor([5, 2], dtype=torch.int32, device=DEV)
+    ne = ops.target_nonempty(tgt, cnt)
+    kept = torch.arange(6, dtype=torch.int32, device=DEV).repeat(2, 1).contiguous()
+    model = build_kd_model(num_queries=8, num_frames=T, num_points=64)
+    model.distillation_nms, model.nms_threshold = True, 0.75
+    t2, c2, n2 = model._kd_nms(tgt.clone(), cnt.clone(), ne.clone(), kept)
+    want = oracle.mask_nms(planes.astype(bool), np.zeros(5, np.int64), 0.75)
+    assert list(want) == [0, 2, 4] and c2.cpu().tolist() == [3, 2]
+    np.testing.assert_array_equal(t2[0, :3].cpu().numpy(), planes[[0, 2, 4]])
+    assert int(t2[0, 3:].sum()) == 0 and int(n2[0, 3:].sum()) == 0 and kept[0, :3].cpu().tolist() == [0, 2, 4]
+    np.testing.assert_array_equal(t2[1].cpu().numpy(), tgt[1].cpu().numpy())
+    bits = ops.pack_mask_bits(torch.from_numpy(planes).to(DEV))
+    inter = ops.mask_pair_counts(bits).cpu().numpy()
+    flat = planes.reshape(5, -1).astype(np.int64)
+    np.testing.assert_array_equal(inter, flat @ flat.T)
+
+
+def test_amp_trainer_statements_autocast_and_gradscaler():
+    """SOLVER.AMP.ENABLED True (every shipped config): the reference trainer wraps the forward in autocast and drives a
+    GradScaler (engine/train_loop.py:709-726).  The HIP path computes in fp32 whatever the autocast state (the parity target),
+    the losses come back fp32, and the scaler's loss scale flows through the bridge: unscaled gradients equal the unscaled run's"""
+    from s2d_amd import ops
+    from s2d_amd.modeling import build_kd_model
+    torch.manual_seed(0)
+    model = build_kd_model(num_queries=16, num_frames=2, num_points=256, weights=(2.0, 5.0, 5.0), dropout=0.0).to(DEV)
+    with torch.no_grad():
+        model.teacher[1].predictor.class_embed.bias.copy_(torch.tensor([2.0, -2.0]))
+    model.train()
+    data = _clip_batch(2, 64, 96, 3, seed=9, B=1)
+    params = [p for p in model.student.parameters()]
+
+    def grads(amp):
+        for p in params:
+            p.grad = None
+        model.criterion.seed = 0; model.criterion.matcher.seed = 0
+        scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=2.0 ** 14)
+        opt = torch.optim.SGD(params, lr=0.0)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            loss_dict = model(data)
+            losses = sum(loss_dict.values())
+        assert losses.dtype == torch.float32
+        scaler.scale(losses).backward()
+        scaler.unscale_(opt)                                           # what scaler.step does first; also its inf check
+        scaler.step(opt); scaler.update()
+        return float(losses), [p.grad.clone() for p in params]
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12
