@@ -15,6 +15,7 @@
 #include "gemm_params.h"
 #include "dropout.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -22,6 +23,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((vector_size(16)));
 
 constexpr int BN = 128, BK = 32, ROWW = 36;  // LDS row = 36 words (144 B)
 
@@ -795,6 +797,394 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave-specialised persistent split-fp16 x3 kernel ("ws"): 128 x 128 x 32 tiles, 8 waves per workgroup, one workgroup
+// per CU looping over its tiles.
+//   waves 0-3 (one per SIMD)  consumers: 64 x 64 of the tile each; their instruction stream is ds_read_b128 + MFMA only
+//                             (fragments of half a k-tile are read one half ahead of the MFMAs that use them), so
+//                             the matrix pipe never waits behind a global load or the fp16 split of the same wave
+//   waves 4-7 (one per SIMD)  producers: global loads D k-tiles ahead (D register sets), fp16 split, LDS stores of
+//                             k-tile q+1 while the consumers work on k-tile q, and - spread over the k-loop of the
+//                             NEXT tile - the epilogue of the previous tile (scale / bias / dropout / residual / ReLU,
+//                             16-B row stores) out of an LDS staging area the consumers park their accumulators in
+// The k-tile stream runs across tile boundaries, so prologue, epilogue and the C write-back of a tile overlap the
+// MFMAs of its neighbours.  One s_barrier per k-tile couples the two roles (LDS: 2 operand slots of 36.9 KB + 69.6 KB
+// of C staging = 143.4 KB).
+template <bool CONV, bool BSPLIT, bool DROP, bool RES>
+__global__ __launch_bounds__(512, 1) void gemm_f16x3_ws_kernel(GemmParams p)
+{
+    constexpr int BM = 128, RPT = 32, D = 3, SLOT = (BM + BN) * ROWW;
+    constexpr int EPC = DROP ? 8 : 16;                       // epilogue chunks per tile and producer wave
+    constexpr int CPI = DROP ? 2 : 3;                        // chunks per k-tile: (nk - 1) * CPI >= EPC needs nk >= 7
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *ring = lds;                                             // [2][BM + BN][ROWW]
+    float *cst = reinterpret_cast<float *>(lds + 2 * SLOT);               // [4][64][68]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int nk = (p.K + BK - 1) / BK;
+    const int G = gridDim.x;
+    const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
+    const int Q = my_tiles * nk;                             // k-tiles of this workgroup, all its tiles back to back
+    auto tile_origin = [&](int j, int &m0, int &n0) {
+        int bid = blockIdx.x + j * G;
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * BN;
+    };
+
+    if (wave < 4) {
+        // ---------------------------------------------------------------- consumers
+        const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
+        __builtin_amdgcn_s_setprio(2);
+        f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+        f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];       // [half of the k-tile][row block / column block]
+        const unsigned int *abase = ring + (wm * 64 + l32) * ROWW + 4 * h;
+        const unsigned int *bbase = ring + (BM + wn * 64 + l32) * ROWW + 4 * h;
+        auto rd = [&](int slot, auto S) {
+            constexpr int s = decltype(S)::value;
+            const unsigned int *as = abase + slot * SLOT, *bs = bbase + slot * SLOT;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[s][t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 8 * s);
+                bl[s][t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * ROWW + 16 + 8 * s);
+                ah[s][t] = *reinterpret_cast<const f16x8 *>(as + t * 32 * ROWW + 8 * s);
+                al[s][t] = *reinterpret_cast<const f16x8 *>(as + t * 32 * ROWW + 16 + 8 * s);
+            }
+        };
+        auto mm = [&](auto S) {        // 12 MFMAs; the two updates of one cross accumulator are four MFMAs apart
+            constexpr int s = decltype(S)::value;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], accm[i][j], 0, 0, 0);
+        };
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        float *ep = cst + wave * 64 * 68;
+        int kt = 0;
+        __syncthreads();                                      // barrier 0: k-tile 0 is in slot 0
+        rd(0, H0{});
+        for (int q = 0; q < Q; ++q) {
+            const int slot = q & 1;
+            rd(slot, H1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm(H0{});
+            __builtin_amdgcn_sched_barrier(0);                // the MFMAs cover the latency of the reads before the barrier
+            __syncthreads();                                  // k-tile q+1 stored; every read of slot q has landed
+            if (q + 1 < Q) rd(slot ^ 1, H0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm(H1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (++kt == nk) {
+                kt = 0;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] =
+                                accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+                            accm[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f;
+                        }
+            }
+        }
+        __syncthreads();                                      // the last tile is parked
+        return;
+    }
+
+    // -------------------------------------------------------------------- producers
+    // The loop bodies have no branches around loads, so every s_waitcnt vmcnt(N) the compiler places is the exact count of
+    // younger operations and a k-tile's loads stay in flight for D iterations.  Every load is IN RANGE: an out-of-range
+    // buffer load (the usual way to get zeros for masked rows / taps) returns without a memory access and ahead of older
+    // in-range loads, so a counted vmcnt wait behind one is satisfied before the data it guards has landed (measured:
+    // sporadic stale first rows of a register set whenever a masked load sat behind it; profiles/r2_ws_gemm/README.md).
+    // Masked rows / columns read a clamped address instead (their products are never stored), dead k-tiles past the end of
+    // the stream re-read offset 0, and padding taps / the K tail of a convolution are zeroed by a select after the load.
+    const int pw = wave - 4, pt = tid - 256;
+    const int c4 = pt & 7, g = pt >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = BSPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.B), 0, (int)p.bytesB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long)(p.M - 1) * p.ldc + p.N) * 4L), 0x00020000);
+    const int res_h = p.res_rows ? p.res_rows : p.M;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RES ? p.res : p.A), 0, RES ? (int)(((long)(res_h - 1) * p.ldr + (p.res_cols < p.N ? p.res_cols : p.N)) * 4L) : 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.scale ? p.scale : p.ones), 0, p.N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias ? p.bias : p.zeros), 0, p.N * 4, 0x00020000);
+    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;
+    // load stream: tile lj, k-tile lkt of it.  Past the end of the stream it keeps re-reading the last tile's k-tiles
+    // (in range, never stored to the ring's live slot).
+    int lj = 0, lkt = 0;
+    unsigned int a_off[4], b_off[4];
+    int a_iy0[4], a_ix0[4];
+    auto set_tile = [&](int j) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r0 + RPT * i;
+            const int mc = m < p.M ? m : p.M - 1;              // rows past M: a valid row whose products nobody stores
+            if (CONV) {
+                const int ox = mc % p.Wout, t = mc / p.Wout, oy = t % p.Hout, n = t / p.Hout;
+                a_iy0[i] = oy * p.stride - p.pad;
+                a_ix0[i] = ox * p.stride - p.pad;
+                a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
+            } else {
+                a_off[i] = (unsigned int)((long)mc * p.lda * 4L) + (unsigned int)(c4 * 16);
+                a_iy0[i] = a_ix0[i] = 0;
+            }
+            const int n = n0 + r0 + RPT * i, nc = n < p.N ? n : p.N - 1;
+            b_off[i] = (unsigned int)(BSPLIT ? (long)nc * p.kblocks * 128L + wsel * 4 : (long)nc * p.ldb * 4L + c4 * 16);
+        }
+    };
+    auto load_set = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], unsigned int &zm) {   // next k-tile of the stream -> one register set; zm: rows to zero when the set is stored
+        const int kb = lkt * (BK * 4);                          // uniform byte offset of the k-tile (K % 32 == 0 off the conv path)
+        zm = 0u;
+        int kh = 0, kw = 0, ci = 0;
+        bool kok = true;
+        if (CONV) {
+            const int k = lkt * BK + c4 * 4;
+            kok = k < p.K;                                     // K % 4 == 0 (host-checked): a float4 is inside or outside
+            const int kc = kok ? k : 0;
+            const int tap = kc / p.Cin;
+            ci = kc - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool zero = ((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) < 0) || !kok;           // padding tap or the K tail
+                const int iyc = iy < 0 ? 0 : (iy >= p.Hin ? p.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= p.Win ? p.Win - 1 : ix);
+                off = a_off[i] + (unsigned int)(((iyc * p.Win + ixc) * p.Cin + ci) * 4);
+                if (zero) zm |= 1u << i;
+            } else {
+                off = a_off[i];
+            }
+            // the k-tile's byte offset rides in the instruction's scalar offset: no per-lane address arithmetic
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, CONV ? 0 : kb, 0));
+            // B: pre-split images are zero padded past K; a dynamic B has K % 32 == 0 here
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], kb, 0));
+        }
+        if (++lkt == nk) {
+            lkt = 0;
+            if (++lj < my_tiles) set_tile(lj);
+        }
+    };
+    auto store_set = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4], unsigned int zm, int slot) {
+        unsigned int *As = ring + slot * SLOT, *Bs = As + BM * ROWW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 hi, lo;
+            split4_f16(ra[i], hi, lo);
+            if (CONV && ((zm >> i) & 1u)) { hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u}; }
+            unsigned int *row = &As[(r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+            row = &Bs[(r0 + RPT * i) * ROWW];
+            if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; continue; }
+            split4_f16(rb[i], hi, lo);
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+    };
+    // epilogue stream: producer wave pw writes back the 64 x 64 block consumer wave pw parked, CPI row chunks per k-tile
+    // (a chunk = 4 rows x 256 B, or 8 rows with dropout where a lane owns an 8-column mask block).  The loads a chunk needs
+    // (residual rows, per-column scale / bias) are issued D iterations before the chunk is written, in the same register
+    // set and right behind the operand loads that will be consumed in that iteration, so waiting for them never drains
+    // a younger operand set.  Per tile the stream keeps row / column / byte offsets of this lane's first chunk; a chunk adds
+    // a uniform multiple, so an iteration costs a handful of VALU instructions besides the arithmetic itself.
+    constexpr int EW = DROP ? 8 : 4;                          // columns per lane
+    constexpr int ER = DROP ? 8 : 4;                          // rows per chunk
+    constexpr int EV = EW / 4;
+    const int ewm = pw >> 1, ewn = pw & 1;
+    const int ecl = (DROP ? (lane & 7) : (lane & 15)) * EW, erl = DROP ? (lane >> 3) : (lane >> 4);
+    const float *epb = cst + pw * 64 * 68 + erl * 68 + ecl;  // this lane's float4 of chunk 0
+    struct EpSet {                                            // what one iteration's chunks need, per register set
+        f32x4 sc[EV], bi[EV], rs[CPI][EV];
+        float rmask[EV];                                      // 1: this lane's columns take the residual, 0: they do not
+        int row, col;                                         // this lane's row of chunk 0 / first column, of the tile the chunks belong to
+        unsigned int coff;                                    // byte offset of (row, col) in C
+        int it0;                                              // first chunk (uniform); < 0 or >= EPC: nothing to do
+    };
+    // position of the iteration the loads are issued FOR (x = q + D): x = xtile * nk + xkt
+    int xkt = 0, xtile = 0, x_row = ewm * 64 + erl, x_col = ewn * 64 + ecl, x_rr = 0;
+    unsigned int x_coff = 0u, x_cb = 0u;
+    float x_rmask[EV] = {};
+    const int ldc4 = (int)p.ldc * 4 * ER;
+    auto ep_issue = [&](EpSet &s, bool live) {
+        // the tile that ended at k-tile x - xkt - 1 is parked after barrier x - xkt and visible from xkt = 1 on; it must be
+        // drained before the next one is parked: nk - 1 iterations x CPI chunks >= EPC (host-checked)
+        if (xkt == 1 && xtile > 0) {
+            int m0, n0;
+            tile_origin(xtile - 1, m0, n0);
+            x_row = m0 + ewm * 64 + erl;
+            x_col = n0 + ewn * 64 + ecl;
+            x_coff = (unsigned int)((long)x_row * p.ldc * 4L) + (unsigned int)(x_col * 4);
+            x_cb = x_col < p.N ? (unsigned int)(x_col * 4) : 0u;
+            if (RES) {
+                x_rr = p.res_rows ? x_row % p.res_rows : x_row;
+#pragma unroll
+                for (int w = 0; w < EV; ++w) x_rmask[w] = x_col + 4 * w < p.res_cols ? 1.f : 0.f;
+            }
+        }
+        if (CONV) {
+#pragma unroll
+            for (int w = 0; w < EV; ++w) s.sc[w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, (int)x_cb, 16 * w, 0));
+        }
+#pragma unroll
+        for (int w = 0; w < EV; ++w) s.bi[w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, (int)x_cb, 16 * w, 0));
+        s.row = x_row; s.col = x_col; s.coff = x_coff;
+        s.it0 = (live && xtile > 0) ? (xkt - 1) * CPI : -CPI;
+        if (RES) {
+            const int itb = s.it0 < 0 ? 0 : s.it0;
+#pragma unroll
+            for (int w = 0; w < EV; ++w) s.rmask[w] = x_rmask[w];
+#pragma unroll
+            for (int c = 0; c < CPI; ++c) {
+                const int itc = itb + c < EPC ? itb + c : EPC - 1;      // dead chunks re-read a live row
+                int rr = x_rr + itc * ER;                      // res_rows >= 64 (host-checked): one conditional subtraction
+                if (p.res_rows) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+                else rr = rr < p.M ? rr : p.M - 1;
+                // columns without a residual (rmask 0) read the row's first columns: finite values, multiplied by 0
+                const unsigned int ro = (unsigned int)(rr * (int)p.ldr) * 4u + (x_rmask[EV - 1] != 0.f ? x_cb : 0u);
+#pragma unroll
+                for (int w = 0; w < EV; ++w)
+                    s.rs[c][w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)ro, 16 * w, 0));
+            }
+        }
+        if (++xkt == nk) { xkt = 0; ++xtile; }
+    };
+    // the chunks' LDS reads are issued at the top of the iteration and consumed after the operand split, so their latency
+    // is covered by that arithmetic
+    auto ep_read = [&](const EpSet &s, f32x4 (&v)[CPI][EV]) {
+        if (s.it0 < 0 || s.it0 >= EPC) return;               // uniform
+#pragma unroll
+        for (int c = 0; c < CPI; ++c) {
+            const int it = s.it0 + c < EPC ? s.it0 + c : EPC - 1;
+#pragma unroll
+            for (int w = 0; w < EV; ++w) v[c][w] = *reinterpret_cast<const f32x4 *>(epb + it * (ER * 68) + 4 * w);
+        }
+    };
+    auto ep_write = [&](const EpSet &s, f32x4 (&v)[CPI][EV]) {
+        if (s.it0 < 0 || s.it0 >= EPC) return;               // uniform
+        const bool cok = s.col < p.N;
+#pragma unroll
+        for (int c = 0; c < CPI; ++c) {
+            const int it = s.it0 + c;
+            if (it >= EPC) break;                              // uniform
+            const int row = s.row + it * ER;
+#pragma unroll
+            for (int w = 0; w < EV; ++w) {
+                if (CONV) v[c][w] *= s.sc[w];
+                v[c][w] += s.bi[w];
+            }
+            if constexpr (DROP) {
+                float m[8];
+                s2d_dropout8((uint32_t)row + p.drop_row0, (uint32_t)(s.col >> 3), p.drop_stream, p.drop_k0, p.drop_k1, p.drop_thresh, p.drop_scale, m);
+                v[c][0][0] *= m[0]; v[c][0][1] *= m[1]; v[c][0][2] *= m[2]; v[c][0][3] *= m[3];
+                v[c][EV - 1][0] *= m[4]; v[c][EV - 1][1] *= m[5]; v[c][EV - 1][2] *= m[6]; v[c][EV - 1][3] *= m[7];
+            }
+#pragma unroll
+            for (int w = 0; w < EV; ++w) {
+                if (RES) {                                     // element-wise on purpose: no packed op as the first reader of a loaded register (scripts/isa_lint.py)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[c][w][j] = __builtin_fmaf(s.rs[c][w][j], s.rmask[w], v[c][w][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[c][w][j] = __builtin_amdgcn_fmed3f(v[c][w][j], relu_lo, __builtin_inff());
+            }
+            // the store is predicated, not masked out of range: an out-of-range store retires early just like a load
+            if (cok && row < p.M) {
+#pragma unroll
+                for (int w = 0; w < EV; ++w)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[c][w]), rsC, (int)s.coff, it * ldc4 + 16 * w, 0);
+            }
+        }
+    };
+
+    f32x4 ra[D][4], rb[D][4];
+    unsigned int zm[D];
+    EpSet es[D];
+    set_tile(0);
+    // prologue: the same operation pattern per set as a loop iteration.  Iterations 0 .. D-1 have nothing to write back
+    // (nk > D), so their epilogue sets are dead; the stream position starts at x = D.
+#pragma unroll
+    for (int d = 0; d < D; ++d) {                             // Q >= nk > D
+        load_set(ra[d], rb[d], zm[d]);
+        ep_issue(es[d], false);
+        __builtin_amdgcn_sched_barrier(0);                    // the loop's issue order, so that its waits can be counted from here
+    }
+    store_set(ra[0], rb[0], zm[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(ra[0], rb[0], zm[0]);
+    ep_issue(es[0], false);                                   // rides with k-tile D = iteration D - 1: still the first tile
+    __builtin_amdgcn_sched_barrier(0);
+    xkt = D; xtile = 0;
+    __syncthreads();                                          // barrier 0
+    auto body = [&](int q, auto U) {
+        constexpr int s = (decltype(U)::value + 1) % D;       // q = q0 + u with q0 % D == 0: k-tile q+1 lives in set (u+1) % D
+        // k-tile q+1 -> the slot the consumers left at the last barrier (past the end: a re-read nobody uses), this
+        // iteration's chunks of the parked tile, then the register set takes k-tile q+1+D and the chunk loads of
+        // iteration q+D (where that k-tile is stored).  sched_barrier: issue order = program order, the vmcnt arithmetic
+        // counts on it.
+        f32x4 ev[CPI][EV];
+        ep_read(es[s], ev);
+        __builtin_amdgcn_sched_barrier(0);
+        store_set(ra[s], rb[s], zm[s], (q + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ep_write(es[s], ev);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set(ra[s], rb[s], zm[s]);
+        ep_issue(es[s], q + D < Q);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    static_assert(D == 3, "the unrolled bodies below are written for three register sets");
+    // whole groups of D iterations without a branch between them (a guarded body would make the compiler count only the
+    // loads of the guaranteed bodies as younger and wait for a set one iteration after it was issued), then the remainder
+    int q0 = 0;
+    for (; q0 + D <= Q; q0 += D) { body(q0, U0{}); body(q0 + 1, U1{}); body(q0 + 2, U2{}); }
+    if (q0 < Q) body(q0, U0{});
+    if (q0 + 1 < Q) body(q0 + 1, U1{});
+    __syncthreads();                                          // the last tile is parked
+    xtile = my_tiles;                                         // its chunks, CPI at a time
+    for (int it0 = 0; it0 < EPC; it0 += CPI) {
+        xkt = it0 / CPI + 1;
+        ep_issue(es[0], true);
+        xtile = my_tiles;
+        f32x4 ev[CPI][EV];
+        ep_read(es[0], ev);
+        ep_write(es[0], ev);
+    }
+}
+
 template <bool CONV>
 int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
 {
@@ -821,6 +1211,60 @@ int launch_f16_v(const GemmParams &p, int batch, hipStream_t st)
     hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE, BSPLIT, DROP>), dim3(nwg, batch), dim3(256), lds, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
+}
+
+constexpr int WS_CONST_N = 16384;
+__global__ void ws_constants_kernel(float *z, float *o)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    z[i] = 0.f; o[i] = 1.f;
+}
+
+// per device: WS_CONST_N zeros and ones (an absent bias / scale vector of the wave-specialised kernel)
+int s2d_ws_constants(const float **zeros, const float **ones, hipStream_t st)
+{
+    static float *buf[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return S2D_ERR_LAUNCH;
+    if (!buf[dev]) {
+        float *b = nullptr;
+        if (hipMalloc(&b, sizeof(float) * 2 * WS_CONST_N) != hipSuccess) return S2D_ERR_LAUNCH;
+        hipLaunchKernelGGL(ws_constants_kernel, dim3(WS_CONST_N / 256), dim3(256), 0, st, b, b + WS_CONST_N);
+        if (hipStreamSynchronize(st) != hipSuccess) return S2D_ERR_LAUNCH;   // other streams may launch next
+        buf[dev] = b;
+    }
+    *zeros = buf[dev]; *ones = buf[dev] + WS_CONST_N;
+    return S2D_OK;
+}
+
+template <bool CONV, bool BSPLIT, bool DROP, bool RES>
+int launch_f16_ws_v(const GemmParams &p, hipStream_t st)
+{
+    const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW + sizeof(float) * 4 * 64 * 68;
+    static bool attr_set = false;
+    static int cus = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return S2D_ERR_LAUNCH;
+        cus = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
+    GemmParams q = p;
+    if (s2d_ws_constants(&q.zeros, &q.ones, st) != S2D_OK) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES>), dim3(nwg < cus ? nwg : cus), dim3(512), lds, st, q);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+template <bool CONV, bool BSPLIT, bool DROP>
+int launch_f16_ws(const GemmParams &p, hipStream_t st)
+{
+    return p.res ? launch_f16_ws_v<CONV, BSPLIT, DROP, true>(p, st) : launch_f16_ws_v<CONV, BSPLIT, DROP, false>(p, st);
 }
 
 template <bool CONV, bool PIPE>
@@ -891,6 +1335,23 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (p.Bsplit) {
         if (!f16 || (batch > 1 && p.sB != 0) || (long)p.N * ((p.K + 31) / 32) * 128L > 0xFFFFFF00L) return S2D_ERR_ARG;
         p.kblocks = (p.K + 31) / 32;
+    }
+    static int ws = -1;
+    if (ws < 0) { const char *e = getenv("S2D_GEMM_WS"); ws = e ? atoi(e) : 0; }
+
+    // wave-specialised persistent kernel: one batch slice, >= 7 k-tiles (the previous tile's write-back is spread over the
+    // k-loop), 16-B rows for the row-wise epilogue, 32-bit buffer offsets into C and the residual
+    const long bC = ((long)(p.M - 1) * p.ldc + p.N) * 4L, bR = p.res ? ((long)((p.res_rows ? p.res_rows : p.M) - 1) * p.ldr + p.N) * 4L : 0;
+    const bool ws_ok = ws && f16 && batch == 1 && p.N <= WS_CONST_N && (conv || !p.scale) && p.K >= 7 * BK - (BK - 1) && ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0 &&
+                       (conv ? (p.Cin % 4 == 0 && (p.Bsplit || p.K % BK == 0)) : p.K % BK == 0) &&
+                       bC <= 0xFFFFFF00L && bR <= 0xFFFFFF00L && (!p.res_rows || p.res_rows >= 64) &&
+                       (!p.drop_thresh || (((p.N | p.ldc) & 7) == 0 && (!p.res || ((p.ldr | p.res_cols) & 7) == 0)));
+    if (ws_ok && !conv && (ws == 2 || (p.Bsplit && (long)cdiv(p.M, 128) * cdiv(p.N, BN) >= 512))) {
+        if (p.drop_thresh) return p.Bsplit ? launch_f16_ws<false, true, true>(p, st) : launch_f16_ws<false, false, true>(p, st);
+        return p.Bsplit ? launch_f16_ws<false, true, false>(p, st) : launch_f16_ws<false, false, false>(p, st);
+    }
+    if (ws_ok && conv && !p.drop_thresh && (ws == 2 || (long)cdiv(p.M, 128) * cdiv(p.N, BN) >= 512)) {
+        return p.Bsplit ? launch_f16_ws<true, true, false>(p, st) : launch_f16_ws<true, false, false>(p, st);
     }
     if (p.drop_thresh) {
         // fused dropout lives in the vector epilogue of the pipelined 128x128 split-fp16 kernel (the three encoder-layer

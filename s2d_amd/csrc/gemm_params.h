@@ -26,6 +26,8 @@ struct GemmParams {
     float drop_scale;           // 1 / (1 - p)
     unsigned int drop_k0, drop_k1, drop_stream;   // Philox key (the call's seed) and the stream id of this dropout site
     unsigned int drop_row0;     // mask row of output row 0 (a launch over rows [r0, r1) of a larger activation passes r0)
+    // wave-specialised kernel: 16 K floats of 0 and of 1 that stand in for an absent bias / scale vector (branch-free epilogue)
+    const float *zeros, *ones;
 };
 
 

@@ -97,3 +97,20 @@ def test_presplit_static_weights(oracle, dense_mode):
     y1 = ops.conv2d_nhwc(x, ops.mark_static(w.clone()), 1, 1)
     assert torch.equal(y0, y1)
     ops.clear_weight_cache()
+
+
+def test_wave_specialised_kernel_subprocess():
+    """the opt-in wave-specialised persistent GEMM / conv kernel (S2D_GEMM_WS=2 routes every eligible launch to it) against the
+    same oracle cases as the default dispatch: this file and the fused-dropout cases, in a child process because the switch
+    is read once per process"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("S2D_GEMM_WS"):
+        pytest.skip("already inside the wave-specialised run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2D_GEMM_WS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_dense.py"), os.path.join(root, "tests", "test_gpu_dropin.py"),
+                        "-k", "gemm or conv or dropout"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
