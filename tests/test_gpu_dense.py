@@ -99,15 +99,15 @@ def test_presplit_static_weights(oracle, dense_mode):
     ops.clear_weight_cache()
 
 
-def test_wave_specialised_kernel_subprocess():
+def test_wave_specialised_kernel_subprocess(dense_mode):
     """the opt-in wave-specialised persistent GEMM / conv kernel (S2D_GEMM_WS=2 routes every eligible launch to it) against the
     same oracle cases as the default dispatch: this file and the fused-dropout cases, in a child process because the switch
     is read once per process"""
     import os
     import subprocess
     import sys
-    if os.environ.get("S2D_GEMM_WS"):
-        pytest.skip("already inside the wave-specialised run")
+    if os.environ.get("S2D_GEMM_WS") or dense_mode != "f16x3":
+        pytest.skip("once, from the default mode, outside the wave-specialised run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, S2D_GEMM_WS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
