@@ -71,6 +71,11 @@ int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsig
  * them: out = s2d_split_weights_words(N,K) 32-bit words, laid out [N][ceil(K/32)][16 words hi | 16 words lo] (the LDS
  * row image of the kernels, zero padded past K).  Pass it as B_split / w_split together with the fp32 weights (the
  * other dense modes read those); NULL = split on the fly.  Results are bit-identical either way.  Unbatched B only. */
+/* The GEMM with A pre-split as well: A_split is the s2d_split_weights_f16 image of A's M rows (an activation whose producer wrote it
+ * in that layout, or a one-off conversion); B_split is required.  Same result bits as s2d_gemm_nt_f32 on the fp32 A.  Shapes the
+ * wave-specialised kernel does not take (K < 224, K % 32, N % 4) return S2D_ERR_ARG. */
+int s2d_gemm_nt_presplit_f32(const void *A_split, const float *B, float *C, int M, int N, int K, long ldb, long ldc, const float *bias,
+                             const float *res, long ldr, int res_rows, int res_cols, int relu, const void *B_split, hipStream_t stream);
 long s2d_split_weights_words(int N, int K);
 int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hipStream_t stream);
 

@@ -52,15 +52,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     }
 }
 
-// out[i] = beta * out[i] + sum_s part[s][i], s ascending (fixed order)
+// out[i] = beta * out[i] + sum_s part[s][i] in a fixed order: eight interleaved chains (slice s goes to chain s % 8, ascending
+// within a chain), combined pairwise at the end.  One chain made every thread wait out S dependent HBM round trips (36 us for
+// the 16.8 MB of a 256 x 256 weight gradient); eight loads in flight per thread bring the launch to its bandwidth.
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restrict__ part, int S, long n, long stride, float beta,
                                                             float *__restrict__ out)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float acc = beta != 0.f ? beta * out[i] : 0.f;
-    for (int s = 0; s < S; ++s) acc += part[(long)s * stride + i];
-    out[i] = acc;
+    const float *p = part + i;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    for (int j = 0; s < S; ++s, ++j) a[j] += p[(long)s * stride];
+    const float sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    out[i] = beta != 0.f ? beta * out[i] + sum : sum;
 }
 
 // part[s][c] = sum over the rows of slice s of in[r][c]  (rows_per_slice rows each; sequential in r: fixed order)

@@ -207,6 +207,21 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
     return launch(p, false, batch, stream);
 }
 
+// the same contraction with A handed over pre-split (s2d_split_weights_f16 layout over A's rows) next to static pre-split weights
+int s2d_gemm_nt_presplit_f32(const void *A_split, const float *B, float *C, int M, int N, int K, long ldb, long ldc, const float *bias,
+                             const float *res, long ldr, int res_rows, int res_cols, int relu, const void *B_split, hipStream_t stream)
+{
+    if (!A_split || !B_split || res_rows < 0 || res_cols < 0 || res_cols > N || g_dense_mode != 2) return S2D_ERR_ARG;
+    GemmParams p{};
+    p.Asplit = reinterpret_cast<const unsigned int *>(A_split);
+    p.Bsplit = reinterpret_cast<const unsigned int *>(B_split);
+    p.A = reinterpret_cast<const float *>(A_split); p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = K; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.res = res; p.ldr = res ? ldr : N; p.relu = relu;
+    p.res_rows = res_rows; p.res_cols = res_cols > 0 ? res_cols : N;
+    return launch(p, false, 1, stream);
+}
+
 // the same contraction with dropout fused into the epilogue (see include/s2d_hip.h; dropout.h for the mask definition)
 int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                             const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
 // The k-tile stream runs across tile boundaries, so prologue, epilogue and the C write-back of a tile overlap the
 // MFMAs of its neighbours.  One s_barrier per k-tile couples the two roles (LDS: 2 operand slots of 36.9 KB + 69.6 KB
 // of C staging = 143.4 KB).
-template <bool CONV, bool BSPLIT, bool DROP, bool RES>
+template <bool CONV, bool BSPLIT, bool DROP, bool RES, bool ASPLIT = false>
 __global__ __launch_bounds__(512, 1) void gemm_f16x3_ws_kernel(GemmParams p)
 {
     constexpr int BM = 128, RPT = 32, D = 3, SLOT = (BM + BN) * ROWW;
@@ -921,7 +921,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_ws_kernel(GemmParams p)
     const int pw = wave - 4, pt = tid - 256;
     const int c4 = pt & 7, g = pt >> 3;
     const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = ASPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Asplit), 0, (int)((long)p.M * p.kblocks * 128L), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = BSPLIT
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.B), 0, (int)p.bytesB, 0x00020000);
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_ws_kernel(GemmParams p)
                 a_ix0[i] = ox * p.stride - p.pad;
                 a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
             } else {
-                a_off[i] = (unsigned int)((long)mc * p.lda * 4L) + (unsigned int)(c4 * 16);
+                a_off[i] = ASPLIT ? (unsigned int)((long)mc * p.kblocks * 128L + wsel * 4) : (unsigned int)((long)mc * p.lda * 4L) + (unsigned int)(c4 * 16);
                 a_iy0[i] = a_ix0[i] = 0;
             }
             const int n = n0 + r0 + RPT * i, nc = n < p.N ? n : p.N - 1;
@@ -999,11 +1001,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_ws_kernel(GemmParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 hi, lo;
-            split4_f16(ra[i], hi, lo);
-            if (CONV && ((zm >> i) & 1u)) { hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u}; }
             unsigned int *row = &As[(r0 + RPT * i) * ROWW];
-            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
-            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+            if (ASPLIT) *reinterpret_cast<f32x4 *>(row + wsel) = ra[i];
+            else {
+                split4_f16(ra[i], hi, lo);
+                if (CONV && ((zm >> i) & 1u)) { hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u}; }
+                *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+                *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+            }
             row = &Bs[(r0 + RPT * i) * ROWW];
             if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; continue; }
             split4_f16(rb[i], hi, lo);
@@ -1237,14 +1242,14 @@ int s2d_ws_constants(const float **zeros, const float **ones, hipStream_t st)
     return S2D_OK;
 }
 
-template <bool CONV, bool BSPLIT, bool DROP, bool RES>
+template <bool CONV, bool BSPLIT, bool DROP, bool RES, bool ASPLIT = false>
 int launch_f16_ws_v(const GemmParams &p, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW + sizeof(float) * 4 * 64 * 68;
     static bool attr_set = false;
     static int cus = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES, ASPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
         int dev = 0;
@@ -1256,7 +1261,7 @@ int launch_f16_ws_v(const GemmParams &p, hipStream_t st)
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
     GemmParams q = p;
     if (s2d_ws_constants(&q.zeros, &q.ones, st) != S2D_OK) return S2D_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES>), dim3(nwg < cus ? nwg : cus), dim3(512), lds, st, q);
+    hipLaunchKernelGGL((gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES, ASPLIT>), dim3(nwg < cus ? nwg : cus), dim3(512), lds, st, q);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1346,6 +1351,16 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
                        (conv ? (p.Cin % 4 == 0 && (p.Bsplit || p.K % BK == 0)) : p.K % BK == 0) &&
                        bC <= 0xFFFFFF00L && bR <= 0xFFFFFF00L && (!p.res_rows || p.res_rows >= 64) &&
                        (!p.drop_thresh || (((p.N | p.ldc) & 7) == 0 && (!p.res || ((p.ldr | p.res_cols) & 7) == 0)));
+    if (p.Asplit) {
+        // pre-split A: only the wave-specialised kernel reads it (its producers copy); the caller guarantees a static B image
+        const bool ok = f16 && !conv && batch == 1 && p.Bsplit && !p.scale && p.N <= WS_CONST_N && p.K >= 7 * BK - (BK - 1) && p.K % BK == 0 &&
+                        ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0 && bC <= 0xFFFFFF00L && bR <= 0xFFFFFF00L &&
+                        (long)p.M * p.kblocks * 128L <= 0xFFFFFF00L && (!p.res_rows || p.res_rows >= 64) &&
+                        (!p.drop_thresh || (((p.N | p.ldc) & 7) == 0 && (!p.res || ((p.ldr | p.res_cols) & 7) == 0)));
+        if (!ok) return S2D_ERR_ARG;
+        if (p.drop_thresh) return p.res ? launch_f16_ws_v<false, true, true, true, true>(p, st) : launch_f16_ws_v<false, true, true, false, true>(p, st);
+        return p.res ? launch_f16_ws_v<false, true, false, true, true>(p, st) : launch_f16_ws_v<false, true, false, false, true>(p, st);
+    }
     if (ws_ok && !conv && (ws == 2 || (p.Bsplit && (long)cdiv(p.M, 128) * cdiv(p.N, BN) >= 512))) {
         if (p.drop_thresh) return p.Bsplit ? launch_f16_ws<false, true, true>(p, st) : launch_f16_ws<false, false, true>(p, st);
         return p.Bsplit ? launch_f16_ws<false, true, false>(p, st) : launch_f16_ws<false, false, false>(p, st);

@@ -20,6 +20,9 @@ struct GemmParams {
     // padded past K; NULL = split on the fly
     const unsigned int *Bsplit;
     int kblocks;
+    // optional pre-split A (an activation an upstream kernel already wrote in the same row-image layout, [M][kblocks][32 words]):
+    // wave-specialised kernel only; its producers then copy instead of converting
+    const unsigned int *Asplit;
     // fused dropout of the epilogue value (after scale / bias, before the residual; commutes with the ReLU): the three
     // nn.Dropout sites of the pixel decoder's encoder layers (msdeformattn.py:101-125).  drop_thresh 0 = off.
     unsigned int drop_thresh;   // element kept iff its 16 random bits >= drop_thresh (= round(p * 65536))

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // normalised pixel centre is its reference point on every level, msdeformattn.py:141-153 with valid
 // ratios == 1).  `oa` [N,S,ldoa] holds, per query, the raw sampling offsets [M][L][P][2] followed by the raw
 // attention logits [M][L*P] (one GEMM output).  Softmax over L*P and loc = ref + off/(W_l,H_l) happen here.
-template <int LP_>
+template <int LP_, bool HM = false>
 __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
                                                          int P, int blk_per_n, float *__restrict__ out)
@@ -145,13 +145,15 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
     const float inv = 1.f / den;
-    const long rowstride = ldv;
+    // HM (experiment): value stored head-major, [N][M][S][32], a pixel's 128 B of one head next to its neighbours'
+    const long rowstride = HM ? D : ldv;
     f32x4 acc = f32x4(0.f);
 #pragma unroll
     for (int i = 0; i < LP_; ++i) {
         const int l = i / P;
         const int H = lv.H[l], W = lv.W[l];
-        const float *vbase = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
+        const float *vbase = HM ? value + (((long)n * M + m) * S + lv.start[l]) * D + c * V
+                                : value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
         const float lx = ref_x + offp[2 * i] / (float)W;       // ms_deform_attn.py:106-109
         const float ly = ref_y + offp[2 * i + 1] / (float)H;
         sample_accum<4>(acc, vbase, rowstride, H, W, ly * H - 0.5f, lx * W - 0.5f, lg[i] * inv);
@@ -532,10 +534,13 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
 {
     Levels lv;
     if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
-    if (D != 32 || L * P != 12 || ldoa < M * L * P * 3 || (ldoa & 3) || ldv < M * D || (ldv & 3)) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
+    if (D != 32 || L * P != 12 || ldoa < M * L * P * 3 || (ldoa & 3) || (ldv != -1 && (ldv < M * D || (ldv & 3)))) return S2D_ERR_ARG;  // the S2D geometry (msdeformattn.py:232-239)
     if (N <= 0) return S2D_OK;
     const long items = (long)S * M * 8;
     const int nb = cdiv(items, 256);
+    if (ldv < 0)      // experiment switch of scripts/mb_msda.py: ldv = -1 reads a head-major value tensor [N][M][S][32]
+        hipLaunchKernelGGL((msda_fused_kernel<12, true>), dim3(nb, N), dim3(256), 0, stream, value, 32, lv, offs_logits, ldoa, S, M, L, P, nb, out);
+    else
     hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L,
                        P, nb, out);
     S2D_CHECK_LAUNCH();

@@ -143,6 +143,30 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     return out
 
 
+def split_rows(A):
+    """fp16 hi/lo row image of a [M, K] fp32 matrix (the layout gemm_nt_presplit reads; one HBM pass)"""
+    _chk(A)
+    M, K = A.shape
+    img = torch.empty((lib().call("s2d_split_weights_words", M, K),), device=A.device, dtype=torch.int32)
+    lib().call("s2d_split_weights_f16", A, M, K, K, img, _stream())
+    return img
+
+
+def gemm_nt_presplit(A_split, M, K, B, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0):
+    """gemm_nt with A handed over as split_rows(A) (or written in that layout by its producer); B must be a static weight"""
+    for t in (B, bias, res, out):
+        _chk(t)
+    N = B.shape[0]
+    Bs = _static_split(B, N, K, K)
+    assert Bs is not None and B.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=B.device, dtype=torch.float32)
+    with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (2 if res is not None else 1)))):
+        lib().call("s2d_gemm_nt_presplit_f32", A_split, B, out, M, N, K, K, out.shape[-1], bias, res, res.shape[-1] if res is not None else N,
+                   res_rows, res_cols, int(relu), Bs, _stream())
+    return out
+
+
 def dropout(x, p, seed, site, row0=0, out=None):
     """x [M, N] * mask / (1 - p): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
     _chk(x)

@@ -20,6 +20,18 @@ for (M, N, K, r) in shapes:
     dt = t(lambda: ops.gemm_nt(A, W, bias=b, res=R, relu=not r))
     gb = 4.0 * (M * K + M * N * (2 if r else 1)) / 1e9
     print(f"{tag} gemm {M}x{N}x{K} res={r}: {dt*1e3:7.3f} ms {2*M*N*K/dt/1e12:6.1f} TF  {gb/dt/1e3:5.2f} TB/s", flush=True)
+if os.environ.get("MB_PRESPLIT", "1") == "1":
+    for (M, N, K, r) in shapes:
+        A = torch.randn((M, K), device=dev); W = torch.nn.Parameter(torch.randn((N, K), device=dev) / K ** 0.5, requires_grad=False)
+        b = torch.randn((N,), device=dev)
+        R = torch.randn((M, N), device=dev) if r else None
+        As = ops.split_rows(A)
+        ref = ops.gemm_nt(A, W, bias=b, res=R, relu=not r)
+        out = ops.gemm_nt_presplit(As, M, K, W, bias=b, res=R, relu=not r)
+        same = bool(torch.equal(ref, out))
+        dt = t(lambda: ops.gemm_nt_presplit(As, M, K, W, bias=b, res=R, relu=not r))
+        dts = t(lambda: ops.split_rows(A))
+        print(f"{tag} presplit-A gemm {M}x{N}x{K} res={r}: {dt*1e3:7.3f} ms {2*M*N*K/dt/1e12:6.1f} TF  (split pass {dts*1e3:6.3f} ms, bits equal to gemm_nt: {same})", flush=True)
 for (M, N, K, r, relu) in [(309120, 256, 1024, 1, 0), (309120, 256, 256, 1, 0), (309120, 1024, 256, 0, 1)]:
     A = torch.randn((M, K), device=dev); W = torch.nn.Parameter(torch.randn((N, K), device=dev) / K ** 0.5, requires_grad=False)
     b = torch.randn((N,), device=dev)
