@@ -71,6 +71,13 @@ int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsig
  * them: out = s2d_split_weights_words(N,K) 32-bit words, laid out [N][ceil(K/32)][16 words hi | 16 words lo] (the LDS
  * row image of the kernels, zero padded past K).  Pass it as B_split / w_split together with the fp32 weights (the
  * other dense modes read those); NULL = split on the fly.  Results are bit-identical either way.  Unbatched B only. */
+/* dgrad GEMM with the gate of the differentiated layer in its epilogue: C = gate[row][col] > 0 ? (A.B^T + res) * gate_scale : 0.
+ * Replaces `grad_input = grad_output @ W` followed by the threshold_backward / dropout-scale pass autograd runs for
+ * F.relu / nn.Dropout in the reference's FFNs (mask2former/modeling/pixel_decoder/msdeformattn.py:121-125,
+ * mask2former_video/modeling/transformer_decoder/video_mask2former_transformer_decoder.py FFNLayer).  split-fp16 mode, N, ldc, ldr,
+ * ldg multiples of 4; otherwise S2D_ERR_ARG. */
+int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *res,
+                         long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream);
 /* The GEMM with A pre-split as well: A_split is the s2d_split_weights_f16 image of A's M rows (an activation whose producer wrote it
  * in that layout, or a one-off conversion); B_split is required.  Same result bits as s2d_gemm_nt_f32 on the fp32 A.  Shapes the
  * wave-specialised kernel does not take (K < 224, K % 32, N % 4) return S2D_ERR_ARG. */

@@ -142,14 +142,24 @@ def _transposed_weight(w, Np):
     return ent[0]
 
 
-def input_grad(dy, w, res=None):
-    """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection)"""
+def input_grad(dy, w, res=None, gate=None, gate_scale=1.0):
+    """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection).  gate [M,K]: the output of the
+    ReLU (and dropout) that produced this layer's input -- dx is zeroed where gate <= 0 and multiplied by gate_scale
+    elsewhere, in the GEMM's epilogue when the kernels can (one pass over dx less than relu_scale_backward afterwards)"""
     N = dy.shape[1]
     Np = (N + 3) // 4 * 4                                             # the GEMM wants a contraction length % 4 == 0
     wt = _transposed_weight(w, Np)                                    # [K,Np]: once per weight version
     if Np != N:                                                       # e.g. the 2-way class head: zero-pad the contraction
         dy = torch.nn.functional.pad(dy, (0, Np - N))
-    return ops.gemm_nt(dy, wt, res=res)
+    if gate is None:
+        return ops.gemm_nt(dy, wt, res=res)
+    K = wt.shape[0]
+    gate2 = gate.reshape(-1, K)
+    if ops.gate_fusable(K) and gate2.stride(-1) == 1 and gate2.stride(0) % 4 == 0:
+        return ops.gemm_nt_gate(dy, wt, gate2, gate_scale, res=res)
+    dx = ops.gemm_nt(dy, wt, res=res)
+    scale = None if gate_scale == 1.0 else torch.full((K,), float(gate_scale), device=dx.device, dtype=torch.float32)
+    return relu_scale_backward(dx, gate2, scale)
 
 
 def linear_backward(x, w, dy, need_dx=True, has_bias=True):

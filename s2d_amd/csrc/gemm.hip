@@ -172,6 +172,7 @@ int launch(const GemmParams &p, bool conv, int batch, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0 || batch <= 0) return S2D_OK;
     if (p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return S2D_ERR_ARG;
+    if (p.gate && g_dense_mode != 2) return S2D_ERR_ARG;    // the gate lives in the split-fp16 kernels' vector epilogues
     if (g_dense_mode >= 1) {
         GemmParams q = p;
         if (g_dense_mode != 2) q.Bsplit = nullptr;      // the pre-split image is fp16 hi/lo: only mode 2 reads it
@@ -205,6 +206,21 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
     p.scale = scale; p.bias = bias; p.res = res; p.ldr = ldr; p.sR = strideR; p.relu = relu;
     p.res_rows = res_rows; p.res_cols = res_cols > 0 ? res_cols : N;
     return launch(p, false, batch, stream);
+}
+
+// C[M,N] = gate > 0 ? (A . B^T + res) * gate_scale : 0: a dgrad GEMM with the ReLU (and dropout) gate of the layer it
+// differentiates folded into its epilogue (backward.py input_grad)
+int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *res,
+                         long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream)
+{
+    if (!gate) return S2D_ERR_ARG;
+    GemmParams p{};
+    p.Bsplit = reinterpret_cast<const unsigned int *>(B_split);
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.res = res; p.ldr = res ? ldr : N; p.res_cols = N;
+    p.gate = gate; p.ldg = ldg; p.gate_scale = gate_scale;
+    return launch(p, false, 1, stream);
 }
 
 // the same contraction with A handed over pre-split (s2d_split_weights_f16 layout over A's rows) next to static pre-split weights

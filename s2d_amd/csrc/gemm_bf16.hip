@@ -589,6 +589,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
                 v = v * sc + bi;
                 if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.gate) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(p.gate + (long)row * p.ldg + col);
+                    v[0] = g[0] > 0.f ? v[0] * p.gate_scale : 0.f; v[1] = g[1] > 0.f ? v[1] * p.gate_scale : 0.f;
+                    v[2] = g[2] > 0.f ? v[2] * p.gate_scale : 0.f; v[3] = g[3] > 0.f ? v[3] * p.gate_scale : 0.f;
+                }
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
         }
@@ -775,6 +780,11 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
                 v = v * sc + bi;
                 if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (p.gate) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(p.gate + (long)row * p.ldg + col);
+                    v[0] = g[0] > 0.f ? v[0] * p.gate_scale : 0.f; v[1] = g[1] > 0.f ? v[1] * p.gate_scale : 0.f;
+                    v[2] = g[2] > 0.f ? v[2] * p.gate_scale : 0.f; v[3] = g[3] > 0.f ? v[3] * p.gate_scale : 0.f;
+                }
                 *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
             }
         }
@@ -1347,7 +1357,7 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     // wave-specialised persistent kernel: one batch slice, >= 7 k-tiles (the previous tile's write-back is spread over the
     // k-loop), 16-B rows for the row-wise epilogue, 32-bit buffer offsets into C and the residual
     const long bC = ((long)(p.M - 1) * p.ldc + p.N) * 4L, bR = p.res ? ((long)((p.res_rows ? p.res_rows : p.M) - 1) * p.ldr + p.N) * 4L : 0;
-    const bool ws_ok = ws && f16 && batch == 1 && p.N <= WS_CONST_N && (conv || !p.scale) && p.K >= 7 * BK - (BK - 1) && ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0 &&
+    const bool ws_ok = ws && f16 && batch == 1 && !p.gate && p.N <= WS_CONST_N && (conv || !p.scale) && p.K >= 7 * BK - (BK - 1) && ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0 &&
                        (conv ? (p.Cin % 4 == 0 && (p.Bsplit || p.K % BK == 0)) : p.K % BK == 0) &&
                        bC <= 0xFFFFFF00L && bR <= 0xFFFFFF00L && (!p.res_rows || p.res_rows >= 64) &&
                        (!p.drop_thresh || (((p.N | p.ldc) & 7) == 0 && (!p.res || ((p.ldr | p.res_cols) & 7) == 0)));
@@ -1368,6 +1378,7 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (ws_ok && conv && !p.drop_thresh && (ws == 2 || (long)cdiv(p.M, 128) * cdiv(p.N, BN) >= 512)) {
         return p.Bsplit ? launch_f16_ws<true, true, false>(p, st) : launch_f16_ws<true, false, false>(p, st);
     }
+    if (p.gate && (!f16 || conv || batch != 1 || p.drop_thresh || ((p.N | p.ldc | p.ldr | p.res_cols | p.ldg) & 3))) return S2D_ERR_ARG;
     if (p.drop_thresh) {
         // fused dropout lives in the vector epilogue of the pipelined 128x128 split-fp16 kernel (the three encoder-layer
         // GEMMs that carry it all dispatch there): 8-column mask blocks, 16-B aligned rows

@@ -12,6 +12,11 @@ struct GemmParams {
     long ldr, sR;
     int res_rows, res_cols;   // residual row = row % res_rows (0: row); columns >= res_cols get no residual
     int relu;
+    // optional gate of the epilogue value (the ReLU / dropout gate of a backward pass folded into the dgrad GEMM):
+    // C = gate[row][col] > 0 ? value * gate_scale : 0, applied last; 16-B rows (vector epilogues of the split-fp16 kernels only)
+    const float *gate;
+    long ldg;
+    float gate_scale;
     // implicit-GEMM convolution (A = NHWC input)
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     // byte extents of one batch slice of A and B (buffer-descriptor bounds of the split-bf16 kernel)

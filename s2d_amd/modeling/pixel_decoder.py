@@ -156,12 +156,6 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             tape.append((self, sub[0], x1, s1, h, x2, (p, seed)))
         return ops.layernorm(x2, self.norm2.weight, self.norm2.bias)
 
-    def _drop_scale(self, p, like):
-        key = (p, like.shape[-1], like.device)
-        if getattr(self, "_ds", (None,))[0] != key:
-            self._ds = (key, torch.full((like.shape[-1],), 1.0 / (1.0 - p), device=like.device, dtype=torch.float32))
-        return self._ds[1]
-
     def backward(self, saved, d_out):
         """-> (d_src, d_pos)"""
         from .. import backward as B
@@ -174,7 +168,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         B.acc(self.linear2.weight, B.weight_grad(dm, h)); B.acc(self.linear2.bias, B.bias_grad(dm))
         # h = dropout2(relu(z)) = relu(z) * m / (1 - p): positive exactly where the unit is active AND kept, so the ReLU
         # gate on h is the combined gate and the dropout factor is a constant per-channel scale
-        d_h = B.relu_scale_backward(B.input_grad(dm, self.linear2.weight), h, scale=self._drop_scale(p, h) if p > 0.0 else None)
+        d_h = B.input_grad(dm, self.linear2.weight, gate=h, gate_scale=1.0 / (1.0 - p) if p > 0.0 else 1.0)
         B.acc(self.linear1.weight, B.weight_grad(d_h, s1.view(-1, C))); B.acc(self.linear1.bias, B.bias_grad(d_h))
         d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
         d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)

@@ -167,7 +167,7 @@ class FFNLayer(nn.Module):
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
         Bk.acc(self.linear2.weight, Bk.weight_grad(d2, h)); Bk.acc(self.linear2.bias, Bk.bias_grad(d2))
-        d_h = Bk.relu_scale_backward(Bk.input_grad(d2, self.linear2.weight), h)
+        d_h = Bk.input_grad(d2, self.linear2.weight, gate=h)
         Bk.acc(self.linear1.weight, Bk.weight_grad(d_h, tgt.view(-1, C))); Bk.acc(self.linear1.bias, Bk.bias_grad(d_h))
         return Bk.input_grad(d_h, self.linear1.weight, res=d2).view(B, Q, C)
 
@@ -191,10 +191,8 @@ class MLP(nn.Module):
         from .. import backward as Bk
         for i in reversed(range(len(self.layers))):
             l = self.layers[i]
-            if i < len(self.layers) - 1:
-                d = Bk.relu_scale_backward(d, acts[i + 1])
             Bk.acc(l.weight, Bk.weight_grad(d, acts[i])); Bk.acc(l.bias, Bk.bias_grad(d))
-            d = Bk.input_grad(d, l.weight)
+            d = Bk.input_grad(d, l.weight, gate=acts[i] if i > 0 else None)      # acts[i] (i > 0) is the ReLU output feeding layer i
         return d
 
 

@@ -143,6 +143,25 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     return out
 
 
+def gemm_nt_gate(A, B, gate, gate_scale=1.0, res=None):
+    """(A @ B^T + res) * gate_scale where gate > 0, else 0 (gate [M, N]): a dgrad GEMM with the ReLU / dropout gate folded in"""
+    for t in (A, B, gate, res):
+        _chk(t)
+    M, K = A.shape
+    N = B.shape[0]
+    assert gate.shape == (M, N) and gate.stride(-1) == 1 and (res is None or res.shape == (M, N))
+    out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (3 if res is not None else 2)))):
+        lib().call("s2d_gemm_nt_gate_f32", A, B, out, M, N, K, K, K, N, res, N, gate, gate.stride(0), float(gate_scale),
+                   _static_split(B, N, K, K), _stream())
+    return out
+
+
+def gate_fusable(N):
+    """the gate epilogue exists in the split-fp16 kernels' 16-B row epilogues"""
+    return _MODE == "f16x3" and N % 4 == 0
+
+
 def split_rows(A):
     """fp16 hi/lo row image of a [M, K] fp32 matrix (the layout gemm_nt_presplit reads; one HBM pass)"""
     _chk(A)

@@ -99,6 +99,28 @@ def test_presplit_static_weights(oracle, dense_mode):
     ops.clear_weight_cache()
 
 
+@pytest.mark.parametrize("M,N,K,with_res", [(300, 256, 1024, False), (5000, 1024, 256, True), (77, 64, 128, True)])
+def test_gemm_gate_epilogue(oracle, dense_mode, M, N, K, with_res):
+    """dgrad GEMM with the ReLU / dropout gate in its epilogue == GEMM followed by the separate gate pass"""
+    from s2d_amd import ops, backward as Bk
+    if dense_mode != "f16x3":
+        pytest.skip("the gate epilogue exists in the split-fp16 kernels")
+    A = synth.randn(5, 1, (M, K))
+    B = synth.randn(5, 2, (N, K))
+    g = synth.randn(5, 3, (M, N))
+    g[g < 0.3] = 0.0                                                  # a ReLU output: exact zeros where the unit was off
+    res = synth.randn(5, 4, (M, N)) if with_res else None
+    ref = A.astype(np.float64) @ B.astype(np.float64).T + (res if with_res else 0.0)
+    ref = np.where(g > 0, ref * 1.25, 0.0)
+    out = ops.gemm_nt_gate(_dev(A), _dev(B), _dev(g), 1.25, res=_dev(res) if with_res else None)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # the path the models use: input_grad(dy, w, gate) with w [N_out, K_in] -> dx gated by the layer input's ReLU output
+    dy, w = _dev(synth.randn(5, 5, (M, 96))), torch.nn.Parameter(_dev(synth.randn(5, 6, (96, N))))
+    want = Bk.relu_scale_backward(Bk.input_grad(dy, w), _dev(g))
+    got = Bk.input_grad(dy, w, gate=_dev(g))
+    assert torch.equal(want, got)
+
+
 def test_wave_specialised_kernel_subprocess(dense_mode):
     """the opt-in wave-specialised persistent GEMM / conv kernel (S2D_GEMM_WS=2 routes every eligible launch to it) against the
     same oracle cases as the default dispatch: this file and the fused-dropout cases, in a child process because the switch
