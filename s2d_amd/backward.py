@@ -27,6 +27,26 @@ def acc(param, g):
         param.grad += g
 
 
+def acc_wgrad(param, dy, x):
+    """param.grad += dy^T @ x, written by the slice reduction itself when the gradient buffer already exists (one launch and one
+    pass over the gradient less than weight_grad + acc); param may be any view-compatible shape of [N, K] (1x1 convolutions)"""
+    g = param.grad
+    N, K = dy.shape[1], x.shape[1]
+    if g is not None and g.is_contiguous() and g.numel() == N * K and g.dtype == torch.float32:
+        weight_grad(dy, x, out=g.view(N, K), beta=1.0)
+    else:
+        acc(param, weight_grad(dy, x))
+
+
+def acc_bgrad(param, dy):
+    """param.grad += column sums of dy (see acc_wgrad)"""
+    g = param.grad
+    if g is not None and g.is_contiguous() and g.numel() == dy.shape[1] and g.dtype == torch.float32:
+        bias_grad(dy, out=g.view(-1), beta=1.0)
+    else:
+        acc(param, bias_grad(dy))
+
+
 def sum_slices(x):
     """x [S, ...] -> sum over the leading dim in a fixed order"""
     ops._chk(x)
@@ -112,7 +132,7 @@ def bias_grad(dy, out=None, beta=0.0):
     """db [N] = column sums of dy [M,N]"""
     ops._chk(dy)
     M, N = dy.shape
-    rows = max(256, (M + 255) // 256)
+    rows = max(64, (M + 1023) // 1024)             # up to 1024 slices: four workgroups per CU keep enough rows in flight
     S = (M + rows - 1) // rows
     part = torch.empty((S, N), device=dy.device, dtype=torch.float32)
     lib().call("s2d_colsum_slices_f32", dy, M, N, N, rows, part, _st())

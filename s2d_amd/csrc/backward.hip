@@ -83,13 +83,17 @@ __global__ __launch_bounds__(256) void colsum_slices_kernel(const float *__restr
     const int s = blockIdx.y;
     if (c >= C) return;
     const long r0 = (long)s * rows_per_slice, r1 = r0 + rows_per_slice < R ? r0 + rows_per_slice : R;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                   // four interleaved chains, combined in a fixed order
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // eight interleaved chains (row r goes to chain (r - r0) % 8), combined in a fixed order
     long r = r0;
-    for (; r + 3 < r1; r += 4) {
-        a0 += in[r * ldi + c]; a1 += in[(r + 1) * ldi + c]; a2 += in[(r + 2) * ldi + c]; a3 += in[(r + 3) * ldi + c];
+    for (; r + 7 < r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = in[(r + j) * ldi + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
     }
-    for (; r < r1; ++r) a0 += in[r * ldi + c];
-    part[(long)s * C + c] = (a0 + a1) + (a2 + a3);
+    for (int j = 0; r < r1; ++r, ++j) a[j] += in[r * ldi + c];
+    part[(long)s * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // LayerNorm backward over the last dim C (C % 4 == 0, C <= 1024), one wavefront per row, the input row recomputed into

@@ -88,8 +88,8 @@ class MSDeformAttn(nn.Module):
         n_off = self.sampling_offsets.weight.shape[0]
         d2 = d_out.reshape(-1, C)                                         # d(src + dropout1(proj)): the residual path takes it as is
         dm = d2 if drop is None or drop[0] <= 0.0 else ops.dropout(d2, *drop)   # d(proj): the forward's mask, regenerated
-        B.acc(self.output_proj.weight, B.weight_grad(dm, samp.view(-1, C)))
-        B.acc(self.output_proj.bias, B.bias_grad(dm))
+        B.acc_wgrad(self.output_proj.weight, dm, samp.view(-1, C))
+        B.acc_bgrad(self.output_proj.bias, dm)
         d_samp = B.input_grad(dm, self.output_proj.weight).view(N, S, C)
         d_val, d_oa = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points)
         d_both = torch.cat([d_oa, d_val], -1).view(-1, n_oa + C)
@@ -165,11 +165,11 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         B.acc(self.norm2.weight, dg); B.acc(self.norm2.bias, db)
         d2 = d_x2.view(-1, C)                                           # d(s1 + dropout3(linear2)): the residual takes it as is
         dm = ops.dropout(d2, p, seed, 2) if p > 0.0 else d2               # d(linear2 output)
-        B.acc(self.linear2.weight, B.weight_grad(dm, h)); B.acc(self.linear2.bias, B.bias_grad(dm))
+        B.acc_wgrad(self.linear2.weight, dm, h); B.acc_bgrad(self.linear2.bias, dm)
         # h = dropout2(relu(z)) = relu(z) * m / (1 - p): positive exactly where the unit is active AND kept, so the ReLU
         # gate on h is the combined gate and the dropout factor is a constant per-channel scale
         d_h = B.input_grad(dm, self.linear2.weight, gate=h, gate_scale=1.0 / (1.0 - p) if p > 0.0 else 1.0)
-        B.acc(self.linear1.weight, B.weight_grad(d_h, s1.view(-1, C))); B.acc(self.linear1.bias, B.bias_grad(d_h))
+        B.acc_wgrad(self.linear1.weight, d_h, s1.view(-1, C)); B.acc_bgrad(self.linear1.bias, d_h)
         d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
         d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)
         B.acc(self.norm1.weight, dg); B.acc(self.norm1.bias, db)
@@ -305,8 +305,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         grads = {}
         # mask_features 1x1 conv <- layer_1 (3x3 conv, GN, ReLU) <- adapter_1 (1x1 conv, GN) + upsampled level-2 tokens
         d = d_mf.reshape(-1, d_mf.shape[-1])
-        B.acc(self.mask_features.weight, B.weight_grad(d, y3.view(-1, C)).view_as(self.mask_features.weight))
-        B.acc(self.mask_features.bias, B.bias_grad(d))
+        B.acc_wgrad(self.mask_features.weight, d, y3.view(-1, C))
+        B.acc_bgrad(self.mask_features.bias, d)
         d_y3 = B.input_grad(d, self.mask_features.weight.view(-1, C)).view(N, h2, w2, C)
         d_y2, dg, db, _ = B.groupnorm_up_relu_backward(y2, y3, d_y3, 32, self.layer_1.norm.weight, relu=True, eps=self.layer_1.norm.eps)
         B.acc(self.layer_1.norm.weight, dg); B.acc(self.layer_1.norm.bias, db)
@@ -316,7 +316,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                                            eps=self.adapter_1.norm.eps)
         B.acc(self.adapter_1.norm.weight, dg); B.acc(self.adapter_1.norm.bias, db)
         dc = d_cur.view(-1, C)
-        B.acc(self.adapter_1.weight, B.weight_grad(dc, x2.view(-1, c2)).view_as(self.adapter_1.weight))
+        B.acc_wgrad(self.adapter_1.weight, dc, x2.view(-1, c2))
         grads["res2"] = B.input_grad(dc, self.adapter_1.weight.view(C, c2)).view(N, h2, w2, c2)
         # encoder output tokens: the decoder's gradient per level (+ the FPN's into the finest level)
         parts = []
@@ -348,7 +348,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             B.acc(gn.weight, dg); B.acc(gn.bias, db)
             dz = d_z.view(-1, C)
             cin = x.shape[-1]
-            B.acc(conv.weight, B.weight_grad(dz, x.view(-1, cin)).view_as(conv.weight))
-            B.acc(conv.bias, B.bias_grad(dz))
+            B.acc_wgrad(conv.weight, dz, x.view(-1, cin))
+            B.acc_bgrad(conv.bias, dz)
             grads[f] = B.input_grad(dz, conv.weight.view(C, cin)).view(N, h, w, cin)
         return grads

@@ -84,7 +84,7 @@ class SelfAttentionLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc(m.out_proj.weight, Bk.weight_grad(d2, a.view(-1, C))); Bk.acc(m.out_proj.bias, Bk.bias_grad(d2))
+        Bk.acc_wgrad(m.out_proj.weight, d2, a.view(-1, C)); Bk.acc_bgrad(m.out_proj.bias, d2)
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
         dq, dk, dv = Bk.masked_attn_backward(q, qk[..., C:], v, a, lse, d_a, H=self.nhead)
         d_qk = torch.cat([dq, dk], -1).view(-1, 2 * C)
@@ -131,7 +131,7 @@ class CrossAttentionLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc(m.out_proj.weight, Bk.weight_grad(d2, a.view(-1, C))); Bk.acc(m.out_proj.bias, Bk.bias_grad(d2))
+        Bk.acc_wgrad(m.out_proj.weight, d2, a.view(-1, C)); Bk.acc_bgrad(m.out_proj.bias, d2)
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
         dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead)
         dq2 = dq.view(-1, C)
@@ -166,9 +166,9 @@ class FFNLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc(self.linear2.weight, Bk.weight_grad(d2, h)); Bk.acc(self.linear2.bias, Bk.bias_grad(d2))
+        Bk.acc_wgrad(self.linear2.weight, d2, h); Bk.acc_bgrad(self.linear2.bias, d2)
         d_h = Bk.input_grad(d2, self.linear2.weight, gate=h)
-        Bk.acc(self.linear1.weight, Bk.weight_grad(d_h, tgt.view(-1, C))); Bk.acc(self.linear1.bias, Bk.bias_grad(d_h))
+        Bk.acc_wgrad(self.linear1.weight, d_h, tgt.view(-1, C)); Bk.acc_bgrad(self.linear1.bias, d_h)
         return Bk.input_grad(d_h, self.linear1.weight, res=d2).view(B, Q, C)
 
 
@@ -191,7 +191,7 @@ class MLP(nn.Module):
         from .. import backward as Bk
         for i in reversed(range(len(self.layers))):
             l = self.layers[i]
-            Bk.acc(l.weight, Bk.weight_grad(d, acts[i])); Bk.acc(l.bias, Bk.bias_grad(d))
+            Bk.acc_wgrad(l.weight, d, acts[i]); Bk.acc_bgrad(l.bias, d)
             d = Bk.input_grad(d, l.weight, gate=acts[i] if i > 0 else None)      # acts[i] (i > 0) is the ReLU output feeding layer i
         return d
 
@@ -445,7 +445,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             d_d = self.mask_embed.backward(mlp_acts, d_e.view(B * Q, -1))
             if d_cls is not None:
                 dc = d_cls[slot].reshape(B * Q, -1).contiguous()
-                Bk.acc(self.class_embed.weight, Bk.weight_grad(dc, d)); Bk.acc(self.class_embed.bias, Bk.bias_grad(dc))
+                Bk.acc_wgrad(self.class_embed.weight, dc, d); Bk.acc_bgrad(self.class_embed.bias, dc)
                 d_d = Bk.input_grad(dc, self.class_embed.weight, res=d_d)
             d_out, dg, db = Bk.layernorm_backward(output, d_d.view(B, Q, C), self.decoder_norm.weight)
             Bk.acc(self.decoder_norm.weight, dg); Bk.acc(self.decoder_norm.bias, db)
