@@ -338,7 +338,9 @@ class KDVideoMaskFormer(nn.Module):
         grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
         backbone.backward(tb, grads)
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
-        self.last_tapes = (tb, tp, td)
+        # the activation tapes are garbage once the gradients exist; keeping them alive into the next iteration's forward
+        # costs 45 GiB of peak memory at c4 (keep_tapes = True for tests that inspect them)
+        self.last_tapes = (tb, tp, td) if getattr(self, "keep_tapes", False) else None
         return out
 
     def forward(self, batched_inputs):

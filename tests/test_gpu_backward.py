@@ -589,6 +589,7 @@ def test_whole_model_gradient_directional_derivative():
     params = [p for _, p in named]
     for p in params:
         p.grad = None
+    model.keep_tapes = True
     out = model.forward_backward(images, gt, cg, ck, kd_nmax=Q)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
     # freeze what is piecewise constant: attention masks (from the tape) and the two assignments
