@@ -287,7 +287,7 @@ extern "C" int s2d_split_weights_f16(const float *W, int N, int K, long ldw, voi
     return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream);
 }
 
-extern "C" int s2d_abi_version(void) { return 6; }
+extern "C" int s2d_abi_version(void) { return 7; }
 
 extern "C" int s2d_set_dense_mode(int mode)
 {

@@ -121,6 +121,28 @@ def test_gemm_gate_epilogue(oracle, dense_mode, M, N, K, with_res):
     assert torch.equal(want, got)
 
 
+@pytest.mark.parametrize("M,N,K,with_res,relu", [(700, 256, 1024, True, False), (4096, 1024, 256, False, True), (130, 64, 224, False, False)])
+def test_gemm_presplit_a(oracle, dense_mode, M, N, K, with_res, relu):
+    """A handed over as its fp16 hi/lo row image (what an upstream kernel could write instead of fp32): bit-equal to the GEMM that
+    splits A itself"""
+    from s2d_amd import ops
+    if dense_mode != "f16x3":
+        pytest.skip("the row image is the split-fp16 kernels' format")
+    A = _dev(synth.randn(6, 1, (M, K)))
+    W = torch.nn.Parameter(_dev(synth.randn(6, 2, (N, K))), requires_grad=False)
+    b = _dev(synth.randn(6, 3, (N,)))
+    R = _dev(synth.randn(6, 4, (M, N))) if with_res else None
+    want = ops.gemm_nt(A, W, bias=b, res=R, relu=relu)
+    got = ops.gemm_nt_presplit(ops.split_rows(A), M, K, W, bias=b, res=R, relu=relu)
+    assert torch.equal(want, got)
+    ref = A.double().cpu().numpy() @ W.detach().double().cpu().numpy().T + b.double().cpu().numpy()
+    if with_res:
+        ref = ref + R.double().cpu().numpy()
+    if relu:
+        ref = np.maximum(ref, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
 def test_wave_specialised_kernel_subprocess(dense_mode):
     """the opt-in wave-specialised persistent GEMM / conv kernel (S2D_GEMM_WS=2 routes every eligible launch to it) against the
     same oracle cases as the default dispatch: this file and the fused-dropout cases, in a child process because the switch
