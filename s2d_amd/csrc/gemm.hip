@@ -174,8 +174,7 @@ int launch(const GemmParams &p, bool conv, int batch, hipStream_t st)
     if (p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return S2D_ERR_ARG;
     if (p.gate && g_dense_mode != 2) return S2D_ERR_ARG;    // the gate lives in the split-fp16 kernels' vector epilogues
     if (g_dense_mode >= 1) {
-        GemmParams q = p;
-        if (g_dense_mode != 2) q.Bsplit = nullptr;      // the pre-split image is fp16 hi/lo: only mode 2 reads it
+        GemmParams q = p;      // the pre-split image of a static B was made for the mode in force (s2d_split_weights_f16)
         return s2d_launch_gemm_bf16x3(q, conv, batch, st, g_dense_mode == 2);
     }
     const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -284,7 +283,9 @@ extern "C" long s2d_split_weights_words(int N, int K) { return (long)N * ((K + 3
 extern "C" int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hipStream_t stream)
 {
     if (N < 0 || K <= 0 || ldw < K) return S2D_ERR_ARG;
-    return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream);
+    // the image follows the dense mode in force: fp16 hi / scaled lo (mode 2) or bf16 hi / lo (mode 1); callers key their
+    // caches by the mode (ops._static_split)
+    return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream, g_dense_mode == 1);
 }
 
 extern "C" int s2d_abi_version(void) { return 7; }

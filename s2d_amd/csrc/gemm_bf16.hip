@@ -224,6 +224,228 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_bf16x3_kernel(GemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Split-bf16 x3 with 128 x 64 per wave ("w128"): bf16 needs no scaled low part, so the three products of a tile land in ONE
+// accumulator set -- 128 accumulator registers now cover 128 x 64 per wave instead of 64 x 64.  Per k-step a wave reads 12
+// fragments for 24 MFMAs (0.5 reads per MFMA against 0.67 with 64 x 64 tiles) and a 256 x 128 x 32 tile costs ~3 staging
+// instructions per MFMA instead of ~5.  Workgroup = 4 waves (2 x 2), tile 256 x 128 x 32, ONE LDS operand buffer (55 KB;
+// 69.6 KB with the epilogue staging) so that two workgroups share a CU: one's split / store / barrier phases run under the
+// other's 48-MFMA blocks.  Operand loads for k-tile kt+1 are issued right after the barrier that publishes k-tile kt and
+// land behind its MFMAs.
+template <bool CONV, bool BSPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_w128_kernel(GemmParams p)
+{
+    constexpr int BM = 256, RPT = 32, A_IT = BM / RPT, B_IT = BN / RPT;      // 8 / 4 float4 per thread per k-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *As = lds;                         // [BM][ROWW]
+    unsigned int *Bs = lds + BM * ROWW;             // [BN][ROWW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+    const float *A = p.A + (long)bz * p.sA;
+    const float *B = p.B + (long)bz * p.sB;
+    float *C = p.C + (long)bz * p.sC;
+
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    constexpr unsigned int OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = BSPLIT
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)p.bytesB, 0x00020000);
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;     // BSPLIT: this thread's 4 words of a pre-split row block
+    unsigned int a_off[A_IT], a_bad[A_IT];
+    int a_iy0[A_IT], a_ix0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + RPT * i;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.Wout, t = mm / p.Wout, oy = t % p.Hout, n = t / p.Hout;
+            a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_off[i] = (unsigned int)((long)n * p.Hin * p.Win * p.Cin * 4L);
+        } else {
+            a_off[i] = ok ? (unsigned int)((long)m * p.lda * 4L) : 0u;
+            a_iy0[i] = a_ix0[i] = 0;
+        }
+        a_bad[i] = ok ? 0u : OOB;
+    }
+    unsigned int b_off[B_IT], b_bad[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + r0 + RPT * i;
+        b_off[i] = n < p.N ? (unsigned int)(BSPLIT ? (long)n * p.kblocks * 128L + wsel * 4 : (long)n * p.ldb * 4L) : 0u;
+        b_bad[i] = n < p.N ? 0u : OOB;
+    }
+    // every wait on these loads is a full drain (vmcnt(0) before the split), so masked out-of-range offsets are safe here
+    f32x4 ra[A_IT], rb[B_IT];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + c4 * 4;
+        const unsigned int kmask = (unsigned int)((p.K - 1 - k) >> 31) & OOB;
+        int kh = 0, kw = 0, ci = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            unsigned int off;
+            if (CONV) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const unsigned int tmask = (unsigned int)(((iy | ix | (p.Hin - 1 - iy) | (p.Win - 1 - ix)) >> 31)) & OOB;
+                off = (a_off[i] + (unsigned int)(((iy * p.Win + ix) * p.Cin + ci) * 4)) | tmask | kmask;
+            } else {
+                off = (a_off[i] + (unsigned int)(k * 4)) | a_bad[i] | kmask;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsB, (int)((b_off[i] + (unsigned int)(BSPLIT ? kt * 128 : k * 4)) | b_bad[i] | (BSPLIT ? 0u : kmask)), 0, 0));
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            u32x2 hi, lo;
+            split4(ra[i], hi, lo);
+            unsigned int *row = &As[(r0 + RPT * i) * ROWW];
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            u32x2 hi, lo;
+            unsigned int *row = &Bs[(r0 + RPT * i) * ROWW];
+            if (BSPLIT) { *reinterpret_cast<f32x4 *>(row + wsel) = rb[i]; continue; }
+            split4(rb[i], hi, lo);
+            *reinterpret_cast<u32x2 *>(row + c4 * 2) = hi;
+            *reinterpret_cast<u32x2 *>(row + 16 + c4 * 2) = lo;
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned int *as = &As[(wm * 128 + l32) * ROWW + 4 * h];
+    const unsigned int *bs = &Bs[(wn * 64 + l32) * ROWW + 4 * h];
+    // Fragment reads run one row block ahead of the MFMAs that use them (two A fragment sets, the next k-step's B fragments
+    // fetched during the last row block): left to itself the compiler reads every fragment into the same registers right in
+    // front of its MFMAs and the matrix pipe waits out an LDS round trip per row block.
+    auto compute = [&]() {
+        bf16x8 bh[2][2], bl[2][2], ah[2], al[2];             // [k-step parity][column block] / [row-block parity]
+        auto read_b = [&](int s) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[s & 1][t] = *reinterpret_cast<const bf16x8 *>(bs + t * 32 * ROWW + 8 * s);
+                bl[s & 1][t] = *reinterpret_cast<const bf16x8 *>(bs + t * 32 * ROWW + 16 + 8 * s);
+            }
+        };
+        auto read_a = [&](int s, int i) {
+            ah[i & 1] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWW + 8 * s);
+            al[i & 1] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWW + 16 + 8 * s);
+        };
+        read_b(0); read_a(0, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                         // g = k-step * 4 + row block
+            const int s = g >> 2, i = g & 3;
+            if (g + 1 < 8) read_a((g + 1) >> 2, (g + 1) & 3);
+            if (i == 3 && s == 0) read_b(1);
+            __builtin_amdgcn_sched_barrier(0);
+            // small terms first, the dominant hi.hi last; the two column blocks alternate so that dependent MFMAs are one apart
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[s][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[s][1], acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[s][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[s][1], acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[s][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[s][1], acc[i][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();                                         // k-tile kt: split into the (free) operand buffer
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);                   // lands behind the MFMAs below
+        compute();
+        __syncthreads();                                      // everyone is done reading before the next store
+    }
+
+    // epilogue: two halves of 64 rows per wave through LDS (the operand buffer is dead), 16-B row stores when the shapes allow
+    const float *res = p.res ? p.res + (long)bz * p.sR : nullptr;
+    const bool vec = ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0;
+    float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 68;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (vec) {
+            if (half) __syncthreads();                        // (uniform) the previous half has been streamed out
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] = acc[half * 2 + tm][tn][r];
+            const int c4e = lane & 15, rr = lane >> 4;
+            const int col = n0 + wn * 64 + c4e * 4;
+            if (col < p.N) {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
+                if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
+                const int rbase = m0 + wm * 128 + half * 64 + rr;
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int row = rbase + it * 4;
+                    if (row >= p.M) break;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 4 + rr) * 68 + c4e * 4]);
+                    v = v * sc + bi;
+                    if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    *reinterpret_cast<f32x4 *>(C + (long)row * p.ldc + col) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int col = n0 + wn * 64 + tn * 32 + l32;
+                if (col >= p.N) continue;
+                const float sc = p.scale ? p.scale[col] : 1.f;
+                const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 128 + half * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row >= p.M) continue;
+                        float v = acc[half * 2 + tm][tn][r] * sc + bi;
+                        if (res && col < p.res_cols) v += res[(long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        C[(long)row * p.ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Split-fp16 x3 with a scaled low part ("f16x3"): fp32-class accuracy (~3*2^-22) at the same MFMA count.
 //   x = h + l * 2^-11,   h = fp16_rtz(x),   l = fp16_rtz((x - h) * 2^11)          (22+ significant bits, l never
 //   A.B^T = [Ah.Bh^T] + 2^-11 * [Ah.Bl^T + Al.Bh^T]                                 underflows relative to h)
@@ -1288,6 +1510,29 @@ int launch_f16(const GemmParams &p, int batch, hipStream_t st)
     return p.Bsplit ? launch_f16_v<CONV, PIPE, true>(p, batch, st) : launch_f16_v<CONV, PIPE, false>(p, batch, st);
 }
 
+template <bool CONV, bool BSPLIT>
+int launch_w128_v(const GemmParams &p, int batch, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= operand buffer (55.3 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_w128_kernel<CONV, BSPLIT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.M, 256) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_bf16x3_w128_kernel<CONV, BSPLIT>), dim3(nwg, batch), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+template <bool CONV>
+int launch_w128(const GemmParams &p, int batch, hipStream_t st)
+{
+    return p.Bsplit ? launch_w128_v<CONV, true>(p, batch, st) : launch_w128_v<CONV, false>(p, batch, st);
+}
+
 template <int WM, bool CONV>
 int launch_t(const GemmParams &p, int batch, hipStream_t st)
 {
@@ -1307,6 +1552,7 @@ int launch_t(const GemmParams &p, int batch, hipStream_t st)
 }
 
 // static weights -> [N][kblocks][16 words hi | 16 words lo]: the LDS row image of the split-fp16 kernels, zero padded past K
+template <bool BF16>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ W, int N, int K, long ldw, int kblocks,
                                                             unsigned int *__restrict__ out)
 {
@@ -1322,7 +1568,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
     for (int j = 0; j < 4; ++j)
         if (k + j < K) v[j] = W[n * ldw + k + j];
     u32x2 hi, lo;
-    split4_f16(v, hi, lo);
+    if (BF16) split4(v, hi, lo);            // split-bf16 mode: unscaled low part (gemm_bf16x3_w128_kernel)
+    else split4_f16(v, hi, lo);
     unsigned int *o = out + nb * 32;
     *reinterpret_cast<u32x2 *>(o + c4 * 2) = hi;
     *reinterpret_cast<u32x2 *>(o + 16 + c4 * 2) = lo;
@@ -1330,12 +1577,13 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
 
 }  // namespace
 
-int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st)
+int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st, int bf16)
 {
     const int kblocks = (K + 31) / 32;
     const long n = (long)N * kblocks * 8;
     if (n == 0) return S2D_OK;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
+    if (bf16) hipLaunchKernelGGL(split_weights_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
+    else hipLaunchKernelGGL(split_weights_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1348,9 +1596,10 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (bA > 0xFFFFFF00L || bB > 0xFFFFFF00L) return S2D_ERR_ARG;   // 32-bit buffer offsets
     p.bytesA = (unsigned int)bA; p.bytesB = (unsigned int)bB;
     if (p.Bsplit) {
-        if (!f16 || (batch > 1 && p.sB != 0) || (long)p.N * ((p.K + 31) / 32) * 128L > 0xFFFFFF00L) return S2D_ERR_ARG;
+        if ((batch > 1 && p.sB != 0) || (long)p.N * ((p.K + 31) / 32) * 128L > 0xFFFFFF00L) return S2D_ERR_ARG;
         p.kblocks = (p.K + 31) / 32;
     }
+    if (!f16 && (p.Asplit || p.gate || p.drop_thresh)) return S2D_ERR_ARG;
     static int ws = -1;
     if (ws < 0) { const char *e = getenv("S2D_GEMM_WS"); ws = e ? atoi(e) : 0; }
 
@@ -1408,6 +1657,11 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         if (pipe) return conv ? launch_f16<true, true>(p, batch, st) : launch_f16<false, true>(p, batch, st);
         return conv ? launch_f16<true, false>(p, batch, st) : launch_f16<false, false>(p, batch, st);
     }
+    static int w128 = -1;
+    if (w128 < 0) { const char *e = getenv("S2D_GEMM_W128"); w128 = e ? atoi(e) : 1; }
+    // 128 x 64 per wave: GEMMs with enough tiles for two workgroups per CU (the implicit-GEMM form needs more address registers
+    // than the 256-register budget leaves and spills: convolutions stay on the 64 x 64 kernels)
+    if (w128 && !conv && (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= (w128 == 2 ? 1 : 512)) return launch_w128<false>(p, batch, st);
     static int force = -1;
     if (force < 0) { const char *e = getenv("S2D_GEMM_WM"); force = e ? atoi(e) : 0; }
     bool big = (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= 256;

@@ -39,5 +39,5 @@ struct GemmParams {
 };
 
 
-int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st);
+int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st, int bf16);
 int s2d_launch_gemm_bf16x3(const GemmParams &p, bool conv, int batch, hipStream_t st, int f16);

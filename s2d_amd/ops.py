@@ -79,12 +79,12 @@ def clear_weight_cache():
 
 def _static_split(B, N, K, ldb):
     """cached fp16 hi/lo image of a static weight matrix, or None (dynamic tensor / other dense mode)"""
-    if _MODE != "f16x3" or N * ((K + 31) // 32) * 128 > 0xFFFFFF00:
+    if _MODE == "f32" or N * ((K + 31) // 32) * 128 > 0xFFFFFF00:
         return None
     base = B._base if B._base is not None else B
     if not (isinstance(base, torch.nn.Parameter) or getattr(base, "_s2d_static", False) or getattr(B, "_s2d_static", False)):
         return None
-    key = (B.data_ptr(), N, K, ldb)
+    key = (B.data_ptr(), N, K, ldb, _MODE)      # the image is fp16 hi / scaled lo or bf16 hi / lo, by the mode in force
     ent = _SPLIT.get(key)
     if ent is None or ent[1] != base._version or ent[2] is not base:
         img = torch.empty((lib().call("s2d_split_weights_words", N, K),), device=B.device, dtype=torch.int32)

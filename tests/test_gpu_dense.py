@@ -84,7 +84,7 @@ def test_presplit_static_weights(oracle, dense_mode):
     n0 = len(ops._SPLIT)
     out = ops.gemm_nt(A, W)
     assert torch.equal(out, ref)
-    assert len(ops._SPLIT) == n0 + (1 if dense_mode == "f16x3" else 0)
+    assert len(ops._SPLIT) == n0 + (1 if dense_mode in ("f16x3", "bf16x3") else 0)
     out_v = ops.gemm_nt(A, W[32:160])                      # a row view of the parameter
     assert torch.equal(out_v, ref[:, 32:160])
     with torch.no_grad():
@@ -143,18 +143,19 @@ def test_gemm_presplit_a(oracle, dense_mode, M, N, K, with_res, relu):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
-def test_wave_specialised_kernel_subprocess(dense_mode):
-    """the opt-in wave-specialised persistent GEMM / conv kernel (S2D_GEMM_WS=2 routes every eligible launch to it) against the
-    same oracle cases as the default dispatch: this file and the fused-dropout cases, in a child process because the switch
-    is read once per process"""
+@pytest.mark.parametrize("switch,select", [("S2D_GEMM_WS", "gemm or conv or dropout"), ("S2D_GEMM_W128", "bf16x3 and (gemm or presplit)")])
+def test_forced_kernel_subprocess(dense_mode, switch, select):
+    """kernels the default dispatch only picks for large shapes, forced onto every eligible launch (value 2 of their switch) and
+    run against the same oracle cases: the opt-in wave-specialised persistent kernel (S2D_GEMM_WS) and the 128 x 64-per-wave
+    split-bf16 kernel (S2D_GEMM_W128); in a child process because the switches are read once per process"""
     import os
     import subprocess
     import sys
-    if os.environ.get("S2D_GEMM_WS") or dense_mode != "f16x3":
-        pytest.skip("once, from the default mode, outside the wave-specialised run")
+    if os.environ.get("S2D_GEMM_WS") or os.environ.get("S2D_GEMM_W128") or dense_mode != "f16x3":
+        pytest.skip("once, from the default mode, outside a forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, S2D_GEMM_WS="2")
+    env = dict(os.environ, **{switch: "2"})
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_dense.py"), os.path.join(root, "tests", "test_gpu_dropin.py"),
-                        "-k", "gemm or conv or dropout"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "-k", select], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
