@@ -843,6 +843,184 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// 3 x 3 / stride 1 / pad 1 convolution with the input staged ONCE per channel block ("halo"): the implicit-GEMM kernel above
+// re-loads and re-splits the 128 input rows of a tile for each of the nine taps (9 x 128 rows per 32 channels); here a
+// workgroup owns an 8 x 16 patch of output pixels, stages the 10 x 18 input halo of a 32-channel block (180 rows) and all
+// nine taps read their A fragments from it at shifted rows.  Per tap a thread then only copies its four 16-B pieces of the
+// pre-split weight block: ~15 staging instructions per 24 MFMAs instead of ~100.  Same arithmetic per product; the k order
+// is (channel block, tap) instead of (tap, channel block), so sums differ from the implicit-GEMM kernel in the last bits.
+//   LDS: halo 180 rows (25.9 KB, single: replaced between channel blocks) + two weight buffers (36.9 KB); 69.6 KB with the
+//   epilogue staging -> two workgroups per CU.
+constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * (HT_W + 2);
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *Ah = lds;                              // [HALO_ROWS][ROWW]
+    unsigned int *Bs = lds + HALO_ROWS * ROWW;           // [2][BN][ROWW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int H = p.Hin, W = p.Win, Cin = p.Cin;
+    const int tiles_x = (W + HT_W - 1) / HT_W, tiles_y = (H + HT_H - 1) / HT_H;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M / (H * W)) * tiles_y * tiles_x;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int n0 = tile_n * BN;
+    const int img = tile_m / (tiles_y * tiles_x), trem = tile_m % (tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * HT_H, x0 = (trem % tiles_x) * HT_W;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000);
+    // every load is in range (see the wave-specialised kernel): pixels outside the image read offset 0 and are zeroed when the
+    // halo is stored; weight rows past Cout read the last row (their columns are never stored)
+    // halo staging: item = (halo row, 16-B piece); 1440 items over 256 threads
+    constexpr int A_IT = (HALO_ROWS * 8 + 255) / 256;     // 6
+    unsigned int ha_off[A_IT];
+    int ha_dst[A_IT];
+    bool ha_zero[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int item = tid + 256 * i;
+        const int row = item >> 3, c4 = item & 7;
+        const int hy = row / HALO_W, hx = row - hy * HALO_W;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = row < HALO_ROWS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        ha_off[i] = ok ? (unsigned int)((((long)img * H + iy) * W + ix) * Cin * 4L + c4 * 16) : 0u;
+        ha_zero[i] = !ok;
+        ha_dst[i] = row < HALO_ROWS ? row * ROWW + c4 * 2 : -1;
+    }
+    // weight staging: as the implicit-GEMM kernel (row r0 + 32 i of the tile, 16-B piece wsel of its pre-split block)
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;
+    unsigned int b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_off[i] = (unsigned int)((long)(n < p.N ? n : p.N - 1) * p.kblocks * 128L + wsel * 4);
+    }
+    const int cblocks = Cin / 32;
+    f32x4 ra[A_IT], rb[4];
+    auto load_halo = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)ha_off[i], ha_zero[i] ? 0 : cb * 128, 0));
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            if (ha_dst[i] < 0) continue;
+            u32x2 hi, lo;
+            split4_f16(ra[i], hi, lo);
+            if (ha_zero[i]) { hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u}; }
+            *reinterpret_cast<u32x2 *>(Ah + ha_dst[i]) = hi;
+            *reinterpret_cast<u32x2 *>(Ah + ha_dst[i] + 16) = lo;
+        }
+    };
+    auto load_w = [&](int tap, int cb) {                   // k block of (tap, channel block) in the [Cout][3][3][Cin] weights
+        const unsigned int kb = (unsigned int)(tap * cblocks + cb) * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], (int)kb, 0));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4 *>(Bs + (buf * BN + r0 + 32 * i) * ROWW + wsel) = rb[i];
+    };
+    // fragment rows: output pixel (py, px) of the patch reads halo row (py + dy) * 18 + px + dx for tap (dy, dx)
+    int a_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pix = wm * 64 + i * 32 + l32;
+        a_row[i] = ((pix / HT_W) * HALO_W + (pix % HT_W)) * ROWW + 4 * h;
+    }
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+    auto compute = [&](int tap, int buf) {
+        const int toff = ((tap / 3) * HALO_W + (tap % 3)) * ROWW;
+        const unsigned int *bs = Bs + (buf * BN + wn * 64 + l32) * ROWW + 4 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                bh[t2] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 8 * s);
+                bl[t2] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 16 + 8 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ah + a_row[i] + toff + 8 * s);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(Ah + a_row[i] + toff + 16 + 8 * s);
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accx[i][0], 0, 0, 0);
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accx[i][1], 0, 0, 0);
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accx[i][0], 0, 0, 0);
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accx[i][1], 0, 0, 0);
+                accm[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], accm[i][0], 0, 0, 0);
+                accm[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], accm[i][1], 0, 0, 0);
+            }
+        }
+    };
+    // (channel block, tap) stream: q = cb * 9 + tap.  Weights of step q+1 are loaded during step q and stored into the other
+    // buffer before the barrier; the halo of block cb+1 is loaded during tap 6 of block cb and stored after the barrier that
+    // ends tap 8 (when nobody reads the old halo any more), followed by one more barrier.
+    load_halo(0); load_w(0, 0);
+    store_halo(); store_w(0);
+    __syncthreads();
+    const int Q = cblocks * 9;
+    int tap = 0, cb = 0;
+    for (int q = 0; q < Q; ++q) {
+        const int ntap = tap == 8 ? 0 : tap + 1, ncb = tap == 8 ? cb + 1 : cb;
+        if (q + 1 < Q) load_w(ntap, ncb);
+        if (tap == 6 && cb + 1 < cblocks) load_halo(cb + 1);
+        compute(tap, q & 1);
+        if (q + 1 < Q) store_w((q + 1) & 1);
+        __syncthreads();
+        if (tap == 8 && cb + 1 < cblocks) { store_halo(); __syncthreads(); }
+        tap = ntap; cb = ncb;
+    }
+
+    // epilogue (the 16-B row form; host-checked: Cout % 4 == 0): the wave's 64 pixels x 64 channels through LDS
+    float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 68;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] = accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+    const int c4e = lane & 15, rr = lane >> 4;
+    const int col = n0 + wn * 64 + c4e * 4;
+    if (col < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
+        if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int pix = wm * 64 + it * 4 + rr;
+            const int oy = y0 + pix / HT_W, ox = x0 + pix % HT_W;
+            if (oy >= H || ox >= W) continue;
+            const long row = ((long)img * H + oy) * W + ox;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 4 + rr) * 68 + c4e * 4]);
+            v = v * sc + bi;
+            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + row * p.ldr + col);
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            *reinterpret_cast<f32x4 *>(p.C + row * p.ldc + col) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // High-occupancy split-fp16 x3 variant: 128 x 64 x 32 tile, 4 waves of 64 x 32 (two f32 accumulator sets = 64
 // registers), single LDS buffer (27.6 KB operands, 36.9 KB with the epilogue staging).  ~4 workgroups = 16 waves per
 // CU: while one workgroup splits / stores / waits at its barriers, three others keep the matrix pipe busy (the
@@ -1510,6 +1688,22 @@ int launch_f16(const GemmParams &p, int batch, hipStream_t st)
     return p.Bsplit ? launch_f16_v<CONV, PIPE, true>(p, batch, st) : launch_f16_v<CONV, PIPE, false>(p, batch, st);
 }
 
+int launch_conv3x3_halo(const GemmParams &p, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int imgs = p.M / (p.Hin * p.Win);
+    const int nwg = imgs * cdiv(p.Hin, HT_H) * cdiv(p.Win, HT_W) * cdiv(p.N, BN);
+    hipLaunchKernelGGL(conv3x3_f16x3_halo_kernel, dim3(nwg), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 template <bool CONV, bool BSPLIT>
 int launch_w128_v(const GemmParams &p, int batch, hipStream_t st)
 {
@@ -1640,6 +1834,14 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         // the weights arrive pre-split, on the GEMMs with K >= 512 (+9..23 %) and on K = 256 when 128-wide tiles waste no
         // more columns than 64-wide ones; the 16-waves/CU 128x64 kernel keeps the short-K (<= 128: two to four k-steps,
         // all prologue/epilogue), narrow (N <= 64) and dynamic-B launches
+        static int halo = -1;
+        if (halo < 0) { const char *e = getenv("S2D_CONV_HALO"); halo = e ? atoi(e) : 1; }
+        // 3 x 3 / stride 1 / pad 1 on whole 32-channel blocks with static weights: the input-halo kernel
+        // ... when its 8 x 16 patches cover the image without much overhang (23 x 40 -> 24 x 48 wastes 20 %: implicit GEMM wins)
+        if (halo && conv && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin % 32 == 0 && p.Bsplit && batch == 1 && p.N > 64 &&
+            ((p.N | p.ldc | p.ldr) & 3) == 0 && !p.res_rows && p.res_cols == p.N && !p.gate &&
+            (halo == 2 || (long)p.Hin * p.Win * 100 >= (long)cdiv(p.Hin, HT_H) * HT_H * cdiv(p.Win, HT_W) * HT_W * 88))
+            return launch_conv3x3_halo(p, st);
         static int hi = -1;
         if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }
         bool use_hi;

@@ -95,7 +95,10 @@ def test_presplit_static_weights(oracle, dense_mode):
     w = _dev(synth.randn(3, 4, (128, 3, 3, 64)) * 0.05)
     y0 = ops.conv2d_nhwc(x, w, 1, 1)
     y1 = ops.conv2d_nhwc(x, ops.mark_static(w.clone()), 1, 1)
-    assert torch.equal(y0, y1)
+    if dense_mode == "f16x3":          # static 3x3 weights take the input-halo kernel: same products, (channel block, tap) order
+        assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
+    else:
+        assert torch.equal(y0, y1)
     ops.clear_weight_cache()
 
 
@@ -143,15 +146,38 @@ def test_gemm_presplit_a(oracle, dense_mode, M, N, K, with_res, relu):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("switch,select", [("S2D_GEMM_WS", "gemm or conv or dropout"), ("S2D_GEMM_W128", "bf16x3 and (gemm or presplit)")])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,with_res", [(2, 16, 32, 64, 128, False), (1, 23, 40, 128, 192, True), (3, 9, 17, 32, 68, True),
+                                                      (1, 46, 80, 256, 256, False)])
+def test_conv3x3_halo(oracle, dense_mode, N, H, W, Cin, Cout, with_res):
+    """3x3 / stride 1 / pad 1 with static weights (the input-halo kernel in the default mode): image borders, patches that hang
+    over the bottom / right edge, Cout that is not a multiple of the 128-wide tile, scale + bias + residual + ReLU"""
+    from s2d_amd import ops
+    x = synth.randn(7, 1, (N, H, W, Cin))
+    w = (synth.randn(7, 2, (Cout, 3, 3, Cin)) / np.sqrt(9.0 * Cin)).astype(np.float32)
+    sc = (synth.randn(7, 3, (Cout,)) * 0.5 + 1).astype(np.float32)
+    bi = synth.randn(7, 4, (Cout,))
+    res = synth.randn(7, 5, (N, H, W, Cout)) if with_res else None
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xt, wt, padding=1).permute(0, 2, 3, 1).numpy() * sc + bi
+    if with_res:
+        ref = ref + res
+    ref = np.maximum(ref, 0)
+    out = ops.conv2d_nhwc(_dev(x), ops.mark_static(_dev(w)), 1, 1, scale=_dev(sc), bias=_dev(bi), res=_dev(res) if with_res else None,
+                          relu=True).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("switch,select", [("S2D_GEMM_WS", "gemm or conv or dropout"), ("S2D_GEMM_W128", "bf16x3 and (gemm or presplit)"),
+                                           ("S2D_CONV_HALO", "f16x3 and conv")])
 def test_forced_kernel_subprocess(dense_mode, switch, select):
     """kernels the default dispatch only picks for large shapes, forced onto every eligible launch (value 2 of their switch) and
     run against the same oracle cases: the opt-in wave-specialised persistent kernel (S2D_GEMM_WS) and the 128 x 64-per-wave
-    split-bf16 kernel (S2D_GEMM_W128); in a child process because the switches are read once per process"""
+    split-bf16 kernel (S2D_GEMM_W128), the input-halo 3x3 convolution on every patch geometry (S2D_CONV_HALO); in a child process because the switches are read once per process"""
     import os
     import subprocess
     import sys
-    if os.environ.get("S2D_GEMM_WS") or os.environ.get("S2D_GEMM_W128") or dense_mode != "f16x3":
+    if os.environ.get("S2D_GEMM_WS") or os.environ.get("S2D_GEMM_W128") or os.environ.get("S2D_CONV_HALO") or dense_mode != "f16x3":
         pytest.skip("once, from the default mode, outside a forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **{switch: "2"})
