@@ -162,6 +162,23 @@ def _transposed_weight(w, Np):
     return ent[0]
 
 
+_WF = {}
+
+
+def _flipped_weight(w):
+    """the dgrad kernel of a convolution weight [Cout,KH,KW,Cin]: taps flipped, channels swapped -> [Cin,KH,KW,Cout]; cached per
+    weight version and marked static (like _transposed_weight), so that the dgrad convolutions run on the forward's kernels with
+    a pre-split image"""
+    w = w.detach()
+    base = w._base if w._base is not None else w
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+    ent = _WF.get(key)
+    if ent is None or ent[1] != base._version or ent[2] is not base:
+        ent = (ops.mark_static(w.flip(1, 2).permute(3, 1, 2, 0).contiguous()), base._version, base)
+        _WF[key] = ent
+    return ent[0]
+
+
 def input_grad(dy, w, res=None, gate=None, gate_scale=1.0):
     """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection).  gate [M,K]: the output of the
     ReLU (and dropout) that produced this layer's input -- dx is zeroed where gate <= 0 and multiplied by gate_scale
@@ -195,7 +212,7 @@ def conv_input_grad(dy, w, stride, pad, in_hw):
     N, Ho, Wo, Co = dy.shape
     Co2, KH, KW, Ci = w.shape
     H, W = in_hw
-    wf = w.detach().flip(1, 2).permute(3, 1, 2, 0).contiguous()       # [Cin,KH,KW,Cout]
+    wf = _flipped_weight(w)                                            # [Cin,KH,KW,Cout], once per weight version, pre-split by the dense kernels
     if KH == 1 and KW == 1 and pad == 0:
         g = ops.gemm_nt(dy.view(-1, Co), wf.view(Ci, Co)).view(N, Ho, Wo, Ci)
         if stride == 1:

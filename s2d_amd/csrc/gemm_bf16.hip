@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
     auto load_halo = [&](int cb) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)ha_off[i], ha_zero[i] ? 0 : cb * 128, 0));
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(ha_off[i] + (ha_zero[i] ? 0u : (unsigned int)(cb * 128))), 0, 0));   // per-lane choice: in the vector offset (a divergent scalar offset compiles to a waterfall loop)
     };
     auto store_halo = [&]() {
 #pragma unroll
