@@ -13,6 +13,7 @@
 // contiguous band of queries: a band's sampling footprint (~1/8 of a 20 MB value map) then stays in that
 // XCD's 4 MB L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // normalised pixel centre is its reference point on every level, msdeformattn.py:141-153 with valid
 // ratios == 1).  `oa` [N,S,ldoa] holds, per query, the raw sampling offsets [M][L][P][2] followed by the raw
 // attention logits [M][L*P] (one GEMM output).  Softmax over L*P and loc = ref + off/(W_l,H_l) happen here.
-template <int LP_, bool HM = false>
+template <int LP_, bool HM = false, bool SHARE = false>
 __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
                                                          int P, int blk_per_n, float *__restrict__ out)
@@ -142,12 +143,79 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < LP_; ++i) mx = fmaxf(mx, lg[i]);
     float den = 0.f;
+    if constexpr (SHARE && LP_ <= 16) {
+        // the 12 exponentials as well: lane j of the head's group evaluates logits j and j + 8, the group gathers them and every
+        // lane adds them in index order (the same sum, bit for bit, as the all-in-one-lane form below)
+        const int j = threadIdx.x & 7;
+        float own[2];
 #pragma unroll
-    for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+        for (int r = 0; r < 2; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < LP_; ++k)
+                if (k == j + 8 * r) v = lg[k];
+            own[r] = expf(v - mx);
+        }
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) { lg[i] = __shfl(own[i >> 3], i & 7, 8); den += lg[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+    }
     const float inv = 1.f / den;
     // HM (experiment): value stored head-major, [N][M][S][32], a pixel's 128 B of one head next to its neighbours'
     const long rowstride = HM ? D : ldv;
     f32x4 acc = f32x4(0.f);
+    if constexpr (SHARE && LP_ <= 16) {
+        // The bilinear set-up of a sample (floor, weights, border tests, first pixel) is the same for the 8 lanes of a head.
+        // Lane j of the group prepares samples j and j + 8 and the group reads them back with 8-lane shuffles (ds_bpermute: the
+        // LDS crossbar, idle in this kernel): 2 set-ups per wave instruction stream instead of LP_.  Same formulas, same values.
+        const int j = threadIdx.x & 7;
+        float sw1[2], sw2[2], sw3[2], sw4[2], saw[2];
+        int spix[2], smask[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = j + 8 * r;
+            const int ic = i < LP_ ? i : LP_ - 1;
+            // the lane's own sample: a dynamic index into offp / lg would spill them, so select through the unrolled constants
+            float ox = 0.f, oy = 0.f, lgi = 0.f;
+#pragma unroll
+            for (int k = 0; k < LP_; ++k)
+                if (k == ic) { ox = offp[2 * k]; oy = offp[2 * k + 1]; lgi = lg[k]; }
+            const int l = ic / P;
+            const int H = lv.H[l], W = lv.W[l];
+            const float lx = ref_x + ox / (float)W, ly = ref_y + oy / (float)H;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // cuh:293
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+            sw1[r] = hh * hw; sw2[r] = hh * lw; sw3[r] = lh * hw; sw4[r] = lh * lw;
+            saw[r] = lgi * inv;
+            spix[r] = h0 * W + w0;
+            smask[r] = !in ? 0 : ((h0 >= 0 && w0 >= 0) ? 1 : 0) | ((h0 >= 0 && w1 <= W - 1) ? 2 : 0) | ((h1 <= H - 1 && w0 >= 0) ? 4 : 0) |
+                                 ((h1 <= H - 1 && w1 <= W - 1) ? 8 : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) {
+            const int r = i >> 3, src = i & 7;
+            const int l = i / P;
+            const int W = lv.W[l];
+            const int mask = __shfl(smask[r], src, 8);
+            if (mask == 0) continue;                           // uniform over the head's 8 lanes
+            const int pix = __shfl(spix[r], src, 8);
+            const float c1 = __shfl(sw1[r], src, 8), c2 = __shfl(sw2[r], src, 8), c3 = __shfl(sw3[r], src, 8), c4 = __shfl(sw4[r], src, 8);
+            const float aw = __shfl(saw[r], src, 8);
+            const float *vbase = HM ? value + (((long)n * M + m) * S + lv.start[l]) * D + c * V
+                                    : value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
+            const float *p1 = vbase + (long)pix * rowstride;
+            f32x4 v1 = f32x4(0.f), v2 = f32x4(0.f), v3 = f32x4(0.f), v4 = f32x4(0.f);
+            if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
+            if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + rowstride);
+            if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * rowstride);
+            if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * rowstride);
+            acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < LP_; ++i) {
         const int l = i / P;
@@ -157,6 +225,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
         const float lx = ref_x + offp[2 * i] / (float)W;       // ms_deform_attn.py:106-109
         const float ly = ref_y + offp[2 * i + 1] / (float)H;
         sample_accum<4>(acc, vbase, rowstride, H, W, ly * H - 0.5f, lx * W - 0.5f, lg[i] * inv);
+    }
     }
     *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
 }
@@ -592,9 +661,12 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
     const int nb = cdiv(items, 256);
     if (ldv < 0)      // experiment switch of scripts/mb_msda.py: ldv = -1 reads a head-major value tensor [N][M][S][32]
         hipLaunchKernelGGL((msda_fused_kernel<12, true>), dim3(nb, N), dim3(256), 0, stream, value, 32, lv, offs_logits, ldoa, S, M, L, P, nb, out);
-    else
-    hipLaunchKernelGGL(msda_fused_kernel<12>, dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L,
-                       P, nb, out);
+    else {
+        static int share = -1;
+        if (share < 0) { const char *e = getenv("S2D_MSDA_SHARE"); share = e ? atoi(e) : 1; }
+        if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
+        else hipLaunchKernelGGL((msda_fused_kernel<12, false, false>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
+    }
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
