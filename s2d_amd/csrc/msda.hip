@@ -115,13 +115,42 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
     const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
     const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
 
-    // offsets (2 * LP floats) and logits (LP floats) of this (query, head) as 16-B loads: with scalar loads they were a
-    // quarter of the kernel's L1 accesses (36 instructions x 8 heads' lines per wave vs 9 now)
     const float *row = oa + ((long)n * S + q) * ldoa;
     const float *offp_g = row + m * (LP_ * 2);
     const float *lgp = row + M * LP_ * 2 + m * LP_;
     float offp[LP_ * 2];
     float lg[LP_];
+    float inv;
+    // SHARE: the 8 lanes of a head divide its samples (lane j: samples j and j + 8).  Each lane loads the offsets and the logit of
+    // its own samples, evaluates their exponentials and their bilinear set-up (floor, weights, border tests, first pixel), and the
+    // group reads everything back with 8-lane shuffles (ds_bpermute: the LDS crossbar, idle in this kernel).  Same formulas; the
+    // softmax denominator is added in index order in every lane, so the results are bit-identical to the all-in-one-lane form.
+    const int sj = threadIdx.x & 7;
+    float own_ox[2] = {0.f, 0.f}, own_oy[2] = {0.f, 0.f}, own_e[2] = {0.f, 0.f};
+    if constexpr (SHARE && LP_ <= 16) {
+        float own_lg[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = sj + 8 * r;
+            const bool live = i < LP_;
+            const int ic = live ? i : LP_ - 1;
+            const float2 o = *reinterpret_cast<const float2 *>(offp_g + 2 * ic);
+            own_ox[r] = o.x; own_oy[r] = o.y;
+            own_lg[r] = live ? lgp[ic] : -INFINITY;
+            mx = fmaxf(mx, own_lg[r]);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) own_e[r] = expf(own_lg[r] - mx);
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) den += __shfl(own_e[i >> 3], i & 7, 8);
+        inv = 1.f / den;
+    } else {
+    // offsets (2 * LP floats) and logits (LP floats) of this (query, head) as 16-B loads: with scalar loads they were a
+    // quarter of the kernel's L1 accesses (36 instructions x 8 heads' lines per wave vs 9 now)
     if constexpr (LP_ % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < LP_ * 2; i += 4) {
@@ -143,26 +172,10 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < LP_; ++i) mx = fmaxf(mx, lg[i]);
     float den = 0.f;
-    if constexpr (SHARE && LP_ <= 16) {
-        // the 12 exponentials as well: lane j of the head's group evaluates logits j and j + 8, the group gathers them and every
-        // lane adds them in index order (the same sum, bit for bit, as the all-in-one-lane form below)
-        const int j = threadIdx.x & 7;
-        float own[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < LP_; ++k)
-                if (k == j + 8 * r) v = lg[k];
-            own[r] = expf(v - mx);
-        }
-#pragma unroll
-        for (int i = 0; i < LP_; ++i) { lg[i] = __shfl(own[i >> 3], i & 7, 8); den += lg[i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+    for (int i = 0; i < LP_; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+    inv = 1.f / den;
     }
-    const float inv = 1.f / den;
     // HM (experiment): value stored head-major, [N][M][S][32], a pixel's 128 B of one head next to its neighbours'
     const long rowstride = HM ? D : ldv;
     f32x4 acc = f32x4(0.f);
@@ -170,18 +183,14 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
         // The bilinear set-up of a sample (floor, weights, border tests, first pixel) is the same for the 8 lanes of a head.
         // Lane j of the group prepares samples j and j + 8 and the group reads them back with 8-lane shuffles (ds_bpermute: the
         // LDS crossbar, idle in this kernel): 2 set-ups per wave instruction stream instead of LP_.  Same formulas, same values.
-        const int j = threadIdx.x & 7;
+        const int j = sj;
         float sw1[2], sw2[2], sw3[2], sw4[2], saw[2];
         int spix[2], smask[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int i = j + 8 * r;
             const int ic = i < LP_ ? i : LP_ - 1;
-            // the lane's own sample: a dynamic index into offp / lg would spill them, so select through the unrolled constants
-            float ox = 0.f, oy = 0.f, lgi = 0.f;
-#pragma unroll
-            for (int k = 0; k < LP_; ++k)
-                if (k == ic) { ox = offp[2 * k]; oy = offp[2 * k + 1]; lgi = lg[k]; }
+            const float ox = own_ox[r], oy = own_oy[r], lgi = own_e[r];
             const int l = ic / P;
             const int H = lv.H[l], W = lv.W[l];
             const float lx = ref_x + ox / (float)W, ly = ref_y + oy / (float)H;
