@@ -449,6 +449,70 @@ __global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restri
     const long qm = ((long)n * Lq + q) * M + m;
     const f32x4 tg = *reinterpret_cast<const f32x4 *>(gout + qm * D + c * 4);
     const long rowstride = (long)M * D;
+    const int LP = L * P;
+    if (LP <= 16) {
+        // as in the fused forward: lane j of the head's 8 prepares samples j and j + 8 (location / weight loads, floor, bilinear
+        // weights, border tests) and the group reads them back with 8-lane shuffles
+        const int j = c;
+        float s_lh[2], s_lw[2], s_a[2];
+        int s_pix[2], s_mask[2], s_H[2], s_W[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = j + 8 * r;
+            const int ic = i < LP ? i : LP - 1;
+            const int l = ic / P;
+            const int H = lv.H[l], W = lv.W[l];
+            const long wi = qm * LP + ic;
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * wi);
+            s_a[r] = aw[wi];
+            const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+            const bool in = i < LP && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            s_lh[r] = h_im - h0; s_lw[r] = w_im - w0;
+            s_pix[r] = h0 * W + w0; s_H[r] = H; s_W[r] = W;
+            s_mask[r] = !in ? 0 : ((h0 >= 0 && w0 >= 0) ? 1 : 0) | ((h0 >= 0 && w1 <= W - 1) ? 2 : 0) | ((h1 <= H - 1 && w0 >= 0) ? 4 : 0) |
+                                  ((h1 <= H - 1 && w1 <= W - 1) ? 8 : 0);
+        }
+        for (int i = 0; i < LP; ++i) {
+            const int r = i >> 3, src = i & 7;
+            const int l = i / P;
+            const int mask = __shfl(r ? s_mask[1] : s_mask[0], src, 8);
+            float gw = 0.f, gx = 0.f, gy = 0.f;
+            if (mask) {                                         // uniform over the head's 8 lanes
+                const int W = lv.W[l], H = lv.H[l];
+                const int pix = __shfl(r ? s_pix[1] : s_pix[0], src, 8);
+                const float lh = __shfl(r ? s_lh[1] : s_lh[0], src, 8), lw = __shfl(r ? s_lw[1] : s_lw[0], src, 8);
+                const float a = __shfl(r ? s_a[1] : s_a[0], src, 8);
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float *vb = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * 4 + (long)pix * rowstride;
+                f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+                if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(vb);
+                if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(vb + rowstride);
+                if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(vb + (long)W * rowstride);
+                if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(vb + (long)(W + 1) * rowstride);
+                const float d1 = tg[0] * v1[0] + tg[1] * v1[1] + tg[2] * v1[2] + tg[3] * v1[3];
+                const float d2 = tg[0] * v2[0] + tg[1] * v2[1] + tg[2] * v2[2] + tg[3] * v2[3];
+                const float d3 = tg[0] * v3[0] + tg[1] * v3[1] + tg[2] * v3[2] + tg[3] * v3[3];
+                const float d4 = tg[0] * v4[0] + tg[1] * v4[1] + tg[2] * v4[2] + tg[3] * v4[3];
+                gw = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;          // cuh:150-155 summed over this lane's channels
+                gx = (float)W * a * (hh * (d2 - d1) + lh * (d4 - d3));                     // d/dx: W * sum_d tg_d * a * grad_w_weight
+                gy = (float)H * a * (hw * (d3 - d1) + lw * (d4 - d2));
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {                       // the head's 8 lanes
+                gw += __shfl_xor(gw, o, 8);
+                gx += __shfl_xor(gx, o, 8);
+                gy += __shfl_xor(gy, o, 8);
+            }
+            if (c == 0) {
+                const long wi = qm * LP + i;
+                gaw[wi] = gw;
+                gloc[2 * wi] = gx;
+                gloc[2 * wi + 1] = gy;
+            }
+        }
+        return;
+    }
     for (int l = 0; l < L; ++l) {
         const int H = lv.H[l], W = lv.W[l];
         const float *vb = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * 4;
