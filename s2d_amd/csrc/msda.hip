@@ -79,6 +79,50 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
     const float *wp = aw + qm * L * P;
     const long rowstride = (long)M * D;
     VT acc = VT(0.f);
+    if (V == 4 && dv == 8 && L * P <= 16) {
+        // D = 32: a head is 8 lanes of 4 channels; they divide the per-sample set-up as in the fused kernel below (lane j: samples
+        // j and j + 8: location / weight loads, floor, bilinear weights, border tests), shared by 8-lane shuffles.  Bit-identical.
+        const int LP = L * P, j = c;
+        float s1[2], s2[2], s3[2], s4[2], sa[2];
+        int spix[2], smask[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = j + 8 * r;
+            const int ic = i < LP ? i : LP - 1;
+            const int l = ic / P;
+            const int H = lv.H[l], W = lv.W[l];
+            const float2 xy = *reinterpret_cast<const float2 *>(lp + 2 * ic);
+            sa[r] = wp[ic];
+            const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+            const bool in = i < LP && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;  // cuh:293
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+            s1[r] = hh * hw; s2[r] = hh * lw; s3[r] = lh * hw; s4[r] = lh * lw;
+            spix[r] = h0 * W + w0;
+            smask[r] = !in ? 0 : ((h0 >= 0 && w0 >= 0) ? 1 : 0) | ((h0 >= 0 && w1 <= W - 1) ? 2 : 0) | ((h1 <= H - 1 && w0 >= 0) ? 4 : 0) |
+                                 ((h1 <= H - 1 && w1 <= W - 1) ? 8 : 0);
+        }
+        for (int i = 0; i < LP; ++i) {
+            const int r = i >> 3, src = i & 7;
+            const int l = i / P;
+            const int mask = __shfl(r ? smask[1] : smask[0], src, 8);
+            if (mask == 0) continue;                           // uniform over the head's 8 lanes
+            const int W = lv.W[l];
+            const int pix = __shfl(r ? spix[1] : spix[0], src, 8);
+            const float c1 = __shfl(r ? s1[1] : s1[0], src, 8), c2 = __shfl(r ? s2[1] : s2[0], src, 8);
+            const float c3 = __shfl(r ? s3[1] : s3[0], src, 8), c4 = __shfl(r ? s4[1] : s4[0], src, 8);
+            const float a = __shfl(r ? sa[1] : sa[0], src, 8);
+            const float *p1 = value + ((long)n * S + lv.start[l] + pix) * rowstride + m * D + c * V;
+            VT v1 = VT(0.f), v2 = VT(0.f), v3 = VT(0.f), v4 = VT(0.f);
+            if (mask & 1) v1 = *reinterpret_cast<const VT *>(p1);
+            if (mask & 2) v2 = *reinterpret_cast<const VT *>(p1 + rowstride);
+            if (mask & 4) v3 = *reinterpret_cast<const VT *>(p1 + (long)W * rowstride);
+            if (mask & 8) v4 = *reinterpret_cast<const VT *>(p1 + (long)(W + 1) * rowstride);
+            acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * a;  // cuh:85-88, :299
+        }
+        *reinterpret_cast<VT *>(out + qm * D + c * V) = acc;
+        return;
+    }
     for (int l = 0; l < L; ++l) {
         const int H = lv.H[l], W = lv.W[l];
         const float *vbase = value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
