@@ -262,10 +262,18 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
                                     : value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
             const float *p1 = vbase + (long)pix * rowstride;
             f32x4 v1 = f32x4(0.f), v2 = f32x4(0.f), v3 = f32x4(0.f), v4 = f32x4(0.f);
-            if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
-            if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + rowstride);
-            if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * rowstride);
-            if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * rowstride);
+            if (__builtin_amdgcn_readfirstlane(mask) == 15 && __all(mask == 15)) {
+                // interior sample in every head of the wave (the common case): four loads, no per-corner exec juggling
+                v1 = *reinterpret_cast<const f32x4 *>(p1);
+                v2 = *reinterpret_cast<const f32x4 *>(p1 + rowstride);
+                v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * rowstride);
+                v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * rowstride);
+            } else {
+                if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
+                if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + rowstride);
+                if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * rowstride);
+                if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * rowstride);
+            }
             acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
         }
     } else {
