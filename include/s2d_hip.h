@@ -76,8 +76,12 @@ int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsig
  * F.relu / nn.Dropout in the reference's FFNs (mask2former/modeling/pixel_decoder/msdeformattn.py:121-125,
  * mask2former_video/modeling/transformer_decoder/video_mask2former_transformer_decoder.py FFNLayer).  split-fp16 mode, N, ldc, ldr,
  * ldg multiples of 4; otherwise S2D_ERR_ARG. */
-int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *res,
-                         long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream);
+int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *scale,
+                         const float *res, long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream);
+/* ... and the convolution form (dgrad of a k x k convolution whose input came out of a ReLU; scale: the per-channel FrozenBatchNorm
+ * factor of the layer that produced that input, detectron2 FrozenBatchNorm2d folded as in s2d_conv2d_nhwc_f32; gate [N,Ho,Wo,Cout]) */
+int s2d_conv2d_nhwc_gate_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                             int pad, const float *scale, const float *gate, float gate_scale, const void *w_split, hipStream_t stream);
 /* The GEMM with A pre-split as well: A_split is the s2d_split_weights_f16 image of A's M rows (an activation whose producer wrote it
  * in that layout, or a one-off conversion); B_split is required.  Same result bits as s2d_gemm_nt_f32 on the fp32 A.  Shapes the
  * wave-specialised kernel does not take (K < 224, K % 32, N % 4) return S2D_ERR_ARG. */

@@ -179,24 +179,25 @@ def _flipped_weight(w):
     return ent[0]
 
 
-def input_grad(dy, w, res=None, gate=None, gate_scale=1.0):
+def input_grad(dy, w, res=None, gate=None, gate_scale=1.0, scale=None):
     """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection).  gate [M,K]: the output of the
     ReLU (and dropout) that produced this layer's input -- dx is zeroed where gate <= 0 and multiplied by gate_scale
-    elsewhere, in the GEMM's epilogue when the kernels can (one pass over dx less than relu_scale_backward afterwards)"""
+    elsewhere, in the GEMM's epilogue when the kernels can (one pass over dx less than relu_scale_backward afterwards); scale [K]:
+    a per-channel factor applied before res and the gate (the folded BatchNorm of the layer that produced the input)"""
     N = dy.shape[1]
     Np = (N + 3) // 4 * 4                                             # the GEMM wants a contraction length % 4 == 0
     wt = _transposed_weight(w, Np)                                    # [K,Np]: once per weight version
     if Np != N:                                                       # e.g. the 2-way class head: zero-pad the contraction
         dy = torch.nn.functional.pad(dy, (0, Np - N))
     if gate is None:
-        return ops.gemm_nt(dy, wt, res=res)
+        return ops.gemm_nt(dy, wt, scale=scale, res=res)
     K = wt.shape[0]
     gate2 = gate.reshape(-1, K)
     if ops.gate_fusable(K) and gate2.stride(-1) == 1 and gate2.stride(0) % 4 == 0:
-        return ops.gemm_nt_gate(dy, wt, gate2, gate_scale, res=res)
-    dx = ops.gemm_nt(dy, wt, res=res)
-    scale = None if gate_scale == 1.0 else torch.full((K,), float(gate_scale), device=dx.device, dtype=torch.float32)
-    return relu_scale_backward(dx, gate2, scale)
+        return ops.gemm_nt_gate(dy, wt, gate2, gate_scale, res=res, scale=scale)
+    dx = ops.gemm_nt(dy, wt, scale=scale, res=res)
+    gs = None if gate_scale == 1.0 else torch.full((K,), float(gate_scale), device=dx.device, dtype=torch.float32)
+    return relu_scale_backward(dx, gate2, gs)
 
 
 def linear_backward(x, w, dy, need_dx=True, has_bias=True):
@@ -205,7 +206,7 @@ def linear_backward(x, w, dy, need_dx=True, has_bias=True):
 
 
 # --------------------------------------------------------------------------- convolutions (NHWC, weights [Cout,KH,KW,Cin])
-def conv_input_grad(dy, w, stride, pad, in_hw):
+def conv_input_grad(dy, w, stride, pad, in_hw, gate=None, scale=None):
     """dx [N,H,W,Cin] of y = conv2d_nhwc(x, w, stride, pad): a stride-1 convolution of dy (zero-dilated by `stride`) with
     the flipped, channel-transposed kernel and padding KH-1-pad -- the forward implicit-GEMM kernel again."""
     ops._chk(dy)
@@ -214,6 +215,7 @@ def conv_input_grad(dy, w, stride, pad, in_hw):
     H, W = in_hw
     wf = _flipped_weight(w)                                            # [Cin,KH,KW,Cout], once per weight version, pre-split by the dense kernels
     if KH == 1 and KW == 1 and pad == 0:
+        assert gate is None and scale is None
         g = ops.gemm_nt(dy.view(-1, Co), wf.view(Ci, Co)).view(N, Ho, Wo, Ci)
         if stride == 1:
             return g
@@ -225,7 +227,10 @@ def conv_input_grad(dy, w, stride, pad, in_hw):
         d = torch.zeros((N, Hd, Wd, Co), device=dy.device, dtype=torch.float32)
         d[:, ::stride, ::stride][:, :Ho, :Wo] = dy
         dy = d
-    return ops.conv2d_nhwc(dy, wf, stride=1, pad=KH - 1 - pad)
+    if gate is not None and ops.gate_fusable(Ci):        # gate [N,H,W,Cin]: the ReLU output that was this convolution's input
+        return ops.conv2d_nhwc_gate(dy, wf, gate, stride=1, pad=KH - 1 - pad, scale=scale)
+    dx = ops.conv2d_nhwc(dy, wf, stride=1, pad=KH - 1 - pad, scale=scale)
+    return dx if gate is None else relu_scale_backward(dx, gate)
 
 
 def conv_weight_grad(dy, x, KH, KW, stride, pad):

@@ -209,15 +209,15 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
 
 // C[M,N] = gate > 0 ? (A . B^T + res) * gate_scale : 0: a dgrad GEMM with the ReLU (and dropout) gate of the layer it
 // differentiates folded into its epilogue (backward.py input_grad)
-int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *res,
-                         long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream)
+int s2d_gemm_nt_gate_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, const float *scale,
+                         const float *res, long ldr, const float *gate, long ldg, float gate_scale, const void *B_split, hipStream_t stream)
 {
     if (!gate) return S2D_ERR_ARG;
     GemmParams p{};
     p.Bsplit = reinterpret_cast<const unsigned int *>(B_split);
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.res = res; p.ldr = res ? ldr : N; p.res_cols = N;
+    p.scale = scale; p.res = res; p.ldr = res ? ldr : N; p.res_cols = N;
     p.gate = gate; p.ldg = ldg; p.gate_scale = gate_scale;
     return launch(p, false, 1, stream);
 }
@@ -273,6 +273,25 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
     p.M = N * p.Hout * p.Wout; p.N = Cout; p.K = KH * KW * Cin;
     p.lda = 4; p.ldb = p.K; p.ldc = Cout;
     p.scale = scale; p.bias = bias; p.res = res; p.ldr = Cout; p.relu = relu; p.res_cols = Cout;
+    return launch(p, true, 1, stream);
+}
+
+// the convolution with the gate epilogue of s2d_gemm_nt_gate_f32 (dgrad of a 3x3 convolution whose input came out of a ReLU):
+// y = gate > 0 ? conv(x, w) * scale : 0
+int s2d_conv2d_nhwc_gate_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                             int pad, const float *scale, const float *gate, float gate_scale, const void *w_split, hipStream_t stream)
+{
+    if ((Cin & 3) || !gate) return S2D_ERR_ARG;
+    GemmParams p{};
+    p.Bsplit = reinterpret_cast<const unsigned int *>(w_split);
+    p.Hin = H; p.Win = W; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Hout = (H + 2 * pad - KH) / stride + 1;
+    p.Wout = (W + 2 * pad - KW) / stride + 1;
+    p.A = x; p.B = w; p.C = y;
+    p.M = N * p.Hout * p.Wout; p.N = Cout; p.K = KH * KW * Cin;
+    p.lda = 4; p.ldb = p.K; p.ldc = Cout;
+    p.scale = scale; p.ldr = Cout; p.res_cols = Cout;
+    p.gate = gate; p.ldg = Cout; p.gate_scale = gate_scale;
     return launch(p, true, 1, stream);
 }
 

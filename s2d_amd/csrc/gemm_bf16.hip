@@ -1821,7 +1821,7 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
     if (ws_ok && conv && !p.drop_thresh && (ws == 2 || (long)cdiv(p.M, 128) * cdiv(p.N, BN) >= 512)) {
         return p.Bsplit ? launch_f16_ws<true, true, false>(p, st) : launch_f16_ws<true, false, false>(p, st);
     }
-    if (p.gate && (!f16 || conv || batch != 1 || p.drop_thresh || ((p.N | p.ldc | p.ldr | p.res_cols | p.ldg) & 3))) return S2D_ERR_ARG;
+    if (p.gate && (!f16 || batch != 1 || p.drop_thresh || ((p.N | p.ldc | p.ldr | p.res_cols | p.ldg) & 3))) return S2D_ERR_ARG;
     if (p.drop_thresh) {
         // fused dropout lives in the vector epilogue of the pipelined 128x128 split-fp16 kernel (the three encoder-layer
         // GEMMs that carry it all dispatch there): 8-column mask blocks, 16-B aligned rows

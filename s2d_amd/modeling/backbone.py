@@ -64,12 +64,17 @@ class ConvBN(nn.Module):
             return y.view(N, H, W, -1)
         return ops.conv2d_nhwc(x, w, self.stride, self.pad, scale, shift, res, relu)
 
-    def backward(self, x, y, dy, relu=True, has_res=False, need_dx=True, dx_res=None):
+    def backward(self, x, y, dy, relu=True, has_res=False, need_dx=True, dx_res=None, pre_gated=False, in_scale=None):
         """gradients of y = act(conv(x) * scale + shift [+ res]): accumulates into self.weight.grad and returns
-        (dx [+ dx_res: a gradient arriving at x over another path, added in the dgrad epilogue for 1x1 kernels], dres)."""
+        (dx [+ dx_res: a gradient arriving at x over another path, added in the dgrad epilogue for 1x1 kernels], dres).
+        pre_gated: dy is already d(conv output) (the consumer's dgrad applied this layer's ReLU gate and scale in its epilogue).
+        in_scale: x is the ReLU output of a ConvBN with that folded scale; the returned dx is then d(that convolution's output),
+        gated by x > 0 and scaled in the dgrad epilogue (one pass over the activation gradient less)."""
         from .. import backward as B
         w, scale, _ = self.packed()
-        if has_res and relu:
+        if pre_gated:
+            dz, dres = dy, None
+        elif has_res and relu:
             dz, dres = B.relu_scale_backward(dy, y, scale, want_res=True)       # d(conv output), d(residual): one pass
         else:
             dres = dy if has_res else None
@@ -82,11 +87,13 @@ class ConvBN(nn.Module):
             self.weight.grad += dw
         dx = None
         if need_dx:
+            gate = x if in_scale is not None else None
             if self.k == 1 and self.stride == 1:
                 N, H, W, C = x.shape
-                dx = B.input_grad(dz.view(-1, dz.shape[-1]), w.view(w.shape[0], -1), None if dx_res is None else dx_res.view(-1, C)).view(N, H, W, C)
+                dx = B.input_grad(dz.view(-1, dz.shape[-1]), w.view(w.shape[0], -1), None if dx_res is None else dx_res.view(-1, C),
+                                  gate=gate, scale=in_scale).view(N, H, W, C)
             else:
-                dx = B.conv_input_grad(dz, w, self.stride, self.pad, x.shape[1:3])
+                dx = B.conv_input_grad(dz, w, self.stride, self.pad, x.shape[1:3], gate=gate, scale=in_scale)
                 if dx_res is not None:
                     dx = dx + dx_res
         return dx, dres
@@ -130,11 +137,13 @@ class BottleneckBlock(nn.Module):
     def backward(self, saved, dout):
         """d(block input) from d(block output); parameter gradients accumulate in the ConvBN weights"""
         _, x, sc, y1, y2, out = saved
-        d2, dsc = self.conv3.backward(y2, out, dout, relu=True, has_res=True)
-        d1, _ = self.conv2.backward(y1, y2, d2)
+        # conv3's and conv2's dgrads gate by the ReLU output they differentiate through and apply that layer's folded scale in
+        # their epilogues: d2 / d1 arrive as d(conv2 output) / d(conv1 output)
+        d2, dsc = self.conv3.backward(y2, out, dout, relu=True, has_res=True, in_scale=self.conv2.packed()[1])
+        d1, _ = self.conv2.backward(y1, y2, d2, pre_gated=True, in_scale=self.conv1.packed()[1])
         if self.shortcut is not None:
             dsc, _ = self.shortcut.backward(x, sc, dsc, relu=False)
-        dx, _ = self.conv1.backward(x, y1, d1, dx_res=dsc)             # both paths meet at x
+        dx, _ = self.conv1.backward(x, y1, d1, pre_gated=True, dx_res=dsc)             # both paths meet at x
         return dx
 
 

@@ -143,16 +143,17 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     return out
 
 
-def gemm_nt_gate(A, B, gate, gate_scale=1.0, res=None):
-    """(A @ B^T + res) * gate_scale where gate > 0, else 0 (gate [M, N]): a dgrad GEMM with the ReLU / dropout gate folded in"""
-    for t in (A, B, gate, res):
+def gemm_nt_gate(A, B, gate, gate_scale=1.0, res=None, scale=None):
+    """(A @ B^T * scale + res) * gate_scale where gate > 0, else 0 (gate [M, N], scale [N]): a dgrad GEMM with the ReLU / dropout
+    gate (and the folded-BatchNorm factor) of the layer it differentiates in its epilogue"""
+    for t in (A, B, gate, res, scale):
         _chk(t)
     M, K = A.shape
     N = B.shape[0]
     assert gate.shape == (M, N) and gate.stride(-1) == 1 and (res is None or res.shape == (M, N))
     out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (3 if res is not None else 2)))):
-        lib().call("s2d_gemm_nt_gate_f32", A, B, out, M, N, K, K, K, N, res, N, gate, gate.stride(0), float(gate_scale),
+        lib().call("s2d_gemm_nt_gate_f32", A, B, out, M, N, K, K, K, N, scale, res, N, gate, gate.stride(0), float(gate_scale),
                    _static_split(B, N, K, K), _stream())
     return out
 
@@ -291,6 +292,22 @@ def normalize_pad(frames_u8, div=32, mean=PIXEL_MEAN, std=PIXEL_STD):
     lib().call("s2d_normalize_pad_nhwc4_f32", frames_u8, F_, H0, W0, Hp, Wp, _np.ascontiguousarray(mean, _np.float32),
                _np.ascontiguousarray(std, _np.float32), out, _stream())
     return out
+
+
+def conv2d_nhwc_gate(x, w, gate, stride=1, pad=0, scale=None, gate_scale=1.0):
+    """conv2d_nhwc(x, w) * scale where gate > 0, else 0 (gate: a tensor of the output's shape): dgrad with the gate epilogue"""
+    for t in (x, w, scale, gate):
+        _chk(t)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    assert tuple(gate.shape) == (N, Ho, Wo, Cout)
+    y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    ws = _static_split(w, Cout, KH * KW * Cin, KH * KW * Cin)
+    with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * Cin, ("conv", KH, N * Ho * Wo, Cout, KH * KW * Cin, 4.0 * (x.numel() + w.numel() + 2 * N * Ho * Wo * Cout))):
+        lib().call("s2d_conv2d_nhwc_gate_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, gate, float(gate_scale), ws, _stream())
+    return y
 
 
 def maxpool3x3s2(x):
