@@ -126,6 +126,27 @@ int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host,
                                  int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
                                  long workspace_bytes, hipStream_t stream);
 
+/* The drop-in op with the reference's own argument kinds: spatial shapes [L,2] and level starts [L] as int64 DEVICE tensors,
+ * read inside the kernels exactly as ms_deformable_im2col_gpu_kernel does (ops/src/cuda/ms_deform_attn_cuda.cu:60-75 passes
+ * spatial_shapes.data<int64_t>() / level_start_index.data<int64_t>() straight to the kernels; the module builds both tensors
+ * fresh on every forward, msdeformattn.py:82-83).  No host copy, no cache, no synchronisation: a one-thread kernel turns the two
+ * tensors into the geometry record at the head of `workspace` and every kernel of the call reads it from there.
+ * Shapes that fail the host form's argument checks (H, W <= 0; a level past S) cannot be reported through the return code
+ * without a sync: the call then produces zeros and sets the record's error flag, which s2d_msda_dev_status reads back.
+ * workspace: s2d_msda_dev_forward_workspace_bytes() / s2d_msda_dev_backward_workspace_bytes(...) bytes of device memory, 16-B
+ * aligned, private to the call until it has finished.  The backward is the atomic-free sorted form. */
+long s2d_msda_dev_forward_workspace_bytes(void);
+int s2d_msda_forward_dev_f32(const float *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const float *loc,
+                             const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P, float *out, void *workspace,
+                             hipStream_t stream);
+long s2d_msda_dev_backward_workspace_bytes(int N, int S, int M, int L, int Lq, int P);
+int s2d_msda_backward_dev_f32(const float *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const float *loc,
+                              const float *attn_w, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                              float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace, long workspace_bytes,
+                              hipStream_t stream);
+/* *err_host = the error flag of the *_dev call that used `workspace` (0 = shapes accepted).  Synchronises `stream`. */
+int s2d_msda_dev_status(const void *workspace, int *err_host, hipStream_t stream);
+
 /* Fused pixel-decoder form: also does softmax over L*P and loc = ref + off/(W_l,H_l)
  * (ops/modules/ms_deform_attn.py:101-109) with the query's own pixel centre as reference point
  * (msdeformattn.py:141-153).  offs_logits [N,S,ldoa]: per query M*L*P*2 raw offsets then M*L*P raw logits.
@@ -418,6 +439,14 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
                                 int H, int W, int Nmax, int num_points, float oversample_ratio, float importance_ratio,
                                 int drop_empty, float world_size, void *workspace, float w_mask, float w_dice, float *grad_rows,
                                 unsigned int *bit_scratch, hipStream_t stream);
+
+/* Test hook for the RNG (timing) mode of s2d_point_loss_f32: the oversampled points of rows [0, nrows) for `seed` on an
+ * (hm, wm) logit map, uv [nrows][n_over][2], and every row's strata bounds [nrows][9], from the same device functions the loss
+ * kernels use.  The generator is this library's own (the reference draws torch.rand, point_features.py:89-93; parity tests inject
+ * those draws): i.i.d. uniform points generated per map part -- an exact multinomial split over the parts' v bands, then uniform
+ * inside each band -- which is the law of i.i.d. uniform points.  scratch_list: nrows + 1 ints.  row0 must be 0. */
+int s2d_point_loss_rng_points(uint64_t seed, int hm, int wm, int row0, int nrows, int n_over, float *uv, int *bounds, int *scratch_list,
+                              hipStream_t stream);
 
 /* d(w_ce * loss_labels)/d(class_logits) for one layer (same arguments as s2d_class_loss_f32) -> [B][Q][2] */
 int s2d_class_loss_backward_f32(const float *class_logits, const int *idx_q, const int *n_match, int B, int Q, int maxm,

@@ -1,12 +1,18 @@
 """`MultiScaleDeformableAttention`: the two functions of the reference's pybind module (ops/src/vision.cpp:18-21,
 ops/src/ms_deform_attn.h:25-66), on libs2d_hip.so (s2d_msda_forward_f32 / s2d_msda_backward_f32, csrc/msda.hip).
 
+The two index tensors stay on the GPU, as in the reference: `spatial_shapes` [L,2] and `level_start_index` [L] (int64, built
+fresh by the caller on every forward, msdeformattn.py:82-83) go to s2d_msda_forward_dev_f32 / s2d_msda_backward_dev_f32, whose
+kernels read them from device memory (ms_deform_attn_cuda.cu:60-75).  Nothing is copied to the host or cached, so a sequence of
+clips with different pyramids (MIN_SIZE_TRAIN (360, 480) + random crop) cannot meet stale shapes.
+
 Conventions kept from the CUDA extension (ops/src/cuda/ms_deform_attn_cuda.cu:33-57, :93-116): every tensor must be
 contiguous and on the GPU, else RuntimeError; `batch % min(batch, im2col_step) == 0`; outputs are freshly allocated; work is
 enqueued on the current stream.  Differences: float32 only (the path's dtype; the extension also instantiates float64), and
 `im2col_step` only takes part in that check -- the kernels need no batch chunking.  There is no torch fallback: a missing
 library raises at import."""
-import numpy as np
+import os
+
 import torch
 
 from .. import ops
@@ -14,21 +20,7 @@ from .._lib import lib
 
 lib()          # fail at import, loudly, when libs2d_hip.so is absent (ms_deform_attn_func.py:21-29 does the same for the extension)
 
-_HOST = {}
-
-
-def _host_i64(t):
-    """spatial shapes / level starts are tiny int64 DEVICE tensors in the reference's call; the kernels take them as launch
-    parameters.  One device-to-host copy per distinct tensor (keyed by storage, version and shape), not one per call."""
-    if not isinstance(t, torch.Tensor):
-        return np.ascontiguousarray(t, dtype=np.int64)
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-    h = _HOST.get(key)
-    if h is None:
-        if len(_HOST) > 256:
-            _HOST.clear()
-        h = _HOST[key] = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.int64)
-    return h
+_DEBUG = bool(int(os.environ.get("S2D_MSDA_CHECK", "0")))    # 1: read the device-side shape check back after every call (syncs)
 
 
 def _check(name, t, dtype=torch.float32):
@@ -42,23 +34,31 @@ def _check(name, t, dtype=torch.float32):
 
 def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     _check("value", value); _check("sampling_loc", sampling_loc); _check("attn_weight", attn_weight)
-    _check("spatial_shapes", spatial_shapes, None); _check("level_start_index", level_start_index, None)
+    _check("spatial_shapes", spatial_shapes, torch.int64); _check("level_start_index", level_start_index, torch.int64)
     batch = value.shape[0]
     step = min(batch, int(im2col_step))
     if step <= 0 or batch % step != 0:
         raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
-    return _host_i64(spatial_shapes), _host_i64(level_start_index)
+
+
+def _status(ws):
+    if _DEBUG and ops.msda_dev_status(ws):
+        raise RuntimeError("spatial_shapes / level_start_index do not describe `value` (H, W > 0 and every level inside S)")
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """value [N,S,M,D], spatial_shapes [L,2] (H,W), level_start_index [L], sampling_loc [N,Lq,M,L,P,2], attn_weight
     [N,Lq,M,L,P] -> [N,Lq,M*D]"""
-    sh, ls = _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
-    return ops.msda_forward(value, sh, ls, sampling_loc, attn_weight)
+    _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    out, ws = ops.msda_forward_dev(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, want_ws=True)
+    _status(ws)
+    return out
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]"""
-    sh, ls = _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     _check("grad_output", grad_output)
-    return list(ops.msda_backward(value, sh, ls, sampling_loc, attn_weight, grad_output))
+    gv, gl, gw, ws = ops.msda_backward_dev(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, want_ws=True)
+    _status(ws)
+    return [gv, gl, gw]

@@ -174,6 +174,11 @@ struct LossParams {
     int chunks;
     float *xbuf;              // [xcap][n_over + n_rand]: sampled logits of the first xcap active rows (sampled ONCE)
     int xcap;
+    int *pbound;              // [rows][PB_STRIDE]: RNG mode, first oversampled-point index of every map part of the row (strata)
+};
+constexpr int PB_STRIDE = 9;  // LOSS_CHUNKS + 1
+struct VRange {
+    float v0, dv;             // v band of one map part: v = v0 + dv * r, r uniform in [0, 1)
 };
 
 // one block per layer: active flag + rank (= position among the kept rows of this layer, reference row order
@@ -228,6 +233,56 @@ __global__ void row_list_kernel(LossParams p)
         if (p.active[rowid]) p.list[base + p.rank[rowid]] = (int)rowid;
     }
     if (layer == p.NL - 1 && threadIdx.x == 0) p.lcount[p.NL] = base + p.lcount[layer];
+}
+
+// RNG mode: the multinomial split of every active row's n_over oversampled points over its map parts (see part_vrange below);
+// one thread per row, sequential conditional binomials
+__device__ int binomial_inv(int N, double p, double U);
+__global__ __launch_bounds__(256) void row_strata_kernel(LossParams p, int nparts, int rpp)
+{
+    const int n = p.lcount[p.NL];
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+    for (int li = wave; li < n; li += nwaves) {                  // one wave per row: binomial_inv is a wave-wide call
+        const long rowid = p.list[li];
+        int *pb = p.pbound + rowid * PB_STRIDE;
+        int rem = p.n_over, at = 0;
+        double mass = 1.0;
+        for (int j = 0; j < nparts; ++j) {
+            if ((threadIdx.x & 63) == 0) pb[j] = at;
+            const double ya = j == 0 ? -0.5 : (double)(j * rpp), yb = j == nparts - 1 ? (double)p.hm - 0.5 : (double)((j + 1) * rpp);
+            const double pj = (yb - ya) / (double)p.hm;
+            int nj = rem;
+            if (j < nparts - 1) {
+                const uint64_t h = mix64(p.seed ^ mix64(((uint64_t)rowid * 16u + (uint64_t)j) * 0xD1342543DE82EF95ull + 0x5851F42D4C957F2Dull));
+                const double U = (double)(h >> 11) * (1.0 / 9007199254740992.0);      // 53-bit uniform in [0, 1)
+                const double pc = pj / mass;
+                nj = binomial_inv(rem, pc < 1.0 ? pc : 1.0, U);
+            }
+            at += nj; rem -= nj; mass -= pj;
+        }
+        if ((threadIdx.x & 63) == 0) pb[nparts] = at;
+    }
+}
+
+__global__ void rng_points_prep_kernel(int *list, int nrows)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nrows) list[i] = i;
+    else if (i == nrows) list[i] = nrows;
+}
+__device__ __forceinline__ void over_point_rng(uint32_t key0, int i, const int *pb, const float *v0, const float *dv, int nparts, float &u, float &v);
+__device__ __forceinline__ VRange part_vrange(int j, int nparts, int rpp, int hm);
+__global__ void rng_points_kernel(LossParams p, int nparts, int rpp, float *__restrict__ uv)
+{
+    const int row = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float s_v0[PB_STRIDE], s_dv[PB_STRIDE];
+    if ((int)threadIdx.x < nparts) { const VRange vr = part_vrange(threadIdx.x, nparts, rpp, p.hm); s_v0[threadIdx.x] = vr.v0; s_dv[threadIdx.x] = vr.dv; }
+    __syncthreads();
+    if (i >= p.n_over) return;
+    float u, v;
+    over_point_rng(rand_key(p.seed, (uint64_t)row * 2), i, p.pbound + (long)row * PB_STRIDE, s_v0, s_dv, nparts, u, v);
+    uv[((long)row * p.n_over + i) * 2] = u;
+    uv[((long)row * p.n_over + i) * 2 + 1] = v;
 }
 
 // gather matched query maps: mq[row][pix] = ml[layer][b][t][pix][q]; 64 pixels per block through LDS
@@ -289,6 +344,87 @@ __host__ __device__ inline PartGeom part_geom(int hm, int wm)
     if (g.rows_per_part > hm) g.rows_per_part = hm;
     g.nparts = (hm + g.rows_per_part - 1) / g.rows_per_part;
     return g;
+}
+
+// ---- RNG mode: the oversampled points of a row are generated per map part (stratified, same law) ---------------------------
+// point_features.py:89-93 draws the 3P oversampled points of a row i.i.d. uniform on [0,1]^2.  A map part owns the points whose
+// upper tap row falls in it, i.e. a band of v.  N i.i.d. uniform points are, in law, exactly: a multinomial split (n_0, ..,
+// n_{k-1}) of N over the bands with the bands' areas as probabilities, then n_j points i.i.d. uniform inside band j.  The device
+// generator (timing mode; parity mode injects the reference's recorded draws and keeps the test-every-point path) draws that
+// multinomial once per row -- exact binomial inversion in double, row_strata_kernel -- and point i of the row then lies in the
+// band j with bound[j] <= i < bound[j+1]: v = v0_j + dv_j * r_i, u = r'_i with 24-bit uniforms r, r' as before.  A (row, part)
+// work item walks only its own index range: no per-point ownership test, no compaction (they were ~40 % of hist_kernel<0>'s
+// 1.4 G vector instructions per criterion pass: every point was tested by both parts).
+__host__ __device__ inline void part_yrange(int j, int nparts, int rpp, int hm, double &ya, double &yb)
+{
+    ya = j == 0 ? -0.5 : (double)(j * rpp);                       // y = v * hm - 0.5 in [-0.5, hm - 0.5); part j owns floor(y) in [j * rpp, (j+1) * rpp)
+    yb = j == nparts - 1 ? (double)hm - 0.5 : (double)((j + 1) * rpp);
+}
+__device__ __forceinline__ VRange part_vrange(int j, int nparts, int rpp, int hm)
+{
+    double ya, yb;
+    part_yrange(j, nparts, rpp, hm, ya, yb);
+    VRange r;
+    r.v0 = (float)((ya + 0.5) / (double)hm);
+    r.dv = (float)((yb - ya) / (double)hm);
+    return r;
+}
+// (u, v) of oversampled point i of a row in RNG mode.  pb: the row's strata bounds, v0 / dv: the bands of the map's parts (LDS
+// tables filled once per workgroup: part_vrange divides in double)
+__device__ __forceinline__ void over_point_rng(uint32_t key0, int i, const int *pb, const float *v0, const float *dv, int nparts, float &u, float &v)
+{
+    int j = 0;
+    while (j + 1 < nparts && i >= pb[j + 1]) ++j;
+    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+    v = fmaf((float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f), dv[j], v0[j]);
+}
+
+// Binomial(N, p) by inversion of U, one WAVE per draw (all 64 lanes call with the same arguments and receive the same value).
+// Any fixed enumeration order of the support gives an exact sampler; the order here is: the mode m, then alternately the next
+// 32 values above and the next 32 below.  A step evaluates one such 64-value block: lane's pmf = frontier pmf x prefix product
+// of the two-sided recurrence ratios (6 shuffle steps), block prefix sum (6 more), first lane where U goes negative.  ~1.6 sigma /
+// 32 = ~17 steps for N = 480 000, p = 1/2 (the one-thread walk took 0.3 ms per criterion pass, all in double divisions).
+__device__ int binomial_inv(int N, double p, double U)
+{
+    if (N <= 0 || p <= 0.0) return 0;
+    if (p >= 1.0) return N;
+    const int lane = threadIdx.x & 63, l = lane & 31;
+    const bool isup = lane < 32;
+    const double q = 1.0 - p, r = p / q, ri = q / p;
+    int m = (int)floor((double)(N + 1) * p);
+    if (m > N) m = N;
+    const double f0 = exp(lgamma((double)N + 1.0) - lgamma((double)m + 1.0) - lgamma((double)(N - m) + 1.0) + (double)m * log(p) +
+                          (double)(N - m) * log1p(-p));
+    U -= f0;
+    if (U < 0.0) return m;
+    double fu = f0, fd = f0;                                     // pmf at the two frontiers
+    int up = m, dn = m;
+    for (int it = 0; it < (1 << 15); ++it) {
+        const int k = isup ? up + 1 + l : dn - 1 - l;
+        const bool valid = isup ? k <= N : k >= 0;
+        // pmf(k) = pmf(k-1) (N-k+1)/k p/q  going up;  pmf(k) = pmf(k+1) (k+1)/(N-k) q/p  going down
+        double pr = !valid ? 0.0 : isup ? (double)(N - k + 1) / (double)k * r : (double)(k + 1) / (double)(N - k) * ri;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const double t = __shfl_up(pr, o, 32);
+            if (l >= o) pr *= t;
+        }
+        const double f = (isup ? fu : fd) * pr;
+        double cs = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(cs, o, 64);
+            if (lane >= o) cs += t;
+        }
+        const unsigned long long hit = __ballot(U - cs < 0.0);
+        if (hit) return __shfl(k, __ffsll((long long)hit) - 1, 64);
+        U -= __shfl(cs, 63, 64);
+        fu = __shfl(f, 31, 64);
+        fd = __shfl(f, 63, 64);
+        up += 32; dn -= 32;
+        if ((up >= N && dn <= 0) || (fu < 1e-300 && fd < 1e-300)) break;   // U fell into the rounding residue of the total mass
+    }
+    return m;
 }
 
 // persistent item loop: item = (active row index li, part)
@@ -358,34 +494,49 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
         // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
-        // A part owns about half of the row's points (those whose upper tap row falls in it).  Every point is tested with
-        // one hash (its v coordinate); the owned ones are compacted per wave (ballot + LDS queue) and only full waves of
-        // owned points pay for the second hash, the four LDS taps and the histogram update.
-        {
+        auto tally = [&](int i, float xv) {
+            const unsigned int key = __float_as_uint(fabsf(xv));
+            if (LEVEL == 0 && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
+            if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
+            else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
+            else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+        };
+        if (!cr) {
+            // RNG mode: this item's points are the index range [pb[part], pb[part + 1]) of the row (stratified generation above): every
+            // lane does full work, nothing is tested or compacted.  floor(y) is clamped into the part: v = v0 + dv * r may round onto
+            // the band's upper edge (one point in ~1e7), which then extrapolates the part's last row pair by an ulp.
+            const int *pb = p.pbound + rowid * PB_STRIDE;
+            const int lo = pb[part], hi = pb[part + 1];
+            const VRange vr = part_vrange(part, g.nparts, g.rows_per_part, p.hm);
+            const int y0max = min(yhi, p.hm) - 1;
+#pragma unroll 2
+            for (int i = lo + (int)threadIdx.x; i < hi; i += LTHREADS) {
+                const float u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+                const float v = fmaf((float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f), vr.dv, vr.v0);
+                const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
+                const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
+                const int y0 = min(max((int)floorf(y), ylo), y0max);
+                tally(i, sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0));
+            }
+        } else {
+        // Parity mode (injected coordinates, any order): a part owns about half of the row's points (those whose upper tap row
+        // falls in it).  Every point is tested; the owned ones are compacted per wave (ballot + LDS queue) and only full waves of
+        // owned points pay for the four LDS taps and the histogram update.
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
             int *qi = hq_idx[wv];
             float *qy = hq_y[wv];
             int qn = 0;                                   // wave-uniform
             auto heavy = [&](int i, float y) {
-                float u;
-                if (cr) u = cr[2 * i];
-                else u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
+                const float u = cr[2 * i];
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
-                const float xv = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), (int)floorf(y));
-                const unsigned int key = __float_as_uint(fabsf(xv));
-                if (LEVEL == 0 && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
-                if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
-                else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
-                else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
+                tally(i, sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), (int)floorf(y)));
             };
             const int iters = (p.n_over + LTHREADS - 1) / LTHREADS;      // uniform: the ballots need whole waves
             for (int k = 0; k < iters; ++k) {
                 const int i = k * LTHREADS + threadIdx.x;
                 const bool live = i < p.n_over;
                 const int ic = live ? i : p.n_over - 1;
-                float v;
-                if (cr) v = cr[2 * ic + 1];
-                else v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                const float v = cr[2 * ic + 1];
                 const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const int y0 = (int)floorf(y);
                 const bool own = live && y0 >= ylo && y0 < yhi;
@@ -562,8 +713,13 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
             const bool over = pass == 0;
             const float *cr = coord_rows(p, rowid, over);
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
-            const int cnt = over ? p.n_over : p.n_rand;
-            for (int i0 = threadIdx.x; i0 < cnt; i0 += 4 * LTHREADS) {
+            // RNG mode, oversampled points: this part's own index range of the row (stratified generation), else every point + test
+            const bool strat = over && !cr;
+            const int *pb = p.pbound + rowid * PB_STRIDE;
+            const int ibeg = strat ? pb[part] : 0, cnt = strat ? pb[part + 1] : (over ? p.n_over : p.n_rand);
+            const VRange vr = part_vrange(part, g.nparts, g.rows_per_part, p.hm);
+            const int y0max = min(yhi, p.hm) - 1;
+            for (int i0 = ibeg + (int)threadIdx.x; i0 < cnt; i0 += 4 * LTHREADS) {
                 float xv[4], uu[4], vv[4];
                 bool own[4];
 #pragma unroll
@@ -575,10 +731,12 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
                     else {
                         u = (float)(hash32(key0 + 2u * (uint32_t)ic) >> 8) * (1.0f / 16777216.0f);
                         v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                        if (strat) v = fmaf(v, vr.dv, vr.v0);
                     }
                     const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                     const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
-                    const int y0 = (int)floorf(y);
+                    int y0 = (int)floorf(y);
+                    if (strat) y0 = min(max(y0, ylo), y0max);
                     own[j] = i < cnt && y0 >= ylo && y0 < yhi;
                     xv[j] = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
                     uu[j] = u; vv[j] = v;
@@ -638,6 +796,10 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     const int rows_l = p.B * p.maxm * p.T;
     const int nrows = min(p.lcount[p.NL], p.xcap);
     const long HW = (long)p.H * p.W;
+    __shared__ float s_v0[PB_STRIDE], s_dv[PB_STRIDE];           // RNG mode: v bands of the map parts, strata bounds of the row
+    __shared__ int s_pb[PB_STRIDE];
+    const PartGeom sg_ = part_geom(p.hm, p.wm);
+    if ((int)threadIdx.x < sg_.nparts) { const VRange vr = part_vrange(threadIdx.x, sg_.nparts, sg_.rows_per_part, p.hm); s_v0[threadIdx.x] = vr.v0; s_dv[threadIdx.x] = vr.dv; }
     unsigned int *tb = BWD ? ba.bit_scratch + (long)blockIdx.x * (HW / 32) : tbits;
     float *gh = reinterpret_cast<float *>(tbits);          // BWD: the dynamic LDS is the gradient tile [hh][wm]
     const int hh = (p.hm + 1) / 2;
@@ -650,6 +812,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         const int n = p.idx_t[(long)prob * p.maxm + s];
         const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * HW;
         __syncthreads();
+        if (threadIdx.x < PB_STRIDE) s_pb[threadIdx.x] = p.pbound[rowid * PB_STRIDE + threadIdx.x];   // visible after the barrier below
         // bit-pack the plane: each thread turns 32 bytes (two 16-B loads) into one word
 #pragma unroll 4
         for (long wd = threadIdx.x; wd < HW / 32; wd += LTHREADS) {
@@ -733,6 +896,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             auto heavy = [&](int i, float xv) {           // one selected point: regenerate (u,v), sample the target bits
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
+                else if (over) over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
                 else {
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
@@ -811,10 +975,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             auto tie_point = [&](int i) {
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
-                else {
-                    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
-                    v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
-                }
+                else over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
                 point(xb[i], sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
@@ -1009,7 +1170,7 @@ long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int h
     int n_over, n_unc, n_rand;
     point_counts(num_points, oversample_ratio, importance_ratio, n_over, n_unc, n_rand);
     const long xrows = rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS;
-    return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16) + 4L * (NL + 1) + 1024 +
+    return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16 + PB_STRIDE * 4) + 4L * (NL + 1) + 1024 +
            xrows * (long)(n_over + n_rand + 8) * 4;
 }
 
@@ -1039,6 +1200,7 @@ static int loss_setup(LossParams &p, long &rows, const float *mask_logits, const
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.hist = (unsigned int *)w; w += rows * 2048 * 4;
     p.part = (float *)w; w += rows * LOSS_CHUNKS * 16;
+    p.pbound = (int *)w; w += rows * PB_STRIDE * 4;
     p.mq = (float *)w; w += rows * (long)hm * wm * 4;
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.xbuf = (float *)w;
@@ -1086,6 +1248,8 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     hipLaunchKernelGGL(row_list_kernel, dim3(NL), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)hm * wm, 64), T, NL * B), dim3(256), 0, stream, p);
     const PartGeom pg = part_geom(hm, wm);
+    static_assert(PB_STRIDE == LOSS_CHUNKS + 1, "one bound per part + the end");
+    if (!coords_over) hipLaunchKernelGGL(row_strata_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, p, pg.nparts, pg.rows_per_part);
     const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 1) * wm;
     const size_t lds_hist = lds_map + sizeof(float) * 2048;
     if (int e = loss_attrs()) return e;
@@ -1131,6 +1295,26 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
     // backward walk beyond xcap rows; a dedicated scratch keeps it simple
     hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), lds, stream, p,
                        LossBwdArgs{grad_rows, w_mask, w_dice, bit_scratch});
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+/* Test hook: the oversampled points the RNG mode of s2d_point_loss_f32 generates for rows [row0, row0 + nrows) under `seed` on an
+ * (hm, wm) logit map -- uv [nrows][n_over][2] and the strata bounds [nrows][9] -- produced by the same device functions the loss
+ * kernels call (row_strata_kernel, over_point_rng), so the generator's law can be checked without going through a loss value. */
+int s2d_point_loss_rng_points(uint64_t seed, int hm, int wm, int row0, int nrows, int n_over, float *uv, int *bounds, int *scratch_list,
+                              hipStream_t stream)
+{
+    const PartGeom pg = part_geom(hm, wm);
+    if ((wm & 3) || pg.rows_per_part < 1 || pg.nparts > LOSS_CHUNKS || nrows <= 0 || row0 != 0) return S2D_ERR_ARG;
+    LossParams p = {};
+    p.seed = seed; p.hm = hm; p.wm = wm; p.n_over = n_over; p.NL = 0;
+    p.list = scratch_list;            // [nrows + 1]: identity list, then lcount[NL = 0] = nrows
+    p.lcount = scratch_list + nrows;
+    p.pbound = bounds;
+    hipLaunchKernelGGL(rng_points_prep_kernel, dim3(cdiv(nrows + 1, 256)), dim3(256), 0, stream, scratch_list, nrows);
+    hipLaunchKernelGGL(row_strata_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, stream, p, pg.nparts, pg.rows_per_part);
+    hipLaunchKernelGGL(rng_points_kernel, dim3(cdiv(n_over, 256), nrows), dim3(256), 0, stream, p, pg.nparts, pg.rows_per_part, uv);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

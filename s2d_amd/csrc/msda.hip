@@ -24,6 +24,36 @@ struct Levels {
     long start[MAX_L];
 };
 
+// Bilinear-cell index space of the atomic-free backward (see below).
+struct Cells {
+    int base[MAX_L];      // first cell index of level l inside one (frame, head)
+    int tot;              // cells per (frame, head): sum over levels of (H + 1) * (W + 1)  (floor(y) in [-1, H-1], floor(x) in [-1, W-1])
+};
+
+// Geometry of one call.  The host-shape entry points pass it by value (kernarg memory); the *_dev entry points, whose spatial
+// shapes / level starts are DEVICE tensors as in the reference op (ms_deform_attn_cuda.cu:60-75), have msda_geom_kernel write it
+// into the caller's workspace once per call and every kernel reads it through a pointer (uniform scalar loads either way).
+struct Geom {
+    Levels lv;
+    Cells cl;
+    unsigned int kmax;    // N * M * cl.tot: the key of a sample outside every map
+    int err;              // dev form: the shapes failed fill_levels' checks; kernels then write zeros and touch nothing else
+};
+struct GeomVal {
+    Geom g;
+    __device__ __forceinline__ const Levels &levels() const { return g.lv; }
+    __device__ __forceinline__ const Cells &cells() const { return g.cl; }
+    __device__ __forceinline__ unsigned int kmax() const { return g.kmax; }
+    __device__ __forceinline__ bool bad() const { return false; }
+};
+struct GeomPtr {
+    const Geom *g;
+    __device__ __forceinline__ const Levels &levels() const { return g->lv; }
+    __device__ __forceinline__ const Cells &cells() const { return g->cl; }
+    __device__ __forceinline__ unsigned int kmax() const { return g->kmax; }
+    __device__ __forceinline__ bool bad() const { return g->err != 0; }
+};
+
 __device__ __forceinline__ int xcd_band(int bid, int nblk)
 {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, within = bid / 8;
@@ -59,13 +89,14 @@ __device__ __forceinline__ void sample_accum(typename Vec<V>::T &acc, const floa
 }
 
 // Drop-in form: sampling locations and attention weights are inputs (the reference op's signature).
-template <int V>
-__global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__ value, Levels lv,
+template <int V, class G>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__ value, G geo,
                                                        const float *__restrict__ loc, const float *__restrict__ aw,
                                                        int S, int M, int D, int L, int Lq, int P, int blk_per_n,
                                                        float *__restrict__ out)
 {
     typedef typename Vec<V>::T VT;
+    const Levels &lv = geo.levels();      // a bad dev geometry has H = W = 0 on every level: every sample is outside, the output 0
     const int n = blockIdx.y;
     const int bid = xcd_band(blockIdx.x, blk_per_n);
     const int dv = D / V;
@@ -296,13 +327,15 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict
 // per (query, head); grad_sampling_loc / grad_attn_weight are reduced across the 32 channel lanes with
 // DPP/shuffle butterflies (no LDS, no serial loop); grad_value uses float atomics, issued as 128-B row
 // segments (two per wave-instruction).
-__global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__ value, Levels lv,
+template <class G>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__ value, G geo,
                                                        const float *__restrict__ loc, const float *__restrict__ aw,
                                                        const float *__restrict__ gout, int S, int M, int L, int Lq,
                                                        int P, float *__restrict__ gvalue, float *__restrict__ gloc,
                                                        float *__restrict__ gaw)
 {
     constexpr int D = 32;
+    const Levels &lv = geo.levels();
     const int n = blockIdx.y;
     const long item = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = item < (long)Lq * M * D;
@@ -375,15 +408,14 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
 //      as a corner, and adds weight * grad_out rows in that fixed order -- one 128-B store per row, no atomics, bitwise
 //      reproducible.
 // grad_loc / grad_attn stay query-owned (msda_bwd_loc_kernel): no scatter there.
-struct Cells {
-    int base[MAX_L];      // first cell index of level l inside one (frame, head)
-    int tot;              // cells per (frame, head): sum over levels of (H + 1) * (W + 1)  (floor(y) in [-1, H-1], floor(x) in [-1, W-1])
-};
-
-__global__ __launch_bounds__(256) void msda_cell_key_kernel(const float *__restrict__ loc, Levels lv, Cells cl, unsigned int per_n, int M, int L,
-                                                            int P, unsigned int kmax, unsigned int *__restrict__ keys,
+template <class G>
+__global__ __launch_bounds__(256) void msda_cell_key_kernel(const float *__restrict__ loc, G geo, unsigned int per_n, int M, int L,
+                                                            int P, unsigned int *__restrict__ keys,
                                                             unsigned int *__restrict__ vals)
 {
+    const Levels &lv = geo.levels();
+    const Cells &cl = geo.cells();
+    const unsigned int kmax = geo.kmax();
     const unsigned int n = blockIdx.y;
     const unsigned int w = blockIdx.x * 256u + threadIdx.x;          // sample index inside frame n: (q * M + m) * LP + lp
     if (w >= per_n) return;
@@ -411,11 +443,13 @@ struct __attribute__((aligned(16))) SampleRec {
     unsigned int row;
 };
 
+template <class G>
 __global__ __launch_bounds__(256) void msda_cell_bounds_kernel(const unsigned int *__restrict__ skeys, const unsigned int *__restrict__ svals,
                                                                const float *__restrict__ loc, const float *__restrict__ aw, unsigned int nsamp,
-                                                               unsigned int kmax, unsigned int LP, int *__restrict__ off,
+                                                               G geo, unsigned int LP, int *__restrict__ off,
                                                                SampleRec *__restrict__ rec)
 {
+    const unsigned int kmax = geo.kmax();
     const unsigned int i = blockIdx.x * 256u + threadIdx.x;
     if (i > nsamp) return;
     const long kprev = i ? (long)skeys[i - 1] : -1L;
@@ -433,15 +467,22 @@ __global__ __launch_bounds__(256) void msda_cell_bounds_kernel(const unsigned in
 // one grad_value row (n, s, m, 32 channels) per 8-lane group (16 B per lane): a wave = the 8 heads of one pixel.  A batch of
 // 8 records is prepared by the group's lanes, then its 8 grad_out rows are loaded together (all in flight) and added in record
 // order; slots beyond the segment carry weight 0 (row 0), which leaves the sum's bits unchanged.
+template <class G>
 __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__restrict__ gout, const SampleRec *__restrict__ rec,
-                                                             const int *__restrict__ off, Levels lv, Cells cl, long ntgt, int S, int M, int L,
+                                                             const int *__restrict__ off, G geo, long ntgt, int S, int M, int L,
                                                              float *__restrict__ gvalue)
 {
     constexpr int D = 32;
+    const Levels &lv = geo.levels();
+    const Cells &cl = geo.cells();
     const long item = (long)blockIdx.x * 256 + threadIdx.x;
     const long t = item >> 3;                                       // target row (n, s, m)
     const int c = (int)(item & 7);
     if (t >= ntgt) return;                                          // whole 8-lane groups leave together
+    if (geo.bad()) {                                                // dev form with rejected shapes: zeros, no indexing by them
+        *reinterpret_cast<f32x4 *>(gvalue + t * D + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int m = (int)(t % M);
     const int s = (int)((t / M) % S);
     const long n = t / M / S;
@@ -486,11 +527,13 @@ __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__rest
 // grad_sampling_loc / grad_attn_weight of the backward, query-owned (cuh:119-163 without the grad_value scatter): the forward's
 // geometry -- a wave = one query's 8 heads x 8 lanes x 4 channels, every corner a 16-B load -- with the channel sums reduced
 // over the 8 lanes of a head
-__global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restrict__ value, Levels lv, const float *__restrict__ loc,
+template <class G>
+__global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restrict__ value, G geo, const float *__restrict__ loc,
                                                            const float *__restrict__ aw, const float *__restrict__ gout, int S, int M, int L,
                                                            int Lq, int P, int blk_per_n, float *__restrict__ gloc, float *__restrict__ gaw)
 {
     constexpr int D = 32;
+    const Levels &lv = geo.levels();
     const int n = blockIdx.y;
     const int bid = xcd_band(blockIdx.x, blk_per_n);
     const long item = (long)bid * 256 + threadIdx.x;
@@ -711,9 +754,252 @@ __global__ __launch_bounds__(256) void msda_fused_chain_kernel(const float *__re
     for (int i = 0; i < LP_; i += 4) *reinterpret_cast<f32x4 *>(ol + i) = f32x4{a[i], a[i + 1], a[i + 2], a[i + 3]};
 }
 
+// ---- drop-in op, host-shape and device-shape forms share these launchers ---------------------------------------------------
+static int fill_cells(Cells &cl, const Levels &lv, int L)
+{
+    long tot = 0;
+    for (int l = 0; l < L; ++l) {
+        cl.base[l] = (int)tot;
+        tot += (long)(lv.H[l] + 1) * (lv.W[l] + 1);
+    }
+    if (tot >= (1L << 31)) return S2D_ERR_ARG;
+    cl.tot = (int)tot;
+    return S2D_OK;
+}
+
+static int host_geom(GeomVal &gv, const int64_t *shapes, const int64_t *lsi, int L, long S, int N, int M)
+{
+    if (int e = fill_levels(gv.g.lv, shapes, lsi, L, S)) return e;
+    if (int e = fill_cells(gv.g.cl, gv.g.lv, L)) return e;
+    const long ncell = (long)N * M * gv.g.cl.tot;
+    if (ncell >= (1L << 32) - 1) return S2D_ERR_ARG;
+    gv.g.kmax = (unsigned int)ncell;
+    gv.g.err = 0;
+    return S2D_OK;
+}
+
+template <class G>
+static int launch_forward(const G &geo, const float *value, const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq,
+                          int P, float *out, hipStream_t stream)
+{
+    if ((D & 3) == 0) {
+        const long items = (long)Lq * M * (D / 4);
+        const int nb = cdiv(items, 256);
+        hipLaunchKernelGGL((msda_fwd_kernel<4, G>), dim3(nb, N), dim3(256), 0, stream, value, geo, loc, attn_w, S, M, D, L, Lq, P, nb, out);
+    } else {
+        const long items = (long)Lq * M * D;
+        const int nb = cdiv(items, 256);
+        hipLaunchKernelGGL((msda_fwd_kernel<1, G>), dim3(nb, N), dim3(256), 0, stream, value, geo, loc, attn_w, S, M, D, L, Lq, P, nb, out);
+    }
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+template <class G>
+static int launch_backward_atomic(const G &geo, const float *value, const float *loc, const float *attn_w, const float *grad_out, int N,
+                                  int S, int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
+                                  hipStream_t stream)
+{
+    if (s2d_zero_async(grad_value, sizeof(float) * (size_t)N * S * M * 32, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(grad_loc, sizeof(float) * (size_t)N * Lq * M * L * P * 2, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    if (s2d_zero_async(grad_attn_w, sizeof(float) * (size_t)N * Lq * M * L * P, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    const long items = (long)Lq * M * 32;
+    hipLaunchKernelGGL((msda_bwd_kernel<G>), dim3(cdiv(items, 256), N), dim3(256), 0, stream, value, geo, loc, attn_w, grad_out, S, M, L, Lq,
+                       P, grad_value, grad_loc, grad_attn_w);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+// Workspace of the atomic-free backward: four u32 arrays of one entry per sample (sort ping-pong), the 16-B sample records, the
+// cell offsets, and rocPRIM's temporaries.
+static size_t sorted_ws_layout(long nsamp, long ncell, size_t *o_keys, size_t *o_vals, size_t *o_rec, size_t *o_off, size_t *o_tmp, size_t *tmp_bytes)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    o_keys[0] = o; o = al(o + (size_t)nsamp * 4);
+    o_keys[1] = o; o = al(o + (size_t)nsamp * 4);
+    o_vals[0] = o; o = al(o + (size_t)nsamp * 4);
+    o_vals[1] = o; o = al(o + (size_t)nsamp * 4);
+    *o_rec = o; o = al(o + (size_t)nsamp * 16);
+    *o_off = o; o = al(o + (size_t)(ncell + 2) * 4);
+    *o_tmp = o;
+    *tmp_bytes = (size_t)(4 * nsamp + (1L << 20)) * 4;
+    return o + *tmp_bytes;
+}
+
+// ncell_cap: the number of cells the workspace was sized for (exact for host shapes, the bound of s2d_msda_dev_* for device shapes;
+// it only fixes the offsets array's extent and the number of key bits sorted)
+template <class G>
+static int launch_backward_sorted(const G &geo, long ncell_cap, const float *value, const float *loc, const float *attn_w,
+                                  const float *grad_out, int N, int S, int M, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                                  float *grad_attn_w, char *ws, long workspace_bytes, hipStream_t stream)
+{
+    const long nsamp = (long)N * Lq * M * L * P;
+    if (nsamp >= (1L << 31) || ncell_cap >= (1L << 32) - 1) return S2D_ERR_ARG;      // segment offsets are int
+    size_t ok[2], ov[2], orec, oo, ot, tb;
+    if ((long)sorted_ws_layout(nsamp, ncell_cap, ok, ov, &orec, &oo, &ot, &tb) > workspace_bytes) return S2D_ERR_ARG;
+    unsigned int *keys_in = (unsigned int *)(ws + ok[0]), *keys_out = (unsigned int *)(ws + ok[1]);
+    unsigned int *vals_in = (unsigned int *)(ws + ov[0]), *vals_out = (unsigned int *)(ws + ov[1]);
+    SampleRec *rec = (SampleRec *)(ws + orec);
+    int *off = (int *)(ws + oo);
+    const unsigned int per_n = (unsigned int)((long)Lq * M * L * P);
+    hipLaunchKernelGGL((msda_cell_key_kernel<G>), dim3(cdiv(per_n, 256), N), dim3(256), 0, stream, loc, geo, per_n, M, L, P, keys_in, vals_in);
+    S2D_CHECK_LAUNCH();
+    int bits = 1;
+    while ((1L << bits) <= ncell_cap) ++bits;                // keys 0 .. kmax (kmax = "outside every map"), kmax <= ncell_cap
+    if (int e = s2d_radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, (size_t)nsamp, bits, ws + ot, tb, stream)) return e;
+    hipLaunchKernelGGL((msda_cell_bounds_kernel<G>), dim3(cdiv(nsamp + 1, 256)), dim3(256), 0, stream, keys_out, vals_out, loc, attn_w,
+                       (unsigned int)nsamp, geo, (unsigned int)(L * P), off, rec);
+    S2D_CHECK_LAUNCH();
+    const long ntgt = (long)N * S * M;
+    hipLaunchKernelGGL((msda_bwd_value_kernel<G>), dim3(cdiv(ntgt * 8, 256)), dim3(256), 0, stream, grad_out, rec, off, geo, ntgt, S, M, L,
+                       grad_value);
+    S2D_CHECK_LAUNCH();
+    const int nb = cdiv((long)Lq * M * 8, 256);
+    hipLaunchKernelGGL((msda_bwd_loc_kernel<G>), dim3(nb, N), dim3(256), 0, stream, value, geo, loc, attn_w, grad_out, S, M, L, Lq, P, nb,
+                       grad_loc, grad_attn_w);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+// Device-shape form: one thread turns the reference op's two int64 DEVICE tensors into the Geom the kernels read (the checks of
+// fill_levels, on the device: a geometry that fails them becomes "every level empty" + err = 1, so no kernel indexes by it).
+__global__ void msda_geom_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, int L, long S, int N, int M,
+                                 Geom *__restrict__ g)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    bool ok = true;
+    long tot = 0, cells = 0;
+    for (int l = 0; l < MAX_L; ++l) {
+        long H = 0, W = 0, st = 0;
+        if (l < L) {
+            H = shapes[2 * l]; W = shapes[2 * l + 1]; st = lsi ? lsi[l] : tot;
+            ok = ok && H > 0 && W > 0 && H < (1L << 30) && W < (1L << 30) && st >= 0 && H * W <= S && st + H * W <= S;
+        }
+        g->lv.H[l] = (int)H; g->lv.W[l] = (int)W; g->lv.start[l] = st;
+        g->cl.base[l] = (int)cells;
+        if (l < L) { tot += H * W; cells += (H + 1) * (W + 1); }
+    }
+    ok = ok && (long)N * M * cells < (1L << 32) - 1;
+    if (!ok) {
+        cells = 0;
+        for (int l = 0; l < MAX_L; ++l) {
+            g->lv.H[l] = 0; g->lv.W[l] = 0; g->lv.start[l] = 0;
+            g->cl.base[l] = (int)cells;
+            if (l < L) cells += 1;
+        }
+    }
+    g->cl.tot = (int)cells;
+    g->kmax = (unsigned int)((long)N * M * cells);
+    g->err = ok ? 0 : 1;
+}
+
+static long dev_ncell_cap(int N, int S, int M, int L)
+{
+    // sum over levels of (H + 1)(W + 1) with sum H W <= S and H, W >= 1:  (H + 1)(W + 1) <= 2 H W + 2
+    return (long)N * M * (2L * S + 2L * L);
+}
+
+static int launch_geom(const int64_t *shapes_dev, const int64_t *lsi_dev, int L, long S, int N, int M, void *workspace, hipStream_t stream)
+{
+    if (L < 1 || L > MAX_L || !shapes_dev || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(64), 0, stream, shapes_dev, lsi_dev, L, S, N, M, reinterpret_cast<Geom *>(workspace));
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+constexpr long GEOM_BYTES = 256;
+static_assert(sizeof(Geom) <= GEOM_BYTES, "Geom outgrew its workspace slot");
+
 }  // namespace
 
 extern "C" {
+
+int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                         const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P,
+                         float *out, hipStream_t stream)
+{
+    GeomVal gv;
+    if (int e = host_geom(gv, shapes_host, level_start_host, L, S, N > 0 ? N : 1, M)) return e;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    return launch_forward(gv, value, loc, attn_w, N, S, M, D, L, Lq, P, out, stream);
+}
+
+int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                          const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                          int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
+                          hipStream_t stream)
+{
+    GeomVal gv;
+    if (int e = host_geom(gv, shapes_host, level_start_host, L, S, N > 0 ? N : 1, M)) return e;
+    if (D != 32) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    return launch_backward_atomic(gv, value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w, stream);
+}
+
+long s2d_msda_backward_workspace_bytes(const int64_t *shapes_host, int N, int M, int L, int Lq, int P)
+{
+    long tot = 0;
+    for (int l = 0; l < L; ++l) tot += (shapes_host[2 * l] + 1) * (shapes_host[2 * l + 1] + 1);
+    size_t a[2], b[2], c, d, e, tb;
+    return (long)sorted_ws_layout((long)N * Lq * M * L * P, (long)N * M * tot, a, b, &c, &d, &e, &tb);
+}
+
+int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
+                                 const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                                 int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
+                                 long workspace_bytes, hipStream_t stream)
+{
+    GeomVal gv;
+    if (int e = host_geom(gv, shapes_host, level_start_host, L, S, N > 0 ? N : 1, M)) return e;
+    if (D != 32 || !workspace) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    return launch_backward_sorted(gv, (long)gv.g.kmax, value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w,
+                                  reinterpret_cast<char *>(workspace), workspace_bytes, stream);
+}
+
+long s2d_msda_dev_forward_workspace_bytes(void) { return GEOM_BYTES; }
+
+int s2d_msda_forward_dev_f32(const float *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const float *loc,
+                             const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P, float *out, void *workspace,
+                             hipStream_t stream)
+{
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    if (int e = launch_geom(shapes_dev, level_start_dev, L, S, N, M, workspace, stream)) return e;
+    GeomPtr gp{reinterpret_cast<const Geom *>(workspace)};
+    return launch_forward(gp, value, loc, attn_w, N, S, M, D, L, Lq, P, out, stream);
+}
+
+long s2d_msda_dev_backward_workspace_bytes(int N, int S, int M, int L, int Lq, int P)
+{
+    size_t a[2], b[2], c, d, e, tb;
+    return GEOM_BYTES + (long)sorted_ws_layout((long)N * Lq * M * L * P, dev_ncell_cap(N, S, M, L), a, b, &c, &d, &e, &tb);
+}
+
+int s2d_msda_backward_dev_f32(const float *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const float *loc,
+                              const float *attn_w, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                              float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace, long workspace_bytes,
+                              hipStream_t stream)
+{
+    if (D != 32 || !workspace || workspace_bytes < GEOM_BYTES) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    if (int e = launch_geom(shapes_dev, level_start_dev, L, S, N, M, workspace, stream)) return e;
+    GeomPtr gp{reinterpret_cast<const Geom *>(workspace)};
+    return launch_backward_sorted(gp, dev_ncell_cap(N, S, M, L), value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc,
+                                  grad_attn_w, reinterpret_cast<char *>(workspace) + GEOM_BYTES, workspace_bytes - GEOM_BYTES, stream);
+}
+
+int s2d_msda_dev_status(const void *workspace, int *err_host, hipStream_t stream)
+{
+    // reads back Geom.err of a finished (or, after this call's own stream sync, the last enqueued) *_dev call: the one place the
+    // device-shape form can report rejected shapes.  Synchronises `stream`: a debugging aid, not part of the data path.
+    if (!workspace || !err_host) return S2D_ERR_ARG;
+    Geom g;
+    if (hipMemcpyAsync(&g, workspace, sizeof(Geom), hipMemcpyDeviceToHost, stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    if (hipStreamSynchronize(stream) != hipSuccess) return S2D_ERR_LAUNCH;
+    *err_host = g.err;
+    return S2D_OK;
+}
 
 int s2d_msda_fused_prep_f32(const float *offs_logits, int ldoa, const int64_t *shapes_host, int N, int S, int M, int L, int P, float *loc,
                             float *attn, hipStream_t stream)
@@ -753,28 +1039,6 @@ int s2d_msda_fused_chain_f32(const float *attn, const float *grad_loc, const flo
     return S2D_OK;
 }
 
-int s2d_msda_forward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
-                         const float *loc, const float *attn_w, int N, int S, int M, int D, int L, int Lq, int P,
-                         float *out, hipStream_t stream)
-{
-    Levels lv;
-    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
-    if (N <= 0 || Lq <= 0) return S2D_OK;
-    if ((D & 3) == 0) {
-        const long items = (long)Lq * M * (D / 4);
-        const int nb = cdiv(items, 256);
-        hipLaunchKernelGGL(msda_fwd_kernel<4>, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, S, M, D, L,
-                           Lq, P, nb, out);
-    } else {
-        const long items = (long)Lq * M * D;
-        const int nb = cdiv(items, 256);
-        hipLaunchKernelGGL(msda_fwd_kernel<1>, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, S, M, D, L,
-                           Lq, P, nb, out);
-    }
-    S2D_CHECK_LAUNCH();
-    return S2D_OK;
-}
-
 int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
                                int N, int S, int M, int D, int L, int P, float *out, hipStream_t stream)
 {
@@ -792,102 +1056,6 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
         if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
         else hipLaunchKernelGGL((msda_fused_kernel<12, false, false>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
     }
-    S2D_CHECK_LAUNCH();
-    return S2D_OK;
-}
-
-int s2d_msda_backward_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
-                          const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
-                          int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w,
-                          hipStream_t stream)
-{
-    Levels lv;
-    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
-    if (D != 32) return S2D_ERR_ARG;
-    if (N <= 0 || Lq <= 0) return S2D_OK;
-    if (s2d_zero_async(grad_value, sizeof(float) * (size_t)N * S * M * D, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    if (s2d_zero_async(grad_loc, sizeof(float) * (size_t)N * Lq * M * L * P * 2, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    if (s2d_zero_async(grad_attn_w, sizeof(float) * (size_t)N * Lq * M * L * P, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    const long items = (long)Lq * M * D;
-    hipLaunchKernelGGL(msda_bwd_kernel, dim3(cdiv(items, 256), N), dim3(256), 0, stream, value, lv, loc, attn_w,
-                       grad_out, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w);
-    S2D_CHECK_LAUNCH();
-    return S2D_OK;
-}
-
-
-// Workspace of the atomic-free backward: four u32 arrays of one entry per sample (sort ping-pong), the 16-B sample records, the
-// cell offsets, and rocPRIM's temporaries.
-static size_t sorted_ws_layout(long nsamp, long ncell, size_t *o_keys, size_t *o_vals, size_t *o_rec, size_t *o_off, size_t *o_tmp, size_t *tmp_bytes)
-{
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o = 0;
-    o_keys[0] = o; o = al(o + (size_t)nsamp * 4);
-    o_keys[1] = o; o = al(o + (size_t)nsamp * 4);
-    o_vals[0] = o; o = al(o + (size_t)nsamp * 4);
-    o_vals[1] = o; o = al(o + (size_t)nsamp * 4);
-    *o_rec = o; o = al(o + (size_t)nsamp * 16);
-    *o_off = o; o = al(o + (size_t)(ncell + 2) * 4);
-    *o_tmp = o;
-    *tmp_bytes = (size_t)(4 * nsamp + (1L << 20)) * 4;
-    return o + *tmp_bytes;
-}
-
-static int fill_cells(Cells &cl, const Levels &lv, int L)
-{
-    long tot = 0;
-    for (int l = 0; l < L; ++l) {
-        cl.base[l] = (int)tot;
-        tot += (long)(lv.H[l] + 1) * (lv.W[l] + 1);
-    }
-    if (tot >= (1L << 31)) return S2D_ERR_ARG;
-    cl.tot = (int)tot;
-    return S2D_OK;
-}
-
-long s2d_msda_backward_workspace_bytes(const int64_t *shapes_host, int N, int M, int L, int Lq, int P)
-{
-    long tot = 0;
-    for (int l = 0; l < L; ++l) tot += (shapes_host[2 * l] + 1) * (shapes_host[2 * l + 1] + 1);
-    size_t a[2], b[2], c, d, e, tb;
-    return (long)sorted_ws_layout((long)N * Lq * M * L * P, (long)N * M * tot, a, b, &c, &d, &e, &tb);
-}
-
-int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host, const int64_t *level_start_host,
-                                 const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
-                                 int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
-                                 long workspace_bytes, hipStream_t stream)
-{
-    Levels lv;
-    if (int e = fill_levels(lv, shapes_host, level_start_host, L, S)) return e;
-    Cells cl;
-    if (int e = fill_cells(cl, lv, L)) return e;
-    if (D != 32 || !workspace) return S2D_ERR_ARG;
-    if (N <= 0 || Lq <= 0) return S2D_OK;
-    const long nsamp = (long)N * Lq * M * L * P, ncell = (long)N * M * cl.tot;
-    if (nsamp >= (1L << 32) - 1 || ncell >= (1L << 32) - 1) return S2D_ERR_ARG;
-    size_t ok[2], ov[2], orec, oo, ot, tb;
-    if ((long)sorted_ws_layout(nsamp, ncell, ok, ov, &orec, &oo, &ot, &tb) > workspace_bytes) return S2D_ERR_ARG;
-    char *ws = reinterpret_cast<char *>(workspace);
-    unsigned int *keys_in = (unsigned int *)(ws + ok[0]), *keys_out = (unsigned int *)(ws + ok[1]);
-    unsigned int *vals_in = (unsigned int *)(ws + ov[0]), *vals_out = (unsigned int *)(ws + ov[1]);
-    SampleRec *rec = (SampleRec *)(ws + orec);
-    int *off = (int *)(ws + oo);
-    const unsigned int per_n = (unsigned int)((long)Lq * M * L * P);
-    hipLaunchKernelGGL(msda_cell_key_kernel, dim3(cdiv(per_n, 256), N), dim3(256), 0, stream, loc, lv, cl, per_n, M, L, P, (unsigned int)ncell,
-                       keys_in, vals_in);
-    S2D_CHECK_LAUNCH();
-    int bits = 1;
-    while ((1L << bits) <= ncell) ++bits;                    // keys 0 .. ncell (ncell = "outside every map")
-    if (int e = s2d_radix_sort_pairs_u32(keys_in, keys_out, vals_in, vals_out, (size_t)nsamp, bits, ws + ot, tb, stream)) return e;
-    hipLaunchKernelGGL(msda_cell_bounds_kernel, dim3(cdiv(nsamp + 1, 256)), dim3(256), 0, stream, keys_out, vals_out, loc, attn_w,
-                       (unsigned int)nsamp, (unsigned int)ncell, (unsigned int)(L * P), off, rec);
-    const long ntgt = (long)N * S * M;
-    hipLaunchKernelGGL(msda_bwd_value_kernel, dim3(cdiv(ntgt * 8, 256)), dim3(256), 0, stream, grad_out, rec, off, lv, cl, ntgt, S, M, L,
-                       grad_value);
-    const int nb = cdiv((long)Lq * M * 8, 256);
-    hipLaunchKernelGGL(msda_bwd_loc_kernel, dim3(nb, N), dim3(256), 0, stream, value, lv, loc, attn_w, grad_out, S, M, L, Lq, P, nb, grad_loc,
-                       grad_attn_w);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

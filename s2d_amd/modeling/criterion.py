@@ -80,6 +80,7 @@ class VideoHungarianMatcher(nn.Module):
         C = ops.matcher_cost(out.mask_logits, out.class_logits, targets.masks, targets.count, out.dims, self.num_points,
                              (self.cost_class, self.cost_mask, self.cost_dice), coords=coords, seed=self.seed)
         B = out.mask_logits.shape[1]
+        self.last_cost = C                      # [NL*B, Q, Nmax] (tests compare it with the oracle's cost matrices)
         return ops.lsap(C, targets.count, B)
 
     @torch.no_grad()

@@ -277,6 +277,8 @@ class KDVideoMaskFormer(nn.Module):
         wd = self.criterion.weight_dict                                   # :319-325
         out = {k: v * wd[k] for k, v in losses.items() if k in wd}
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
+        if getattr(self, "keep_kd_targets", False):       # tests: the pseudo-target planes the KD matcher saw (1.5 GB at c4 otherwise freed)
+            self.last["kd_targets"] = tgt
         return out
 
     @torch.no_grad()

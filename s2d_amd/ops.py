@@ -118,6 +118,17 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
         N = B.shape[0]
         if out is None:
             out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        if _MODE != "f16x3" or N % 8 or out.shape[-1] % 8 or (res is not None and res.shape[-1] % 8):
+            # the mask epilogue exists in the split-fp16 kernels only (s2d_gemm_nt_dropout_f32 rejects the other dense modes and
+            # rows that are not whole 8-column mask blocks): same mask, same order of operations, as separate passes
+            assert N % 8 == 0 and out.shape[-1] == N, "dropout masks are generated per 8-column block"
+            gemm_nt(A, B, bias=bias, out=out)
+            dropout_apply(out, p, seed, site, row0, out=out)      # (`dropout` is this function's argument)
+            if res is not None:
+                out.add_(res)
+            if relu:
+                out.relu_()
+            return out
         with _Timed(2.0 * M * N * K, ("gemm", 1, M, N, K, 4.0 * (M * K + N * K + M * N * (2 if res is not None else 1)))):
             lib().call("s2d_gemm_nt_dropout_f32", A, B, out, M, N, K, K, K, out.shape[-1], bias, res, res.shape[-1] if res is not None else N,
                        int(relu), _static_split(B, N, K, K), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), int(row0), _stream())
@@ -187,13 +198,16 @@ def gemm_nt_presplit(A_split, M, K, B, bias=None, res=None, relu=False, out=None
     return out
 
 
-def dropout(x, p, seed, site, row0=0, out=None):
+def dropout_apply(x, p, seed, site, row0=0, out=None):
     """x [M, N] * mask / (1 - p): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
     _chk(x)
     M, N = x.shape
     y = torch.empty_like(x) if out is None else out
     lib().call("s2d_dropout_f32", x, M, N, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), int(row0), y, _stream())
     return y
+
+
+dropout = dropout_apply
 
 
 _DROP_CALLS = [0]
@@ -261,6 +275,48 @@ def msda_backward(value, shapes, level_start, loc, attn_w, grad_out, atomics=Fal
     ws = torch.empty((nb,), device=value.device, dtype=torch.uint8)
     lib().call("s2d_msda_backward_sorted_f32", value, sh, ls, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw, ws, nb, _stream())
     return gv, gl, gw
+
+
+def _chk_i64_dev(t, shape):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and tuple(t.shape) == shape):
+        raise RuntimeError(f"s2d op needs a contiguous int64 CUDA tensor of shape {shape}")
+
+
+def msda_forward_dev(value, shapes_dev, level_start_dev, loc, attn_w, want_ws=False):
+    """msda_forward with the reference op's argument kinds: spatial shapes [L,2] and level starts [L] are int64 CUDA tensors read
+    on the device (ms_deform_attn_cuda.cu:60-75); nothing is copied to the host, cached or synchronised."""
+    for t in (value, loc, attn_w):
+        _chk(t)
+    N, S, M, D = value.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    _chk_i64_dev(shapes_dev, (L, 2)); _chk_i64_dev(level_start_dev, (L,))
+    ws = torch.empty((lib().call("s2d_msda_dev_forward_workspace_bytes"),), device=value.device, dtype=torch.uint8)
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+    lib().call("s2d_msda_forward_dev_f32", value, shapes_dev, level_start_dev, loc, attn_w, N, S, M, D, L, Lq, P, out, ws, _stream())
+    return (out, ws) if want_ws else out
+
+
+def msda_backward_dev(value, shapes_dev, level_start_dev, loc, attn_w, grad_out, want_ws=False):
+    """gradients of msda_forward_dev (atomic-free sorted form), shapes read on the device"""
+    for t in (value, loc, attn_w, grad_out):
+        _chk(t)
+    N, S, M, D = value.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    _chk_i64_dev(shapes_dev, (L, 2)); _chk_i64_dev(level_start_dev, (L,))
+    gv, gl, gw = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn_w)
+    nb = lib().call("s2d_msda_dev_backward_workspace_bytes", N, S, M, L, Lq, P)
+    ws = torch.empty((nb,), device=value.device, dtype=torch.uint8)
+    lib().call("s2d_msda_backward_dev_f32", value, shapes_dev, level_start_dev, loc, attn_w, grad_out, N, S, M, D, L, Lq, P, gv, gl, gw,
+               ws, nb, _stream())
+    return (gv, gl, gw, ws) if want_ws else (gv, gl, gw)
+
+
+def msda_dev_status(ws):
+    """error flag of the *_dev call that used workspace `ws` (0: shapes accepted).  Synchronises the current stream."""
+    import ctypes
+    err = ctypes.c_int(0)
+    lib().call("s2d_msda_dev_status", ws, ctypes.addressof(err), _stream())
+    return err.value
 
 
 def msda_fused_forward(value, shapes, offs_logits, M=8, P=4):

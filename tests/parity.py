@@ -85,6 +85,13 @@ def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4)
     ps = seeded_load(model.student, seed)
     pt = seeded_load(model.teacher, seed + 1)
     model = model.to(dev)
+    return run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL, weights, kd_want)
+
+
+def run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL=10, weights=(2.0, 5.0, 5.0), kd_want=None):
+    """one seeded batch of clips of size (H0, W0) through an EXISTING model instance (parameter sets ps / pt as seeded_load
+    returned them) and through the oracle: a sequence of calls with different sizes exercises everything the instance caches"""
+    dev = next(model.parameters()).device
     frames, tg = make_case(seed, B, T, H0, W0, Q, P, ns)
     images = ops.normalize_pad(torch.from_numpy(frames).to(dev))
     if kd_want is not None:
@@ -107,10 +114,12 @@ def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4)
     cg = make_coords(seed + 10, NL, B, Q, Ngt, T, P)
     ck = make_coords(seed + 11, NL, B, Q, Q, T, P)
     to = lambda c: {k: torch.from_numpy(v).to(dev) for k, v in c.items()}
+    model.keep_kd_targets = True
     losses = model.forward_losses(images, TargetSet.from_list(gts, device=dev), to(cg), to(ck), kd_nmax=Q)
     torch.cuda.synchronize()
     st = model.last["student"]
-    hip = dict(losses={k: float(v) for k, v in losses.items()}, kd_counts=model.last["kd_count"].cpu().tolist(),
+    kdc = model.last["kd_count"].cpu().tolist()
+    hip = dict(coords_kd=ck, kd_targets=[model.last["kd_targets"][b, :kdc[b]].cpu().numpy() for b in range(B)], matcher_weights=weights,losses={k: float(v) for k, v in losses.items()}, kd_counts=model.last["kd_count"].cpu().tolist(),
                s_logits=st.class_logits.cpu().numpy(), s_masks=torch.stack([st.pred_masks(i) for i in range(NL)]).cpu().numpy(),
                model=model, inputs=(images, gts, to(cg)), idx_gt=None)
     ref = None

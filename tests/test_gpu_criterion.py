@@ -298,3 +298,46 @@ def test_point_loss_vs_oracle_both_paths(oracle, P, H, W):
     ref_dice = (1 - (2 * (sg * labels).sum(-1) + 1) / (sg.sum(-1) + labels.sum(-1) + 1)).sum() / num_masks
     np.testing.assert_allclose(L[0, 0], ref_mask, rtol=1e-3)
     np.testing.assert_allclose(L[0, 1], ref_dice, rtol=1e-3)
+
+
+def test_rng_mode_points_are_iid_uniform_in_law():
+    """Timing mode generates the 3P oversampled points of a row per map part (an exact multinomial split over the parts' v bands,
+    then uniform inside each band) instead of testing every point against every part.  That is the law of i.i.d. uniform points
+    (point_features.py:89-93 draws torch.rand): checked on the points the device functions emit (s2d_point_loss_rng_points) --
+    every point inside its own part's band, band counts within binomial fluctuations and varying from row to row, u and v
+    uniform (Kolmogorov-Smirnov), u and v uncorrelated, rows independent -- at the shipped geometry (184 x 320 map -> 2 parts) and a
+    1080p-shaped one (272 x 480 -> 5 parts)."""
+    from scipy import stats
+    from s2d_amd._lib import lib
+    for hm, wm, n_over, nrows in ((184, 320, 480000, 6), (272, 480, 60000, 8), (16, 24, 768, 4)):
+        uv = torch.empty((nrows, n_over, 2), device="cuda", dtype=torch.float32)
+        bounds = torch.zeros((nrows, 9), device="cuda", dtype=torch.int32)
+        scratch = torch.empty((nrows + 1,), device="cuda", dtype=torch.int32)
+        lib().call("s2d_point_loss_rng_points", 0xC0FFEE + hm, hm, wm, 0, nrows, n_over, uv, bounds, scratch, torch.cuda.current_stream().cuda_stream)
+        uvh, bh = uv.cpu().numpy().astype(np.float64), bounds.cpu().numpy()
+        rpp = min(120 * 1024 // (wm * 4) - 1, hm)
+        nparts = -(-hm // rpp)
+        assert (uvh >= 0).all() and (uvh < 1).all()
+        counts = []
+        for r in range(nrows):
+            b = bh[r, :nparts + 1]
+            assert b[0] == 0 and b[-1] == n_over and (np.diff(b) >= 0).all()
+            y0 = np.floor(uvh[r, :, 1] * hm - 0.5).astype(int)
+            for j in range(nparts):
+                ya = -1 if j == 0 else j * rpp
+                yb = min((j + 1) * rpp, hm)
+                own = y0[b[j]:b[j + 1]]
+                # a point generated for part j lies in part j's band (floor(y) one past the band's top edge only by float rounding)
+                assert (own >= ya).all() and (own <= yb).all() and (own == yb).mean() < 1e-4
+                pj = ((hm - 0.5 if j == nparts - 1 else (j + 1) * rpp) - (-0.5 if j == 0 else j * rpp)) / hm
+                n = b[j + 1] - b[j]
+                assert abs(n - n_over * pj) < 5.5 * np.sqrt(n_over * pj * (1 - pj)) + 1, (hm, r, j, n, n_over * pj)
+            counts.append(tuple(np.diff(b)))
+            if n_over >= 10000:
+                for c in (0, 1):
+                    assert stats.kstest(uvh[r, :, c], "uniform").pvalue > 1e-4, (hm, r, c)
+                assert abs(np.corrcoef(uvh[r, :, 0], uvh[r, :, 1])[0, 1]) < 5 / np.sqrt(n_over)
+        if n_over >= 10000:
+            assert len(set(counts)) > 1                       # the split is random per row, not the expectation rounded
+            assert abs(np.corrcoef(np.sort(uvh[0, :, 0]), np.sort(uvh[1, :, 0]))[0, 1]) > 0.999   # same law ...
+            assert not np.array_equal(uvh[0], uvh[1])         # ... different draws

@@ -134,6 +134,108 @@ def test_msda_compat_module_and_function(oracle):
         MSDA.ms_deform_attn_forward(torch.cat([v, v[:1]]), shapes, lsi, torch.cat([loc, loc[:1]]), torch.cat([w, w[:1]]), 2)   # 3 % 2
 
 
+def test_msda_compat_fresh_shape_tensors_of_different_pyramids(oracle):
+    """The reference builds `spatial_shapes` / `level_start_index` fresh on every forward (msdeformattn.py:82-83:
+    torch.as_tensor(list) -> cat / cumsum) and frees them afterwards, so the caching allocator hands the same small blocks to the
+    next clip's tensors.  With MIN_SIZE_TRAIN (360, 480) + random crops consecutive clips have different pyramids of possibly the
+    SAME total length S -- a host-side cache keyed by (pointer, version, shape) then serves the previous clip's shapes.  The shapes
+    are read on the device now: a sequence of pyramids (equal S, transposed, smaller, larger) through the reference's calling
+    pattern, forward and backward, each against the oracle."""
+    import s2d_amd.compat as compat
+    compat.install()
+    import MultiScaleDeformableAttention as MSDA
+    from s2d_amd.compat.ms_deform_attn_func import MSDeformAttnFunction
+    dev = torch.device(DEV)
+    N, M, D, P, Lq = 2, 8, 32, 4, 50
+    pyramids = [[(6, 8), (12, 16), (24, 32)], [(8, 6), (16, 12), (32, 24)],      # same S, transposed levels
+                [(4, 12), (8, 24), (16, 48)],                                    # same S again, other aspect ratio
+                [(3, 5), (6, 10), (12, 20)], [(12, 23), (23, 45), (45, 90)], [(6, 8), (12, 16), (24, 32)]]
+    seen_ptrs = set()
+    for it, shapes_l in enumerate(pyramids):
+        g = torch.Generator().manual_seed(100 + it)
+        L = len(shapes_l)
+        S = sum(h * w for h, w in shapes_l)
+        value = torch.randn((N, S, M, D), generator=g)
+        loc = torch.rand((N, Lq, M, L, P, 2), generator=g) * 1.2 - 0.1         # some samples outside the maps
+        w = torch.softmax(torch.randn((N, Lq, M, L * P), generator=g), -1).view(N, Lq, M, L, P)
+        go = torch.randn((N, Lq, M * D), generator=g)
+        # the reference's construction, verbatim in effect: fresh device tensors, version 0, freed after the call
+        spatial_shapes = torch.as_tensor(shapes_l, dtype=torch.long, device=dev)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        seen_ptrs.add(spatial_shapes.data_ptr())
+        vr, lr, wr = (t.to(dev).requires_grad_(True) for t in (value, loc, w))
+        out = MSDeformAttnFunction.apply(vr, spatial_shapes, level_start_index, lr, wr, 128)
+        (out * go.to(dev)).sum().backward()
+        o2 = MSDA.ms_deform_attn_forward(vr.detach(), spatial_shapes, level_start_index, lr.detach(), wr.detach(), 128)
+        assert torch.equal(o2, out)
+        shp = np.asarray(shapes_l, np.int64)
+        lsi = np.concatenate([[0], np.cumsum(shp[:, 0] * shp[:, 1])[:-1]]).astype(np.int64)
+        ref = oracle.msda_core(value.numpy(), shp, lsi, loc.numpy(), w.numpy())
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5, err_msg=f"pyramid {it}")
+        rv, rl, rw = oracle.msda_core_backward(value.numpy(), shp, lsi, loc.numpy(), w.numpy(), go.numpy())
+        for got, want, name in ((vr.grad, rv, "grad_value"), (lr.grad, rl, "grad_loc"), (wr.grad, rw, "grad_attn")):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max(), err_msg=f"pyramid {it} {name}")
+        del spatial_shapes, level_start_index, out, o2, vr, lr, wr
+    # (informational) the allocator did recycle the index tensors' block at least once -- the situation the old cache got wrong
+    print("distinct spatial_shapes addresses over", len(pyramids), "calls:", len(seen_ptrs))
+
+
+def test_msda_dev_shapes_rejected_on_device():
+    """shapes that do not describe `value` cannot fail the call without a sync: the device-shape form writes zeros and raises
+    the geometry record's flag (s2d_msda_dev_status); nothing is indexed by the bad numbers"""
+    from s2d_amd import ops
+    dev = torch.device(DEV)
+    N, M, D, P, Lq, L = 1, 8, 32, 4, 20, 2
+    S = 6 * 8 + 3 * 4
+    value = torch.randn((N, S, M, D), device=dev)
+    loc = torch.rand((N, Lq, M, L, P, 2), device=dev)
+    w = torch.softmax(torch.randn((N, Lq, M, L * P), device=dev), -1).view(N, Lq, M, L, P)
+    go = torch.randn((N, Lq, M * D), device=dev)
+    good = torch.tensor([[6, 8], [3, 4]], dtype=torch.long, device=dev)
+    lsi = torch.tensor([0, 48], dtype=torch.long, device=dev)
+    out, ws = ops.msda_forward_dev(value, good, lsi, loc, w, want_ws=True)
+    assert ops.msda_dev_status(ws) == 0 and out.abs().sum() > 0
+    for bad in ([[6, 8], [30, 40]], [[0, 8], [3, 4]], [[-6, 8], [3, 4]]):
+        shp = torch.tensor(bad, dtype=torch.long, device=dev)
+        out, ws = ops.msda_forward_dev(value, shp, lsi, loc, w, want_ws=True)
+        assert ops.msda_dev_status(ws) == 1 and torch.count_nonzero(out) == 0
+        gv, gl, gw, ws = ops.msda_backward_dev(value, shp, lsi, loc, w, go, want_ws=True)
+        assert ops.msda_dev_status(ws) == 1
+        assert torch.count_nonzero(gv) == 0 and torch.count_nonzero(gl) == 0 and torch.count_nonzero(gw) == 0
+    with pytest.raises(RuntimeError):
+        ops.msda_forward_dev(value, good.cpu(), lsi, loc, w)                  # index tensors must be on the device
+    with pytest.raises(RuntimeError):
+        ops.msda_forward_dev(value, good.int(), lsi, loc, w)                  # and int64, as the extension reads them
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_gemm_dropout_in_the_other_dense_modes(mode):
+    """training-mode encoder layers under --dense bf16x3 / f32: the mask epilogue exists in the split-fp16 kernels only, the other
+    modes apply the same mask as a separate pass (same values as that mode's GEMM followed by the mask)"""
+    from s2d_amd import ops
+    from s2d_amd.modeling.pixel_decoder import MSDeformAttnTransformerEncoderLayer
+    ops.set_dense_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(5)
+        M, N, K = 500, 256, 256
+        A = torch.randn((M, K), generator=g).to(DEV)
+        W = torch.nn.Parameter(torch.randn((N, K), generator=g).mul_(K ** -0.5).to(DEV))
+        b = torch.randn((N,), generator=g).to(DEV)
+        R = torch.randn((M, N), generator=g).to(DEV)
+        p, seed, site = 0.3, 1234, 1
+        y = ops.gemm_nt(A, W, bias=b, res=R, relu=True, dropout=(p, seed, site))
+        ref = torch.relu(ops.gemm_nt(A, W, bias=b) * ops.dropout(torch.ones((M, N), device=DEV), p, seed, site) + R)
+        assert torch.equal(y, ref)
+        torch.manual_seed(2)
+        layer = MSDeformAttnTransformerEncoderLayer(dropout=0.3).to(DEV).train()
+        shapes = [(4, 6), (8, 12), (16, 24)]
+        S = sum(h * w for h, w in shapes)
+        out = layer(torch.randn((2, S, 256), device=DEV), torch.randn((S, 256), device=DEV), torch.tensor(shapes, dtype=torch.int64))
+        assert torch.isfinite(out).all()
+    finally:
+        ops.set_dense_mode("f16x3")
+
+
 # ------------------------------------------------------------------------------------------------ A8 prepare_targets
 def test_prepare_targets_product_path_vs_reference_golden():
     """_gt_target_list + TargetSet.from_list (the product's prepare_targets, kd_video_maskformer_model.py:358-386) against the
