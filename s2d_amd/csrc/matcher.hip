@@ -249,13 +249,15 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, unsigned int &lo)
 {
     const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ha = (float)h[0], hb = (float)h[1];
-    const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - ha) * 2048.f, (b - hb) * 2048.f);
+    // (a - h) * 2048 == fma(h, -2048, a * 2048) exactly (a - h is exact, the factor a power of two): one multiply + one
+    // v_fma_mix_f32 (fp16 operand converted inside the fma) per value instead of convert, subtract, multiply
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -2048.f, a * 2048.f), __builtin_fmaf((float)h[1], -2048.f, b * 2048.f));
     hi = __builtin_bit_cast(unsigned int, h);
     lo = __builtin_bit_cast(unsigned int, l);
 }
 
 constexpr int SPANMAX = 24;     // staged logit rows per tap row (upper / lower): a 32-point batch spans ~12 cells at S2D density
+constexpr int ROWS = 2 * SPANMAX + 3;   // LDS rows of one staged block: slack, upper run, slack, lower run, slack
 __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
 {
     constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
@@ -267,7 +269,11 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     // 128, and no lane waits on a gather.  A batch whose run is longer than SPANMAX (sparse or injected points) takes the
     // direct-gather path.  One barrier per batch: tap tables in a ring of 3 (batch i in use, i+1 target gathers and row
     // loads in flight, i+2 being set up), staged rows and target tile in rings of 2.
-    extern __shared__ __attribute__((aligned(16))) float rowbuf[];          // [2][2 * SPANMAX][128]
+    // rowbuf [2][ROWS][128], ROWS = 2 * SPANMAX + 3: [slack][upper run: span rows][slack][lower run: span rows][slack].  The two
+    // x-adjacent taps of a tap row are LDS rows r and r + 1 (512 B apart): one ds_read2_b32 per tap row from one address.  A tap
+    // outside the map has weight 0 and reads whatever finite number lies there: the slack rows (x0 = -1 reads the row before a
+    // run, x1 = wm the row after; y0 = -1 / y1 = hm read rows 0 / 1) -- the buffer is zeroed once and only ever receives logits.
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     __shared__ __attribute__((aligned(16))) unsigned int Th[2][TN][TROW], Tl[2][TN][TROW];
     __shared__ __attribute__((aligned(16))) int bqi[3][SB][4], bti[3][SB][4];      // per sample: 4 tap offsets / weights,
     __shared__ __attribute__((aligned(16))) float bqw[3][SB][4], btw[3][SB][4];   // read back as one 16-B LDS load each
@@ -320,23 +326,39 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { cmin = min(cmin, __shfl_xor(cmin, o, 64)); cmax = max(cmax, __shfl_xor(cmax, o, 64)); }
             if (cmax < 0) { cmin = 0; cmax = 0; }            // all-tail batch
-            const int span = cmax - cmin + 2;
+            const int span = (cmax - cmin + 3) & ~1;         // cells cmin .. cmax + 1, rounded up to whole row pairs of the DMA
             const bool staged = span <= SPANMAX;
             if (setq) {
                 const int ii[4] = {a.i00, a.i01, a.i10, a.i11};
                 const float ww[4] = {a.w00, a.w01, a.w10, a.w11};
                 i32x4 o; f32x4 w;
+                if (staged) {
+                    // o[0] / o[1]: float offset of the LEFT tap of the tap row y0 / y0 + 1 in the staged block; its right tap is the
+                    // next LDS row.  The block holds pixels [cmin, cmin + span) at LDS rows 1 .. span and [cmin + wm, cmin + wm + span)
+                    // at rows span + 2 .. 2 span + 1; a left tap one pixel before a run (x0 = -1) is the slack row in front of it, a
+                    // right tap one past it the slack row behind.  A tap row outside the map reads rows 0 / 1 with zero weights.
+                    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+                    auto locate = [&](int y, bool &ok) {
+                        ok = y >= 0 && y < p.hm;
+                        const int d = y * p.wm + x0 - cmin, d2 = d - p.wm;
+                        if (ok && d >= -1 && d < span) return (1 + d) * 128;
+                        if (ok && d2 >= -1 && d2 < span) return (span + 2 + d2) * 128;
+                        ok = false;                          // cannot happen for a row inside the map; keep it harmless
+                        return 0;
+                    };
+                    bool uok, lok;
+                    o[0] = locate(y0, uok);
+                    o[1] = locate(y0 + 1, lok);
+                    o[2] = 0; o[3] = 0;
+                    w[0] = (uok && ii[0] >= 0 && !tail) ? ww[0] : 0.f; w[1] = (uok && ii[1] >= 0 && !tail) ? ww[1] : 0.f;
+                    w[2] = (lok && ii[2] >= 0 && !tail) ? ww[2] : 0.f; w[3] = (lok && ii[3] >= 0 && !tail) ? ww[3] : 0.f;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bool ok = ii[e] >= 0 && !tail;
-                    int off = 0;
-                    if (staged) {                            // float offset of the tap's pixel row in the staged block
-                        const int d = ii[e] - cmin, d2 = d - p.wm;
-                        if (d >= 0 && d < span) off = d * 128;
-                        else if (d2 >= 0 && d2 < span) off = (span + d2) * 128;
-                        else ok = false;                     // cannot happen for a valid tap; keep it harmless
-                    } else off = ii[e] < 0 ? 0 : ii[e] * (p.ldq * 4);      // byte offset into the (problem, frame) logit map
-                    o[e] = off; w[e] = ok ? ww[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = ii[e] >= 0 && !tail;
+                        o[e] = ii[e] < 0 ? 0 : ii[e] * (p.ldq * 4);      // byte offset into the (problem, frame) logit map
+                        w[e] = ok ? ww[e] : 0.f;
+                    }
                 }
                 *reinterpret_cast<i32x4 *>(bqi[buf][l32]) = o;
                 *reinterpret_cast<f32x4 *>(bqw[buf][l32]) = w;
@@ -364,8 +386,9 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
             const int row = 2 * rp + (lane >> 5);
             const int pix = cmin + row + (row >= span ? p.wm - span : 0);
             const bool ok = row < 2 * span && pix < npix && c4 < l4;
+            // span is even, so a row pair lies in one run: LDS rows 1 + row (upper run) or 2 + row (lower run, behind its slack row)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsM, (__attribute__((address_space(3))) void *)(rowbuf + ((long)buf * 2 * SPANMAX + 2 * rp) * 128), 16,
+                rsM, (__attribute__((address_space(3))) void *)(rowbuf + ((long)buf * ROWS + 2 * rp + (2 * rp >= span ? 2 : 1)) * 128), 16,
                 ok ? (pix * p.ldq + c4 * 4) * 4 : (int)0xFFFFFFF0u, 0, 0, 0);
         }
     };
@@ -399,6 +422,8 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         if ((setq || sett) && !tail) { u = cr[2 * (base + l32)]; v = cr[2 * (base + l32) + 1]; }
     };
 
+    for (int i = tid; i < 2 * ROWS * 128 / 4; i += 256) reinterpret_cast<f32x4 *>(rowbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite slack rows
+    __syncthreads();
     const int base0 = c * SB, bstep = CHM * SB;
     if (base0 < p.P) {
         float u, v; bool tail;
@@ -425,11 +450,12 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         rows_dma(r1, cur ^ 1);                              // batch i+1's logit rows -> rows [cur^1] (last read before the previous barrier)
         // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
         const bool staged_now = bmeta[r0][2] != 0;
-        const float *rb = rowbuf + (long)cur * 2 * SPANMAX * 128 + qr;
+        const float *rb = rowbuf + (long)cur * ROWS * 128 + qr;
         // softplus(x) = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)): the two sums are kept apart and ln2 is applied once.
         // A tail sample (zero tap weights) has x == 0 exactly; only the one partial batch of a chunk pays for the masks.
         unsigned int xh[2][4], xl[2][4], gh[2][4], gl[2][4];
         auto query_half = [&](int st, auto masked, auto staged) {
+            float dprod = 1.f;
             float m[8][4];                                   // direct-gather path: this half's 32 taps in flight together
             if constexpr (!decltype(staged)::value) {
 #pragma unroll
@@ -449,27 +475,29 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
                     const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
                     float m0, m1, m2, m3;
                     if constexpr (decltype(staged)::value) {
-                        const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][k]);
-                        m0 = rb[qi[0]]; m1 = rb[qi[1]]; m2 = rb[qi[2]]; m3 = rb[qi[3]];
+                        typedef int i32x2 __attribute__((ext_vector_type(2)));
+                        const i32x2 qi = *reinterpret_cast<const i32x2 *>(bqi[r0][k]);     // left taps of the two tap rows
+                        m0 = rb[qi[0]]; m1 = rb[qi[0] + 128]; m2 = rb[qi[1]]; m3 = rb[qi[1] + 128];    // one ds_read2_b32 per tap row
                     } else { m0 = m[s8][0]; m1 = m[s8][1]; m2 = m[s8][2]; m3 = m[s8][3]; }
                     const float x = fmaf(m3, qw[3], fmaf(m2, qw[2], fmaf(m1, qw[1], m0 * qw[0])));
                     const float ex = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504f);
                     const float den = 1.f + ex;
                     const float inv = __builtin_amdgcn_rcpf(den);
                     float sgm = x >= 0.f ? inv : ex * inv;
-                    float lg = __builtin_amdgcn_logf(den);
+                    float dl = den;
                     if constexpr (decltype(masked)::value) {
-                        const float liveq = k < nvalid ? 1.f : 0.f;
-                        sgm *= liveq; lg *= liveq;
+                        const bool liveq = k < nvalid;
+                        sgm = liveq ? sgm : 0.f; dl = liveq ? den : 1.f;
                     }
                     relusum += fmaxf(x, 0.f);
-                    lg2sum += lg;
+                    dprod *= dl;                               // sum of log2(1 + e) over the half's 8 samples = log2 of the product (<= 2^8)
                     sgsum += sgm;
                     xv[e] = x; sv[e] = sgm;
                 }
                 split_pair(xv[0], xv[1], xh[st][jp], xl[st][jp]);
                 split_pair(sv[0], sv[1], gh[st][jp], gl[st][jp]);
             }
+            lg2sum += __builtin_amdgcn_logf(dprod);
         };
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -722,7 +750,7 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     p.coords = sorted;
     const int npairs = nprob * T;
     const int grid = ((npairs + 7) / 8) * 8 * CHM;
-    const size_t lds_rows = sizeof(float) * 2 * 2 * SPANMAX * 128;
+    const size_t lds_rows = sizeof(float) * 2 * ROWS * 128;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

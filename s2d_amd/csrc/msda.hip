@@ -169,24 +169,46 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // normalised pixel centre is its reference point on every level, msdeformattn.py:141-153 with valid
 // ratios == 1).  `oa` [N,S,ldoa] holds, per query, the raw sampling offsets [M][L][P][2] followed by the raw
 // attention logits [M][L*P] (one GEMM output).  Softmax over L*P and loc = ref + off/(W_l,H_l) happen here.
-template <int LP_, bool HM = false, bool SHARE = false>
-__global__ __launch_bounds__(256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
+// TILED: a 1024-thread workgroup = the 16 queries of a 4 x 4 pixel patch of one level (wave w: pixel (w / 4, w % 4) of the patch), the
+// patches of a frame numbered level by level, row-major, and dealt to the XCDs in contiguous bands.  The 16 waves of a workgroup
+// are co-resident on one CU by construction, so the corner rows neighbouring queries share (their sampling offsets differ by
+// less than the patch when the offsets field is smooth) are fetched into that CU's L1 once; with 256-thread workgroups of 4
+// consecutive queries the dispatcher deals a CU workgroups that lie 128 queries apart.
+template <int LP_, bool HM = false, bool SHARE = false, bool TILED = false>
+__global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
                                                          int P, int blk_per_n, float *__restrict__ out)
 {
     constexpr int D = 32, V = 4, dv = D / V;
     const int n = blockIdx.y;
     const int bid = xcd_band(blockIdx.x, blk_per_n);
-    const long item = (long)bid * 256 + threadIdx.x;
-    if (item >= (long)S * M * dv) return;
-    const int c = (int)(item % dv);
-    const int m = (int)((item / dv) % M);
-    const int q = (int)(item / ((long)dv * M));
-    // which level does query q live on, and where
-    int lq = 0;
-    while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
-    const int qi = q - (int)lv.start[lq];
-    const int qy = qi / lv.W[lq], qx = qi - qy * lv.W[lq];
+    int c, m, q, lq = 0, qy, qx;
+    if constexpr (TILED) {
+        int tb = bid, ntx = 1;
+        for (;; ++lq) {
+            ntx = (lv.W[lq] + 3) >> 2;
+            const int nt = ntx * ((lv.H[lq] + 3) >> 2);
+            if (tb < nt || lq == L - 1) break;
+            tb -= nt;
+        }
+        const int w = threadIdx.x >> 6;
+        qy = (tb / ntx) * 4 + (w >> 2);
+        qx = (tb % ntx) * 4 + (w & 3);
+        if (qy >= lv.H[lq] || qx >= lv.W[lq]) return;         // whole waves leave (patches overhanging the level's border)
+        q = (int)lv.start[lq] + qy * lv.W[lq] + qx;
+        c = threadIdx.x & 7;
+        m = (threadIdx.x >> 3) & 7;
+    } else {
+        const long item = (long)bid * 256 + threadIdx.x;
+        if (item >= (long)S * M * dv) return;
+        c = (int)(item % dv);
+        m = (int)((item / dv) % M);
+        q = (int)(item / ((long)dv * M));
+        // which level does query q live on, and where
+        while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
+        const int qi = q - (int)lv.start[lq];
+        qy = qi / lv.W[lq]; qx = qi - qy * lv.W[lq];
+    }
     const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
     const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
 
@@ -1051,9 +1073,14 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
     if (ldv < 0)      // experiment switch of scripts/mb_msda.py: ldv = -1 reads a head-major value tensor [N][M][S][32]
         hipLaunchKernelGGL((msda_fused_kernel<12, true>), dim3(nb, N), dim3(256), 0, stream, value, 32, lv, offs_logits, ldoa, S, M, L, P, nb, out);
     else {
-        static int share = -1;
+        static int share = -1, tiled = -1;
         if (share < 0) { const char *e = getenv("S2D_MSDA_SHARE"); share = e ? atoi(e) : 1; }
-        if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
+        if (tiled < 0) { const char *e = getenv("S2D_MSDA_TILED"); tiled = e ? atoi(e) : 1; }
+        if (tiled && M == 8) {
+            int ntile = 0;
+            for (int l = 0; l < L; ++l) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);
+            hipLaunchKernelGGL((msda_fused_kernel<12, false, true, true>), dim3(ntile, N), dim3(1024), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, ntile, out);
+        } else if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
         else hipLaunchKernelGGL((msda_fused_kernel<12, false, false>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
     }
     S2D_CHECK_LAUNCH();
