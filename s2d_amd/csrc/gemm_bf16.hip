@@ -1748,7 +1748,7 @@ int launch_t(const GemmParams &p, int batch, hipStream_t st)
 // static weights -> [N][kblocks][16 words hi | 16 words lo]: the LDS row image of the split-fp16 kernels, zero padded past K
 template <bool BF16>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ W, int N, int K, long ldw, int kblocks,
-                                                            unsigned int *__restrict__ out)
+                                                            unsigned int *__restrict__ out, int vec4)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)N * kblocks * 8) return;
@@ -1757,10 +1757,23 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
     const int kb = (int)(nb % kblocks);
     const long n = nb / kblocks;
     const int k = kb * 32 + c4 * 4;
+    // one 16-B load when the row layout allows it (every GEMM operand of the library: K, ldw multiples of 4, 16-B aligned base):
+    // the conversions below are packed ops, which must not be the first readers of single-dword loads (scripts/isa_lint.py)
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec4) { if (k < K) v = *reinterpret_cast<const f32x4 *>(W + n * ldw + k); }
+    else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (k + j < K) v[j] = W[n * ldw + k + j];
+        for (int j = 0; j < 4; ++j)
+            if (k + j < K) t[j] = W[n * ldw + k + j];
+        // ragged rows: every value passes through a plain move first (an opaque v_mov_b32 the optimiser cannot fold away)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(t[j]));
+            v[j] = r;
+        }
+    }
     u32x2 hi, lo;
     if (BF16) split4(v, hi, lo);            // split-bf16 mode: unscaled low part (gemm_bf16x3_w128_kernel)
     else split4_f16(v, hi, lo);
@@ -1776,8 +1789,9 @@ int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned in
     const int kblocks = (K + 31) / 32;
     const long n = (long)N * kblocks * 8;
     if (n == 0) return S2D_OK;
-    if (bf16) hipLaunchKernelGGL(split_weights_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
-    else hipLaunchKernelGGL(split_weights_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out);
+    const int vec4 = ((K | ldw) & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    if (bf16) hipLaunchKernelGGL(split_weights_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out, vec4);
+    else hipLaunchKernelGGL(split_weights_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, W, N, K, ldw, kblocks, out, vec4);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

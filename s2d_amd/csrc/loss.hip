@@ -949,15 +949,24 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 if (i4 < cnt4) x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
                 return x4;
             };
-            f32x4 nx0 = load4(0), nx1 = load4(1);                  // two loads ahead of the consumer
-            for (int k = 0; k < it4; ++k) {
-                const int i4 = k * LTHREADS + threadIdx.x;
-                const bool live = i4 < cnt4;
-                const f32x4 x4 = nx0;
-                nx0 = nx1;
-                nx1 = load4(k + 2);
+            // DEPTH loads ahead of the consumer (a ring in registers, the loop unrolled over it): one workgroup per CU streams its
+            // row at the latency x depth product -- with two loads in flight the pass ran at ~8 GB/s per CU
+            constexpr int DEPTH = 8;
+            f32x4 ring[DEPTH];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) test(4 * i4 + j, x4[j], live);
+            for (int d = 0; d < DEPTH; ++d) ring[d] = load4(d);
+            for (int k0 = 0; k0 < it4; k0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int k = k0 + d;
+                    if (k >= it4) break;                           // uniform over the workgroup
+                    const int i4 = k * LTHREADS + threadIdx.x;
+                    const bool live = i4 < cnt4;
+                    const f32x4 x4 = ring[d];
+                    ring[d] = load4(k + DEPTH);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) test(4 * i4 + j, x4[j], live);
+                }
             }
             const int tail0 = 4 * cnt4, itt = (cnt - tail0 + LTHREADS - 1) / LTHREADS;
             for (int k = 0; k < itt; ++k) {

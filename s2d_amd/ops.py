@@ -329,8 +329,10 @@ def msda_fused_forward(value, shapes, offs_logits, M=8, P=4):
     sh = _host_i64(shapes)
     L = sh.shape[0]
     out = torch.empty((N, S, C), device=value.device, dtype=torch.float32)
-    lib().call("s2d_msda_fused_forward_f32", value, value.stride(1), sh, offs_logits, offs_logits.stride(1), N, S, M, C // M, L, P,
-               out, _stream())
+    # algorithmic bytes: value read once + output written once + offsets / logits read once
+    with _Timed(0.0, ("msda", N, S, C, L * P, 4.0 * N * (2 * S * C + S * M * L * P * 3))):
+        lib().call("s2d_msda_fused_forward_f32", value, value.stride(1), sh, offs_logits, offs_logits.stride(1), N, S, M, C // M, L, P,
+                   out, _stream())
     return out
 
 
@@ -452,7 +454,9 @@ def masked_attn(q, k, v, bits=None, unmasked=None, H=8, want_lse=False):
     ws = torch.empty((n,), device=q.device, dtype=torch.float32)
     out = torch.empty_like(q)
     lse = torch.empty((B, H, 128), device=q.device, dtype=torch.float32) if want_lse else None
-    lib().call("s2d_masked_attn_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, B, Q, K, C, H, ws, out, lse, _stream())
+    # QK^T + AV: 4 B Q K C flops; K and V rows read once
+    with _Timed(4.0 * B * Q * K * C, ("xattn" if bits is not None else "sattn", B, Q, K, C, 4.0 * (2.0 * B * K * C + 2.0 * B * Q * C))):
+        lib().call("s2d_masked_attn_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, B, Q, K, C, H, ws, out, lse, _stream())
     return (out, lse) if want_lse else out
 
 

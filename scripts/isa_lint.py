@@ -14,9 +14,18 @@ v_mov_b32) as first reader, or with dwordx4 loads, never did.  The load, the wai
 correct, so the library avoids the shape instead: the kernels are built with -fno-slp-vectorize (the compiler's SLP pass is
 what turns scalar arithmetic on freshly loaded values into v_pk_* instructions), and this lint checks the result.
 
-Rule: inside one kernel, a `v_pk_*` instruction that directly follows an `s_waitcnt` carrying a vmcnt field (only `s_nop`
+Rule 1: inside one kernel, a MULTI-ELEMENT consumer -- `v_pk_*`, `v_cvt_pk*`, `v_dot*`, `v_mfma*`: instructions that read a
+register as packed halves or as part of a fragment -- that directly follows an `s_waitcnt` carrying a vmcnt field (only `s_nop`
 in between) and reads a VGPR that a ONE-register vector-memory load (dword or narrower) wrote earlier in the kernel is an
-error.  (Multi-register loads -- dwordx2/x4, the library's normal access width -- never showed the effect: the 16-B form of
+error.  (Round 2 linted `v_pk_*` only; the measured failure was a `v_pk_mul_f32`, the other three classes are refused on the same
+grounds -- first reader of a just-awaited single dword that is not a plain one-lane-one-value VALU op -- without having been
+seen to fail.  A plain VALU first reader is what the fixed kernels use and what ran clean.)
+
+Rule 2 (source level): a function that spells out its own counted `s_waitcnt vmcnt(N)` with N > 0 in inline asm (a hand-built
+pipeline: today the wave-specialised GEMM) must not issue masked buffer loads -- the `| OOB` / 0xFFFFFFF0 offset trick that lets
+the hardware bounds check drop a load -- inside it: round 2's WS kernel read a register set's first rows before they had landed
+whenever such dropped loads sat in the counted window (profiles/r2_ws_gemm/README.md), and ran clean once every load was clamped
+in range.  Compiler-inserted counted waits are not concerned: the compiler counts what it issued.  (Multi-register loads -- dwordx2/x4, the library's normal access width -- never showed the effect: the 16-B form of
 the same kernel ran 0 wrong words in > 500 two-stream launches, and every other kernel of the two-stream schedule is
 bitwise equal to its one-stream result.)
 
@@ -31,6 +40,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "s2d_amd", "csrc")
+MULTI = ("v_pk_", "v_cvt_pk", "v_dot", "v_mfma")
 LOAD = re.compile(r"^\s*(global_load|buffer_load|flat_load|scratch_load)_(\w+)\s+(v\[\d+:\d+\]|v\d+)")
 REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
@@ -78,7 +88,7 @@ def lint_text(text, name):
         used = set()
         for t in parts[1:]:                       # first operand is the destination
             used |= regs(t)
-        if prev_wait and s.startswith("v_pk_"):
+        if prev_wait and s.startswith(MULTI):
             hit = used & loaded
             if hit:
                 bad.append(f"{name}:{ln}: {kernel}: `{s}` straight behind s_waitcnt vmcnt reads loaded v{sorted(hit)}")
@@ -87,6 +97,24 @@ def lint_text(text, name):
         if parts and not s.startswith(("global_store", "buffer_store", "flat_store", "ds_write", "ds_store", "scratch_store")):
             loaded -= regs(parts[0])
         prev_wait = False
+    return bad
+
+
+def lint_source(path):
+    """Rule 2: hand-counted vmcnt(N > 0) and masked (OOB-dropped) buffer loads in one function"""
+    bad = []
+    text = open(path).read()
+    # split at kernel / function heads: good enough for these files (one `__global__` or `__device__` head per definition)
+    heads = [m.start() for m in re.finditer(r"^(template\s*<[^>]*>\s*)?(__global__|__device__|static)\b", text, re.M)] + [len(text)]
+    for a, b in zip(heads, heads[1:]):
+        body = text[a:b]
+        counted = [m for m in re.finditer(r'asm\s+volatile\s*\(\s*"s_waitcnt\s+vmcnt\((\d+)\)', body) if int(m.group(1)) > 0]
+        counted += [m for m in re.finditer(r"__builtin_amdgcn_s_waitcnt\s*\(", body)]
+        if not counted:
+            continue
+        if re.search(r"\bOOB\b|0xFFFFFFF0", body) and "lint: every load in range" not in body:
+            name = re.search(r"(\w+)\s*\(", body[body.find("void"):] if "void" in body else body)
+            bad.append(f"{os.path.basename(path)}: {name.group(1) if name else '?'}: hand-counted s_waitcnt vmcnt(N>0) together with masked (OOB) buffer loads")
     return bad
 
 
@@ -108,6 +136,8 @@ def main(argv):
     for f in files:
         text = open(f).read() if f.endswith(".s") else disassemble(f)
         bad += lint_text(text, os.path.basename(f))
+        if not f.endswith(".s"):
+            bad += lint_source(f)
     for b in bad:
         print(b)
     print(f"isa_lint: {len(files)} file(s), {len(bad)} finding(s)")
