@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the extra report of one full training iteration (fwd + loss + backward + all-reduce + clip/AdamW/EMA, BASELINE config 4)")
     ap.add_argument("--no-keymask", action="store_true", help="skip the keymask kernel-set report (BASELINE config 3)")
+    ap.add_argument("--no-amp", action="store_true", help="skip the extra `amp` report (the same step with AMP compute switched on)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--one-stream", "--no-overlap", dest="one_stream", action="store_true",
                     help="time the one-stream schedule (default: teacher forward + GT criterion on a second HIP stream; the other "
@@ -487,6 +488,26 @@ def main():
         events_note = "HIP events around every dense launch inside the timed region"
     model.overlap_teacher = model.overlap_criteria = two
 
+    # Extra report, never `value`: the same step with AMP COMPUTE on -- the arithmetic the reference itself trains in (every shipped
+    # yaml sets SOLVER.AMP.ENABLED, engine/train_loop.py:709 `with autocast():`): single-pass fp16 MFMA with f32 accumulation for
+    # the modules autocast runs in fp16 (R50 trunk, video decoder linears, mask-logit einsum); pixel decoder, matcher, losses as above.
+    amp_res = None
+    if not args.no_amp and args.dense == "f16x3":
+        from s2d_amd.modeling import set_amp_compute
+        set_amp_compute(model, True)
+        try:
+            n_amp = max(args.steps // 2, 2)
+            dt_amp, tot_amp, _ = timed(False, two, n_amp, 1)
+            dt_amp = _max_over_ranks(dt_amp, world, cdev or dev)
+            amp_res = {"what": "same workload and schedule, AMP compute on (s2d_amd.modeling.set_amp_compute): fp16 operands / f32 accumulate, one MFMA pass, in "
+                               "the R50 trunk, the video decoder's linear layers and the mask-logit einsum -- the modules torch.autocast runs in fp16 in the "
+                               "reference; pixel decoder, matcher and losses unchanged (fp32-class)",
+                       "value": round(world * B * T * n_amp / dt_amp, 3), "unit": "clip-frames/s", "ms_per_step": round(1000 * dt_amp / n_amp, 3),
+                       "steps": n_amp, "loss_total_finite": bool(torch.isfinite(tot_amp)),
+                       "hbm_roofline_frac": round(world * B * T * n_amp / dt_amp / world * 19.0 / 8000.0, 4) if args.config == "c4" else None}
+        finally:
+            set_amp_compute(model, False)
+
     fallback = False
     if same is False and two and dt_other == dt_other:
         # The two schedules must agree bit for bit (every kernel is deterministic).  If they do not, the two-stream timing is not
@@ -552,6 +573,8 @@ def main():
         if args.config == "c4":
             res["hbm_roofline"] = {"algorithmic_GB_per_frame": 19.0, "peak_TBps": 8.0,
                                    "frac": round(res["value"] / world * 19.0 / 8000.0, 4), "target_frac": 0.4}
+        if amp_res is not None:
+            res["amp"] = amp_res
         if prof and args.dense_breakdown:
             import collections
             agg = collections.defaultdict(lambda: [0, 0.0, 0.0])

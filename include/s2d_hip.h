@@ -98,6 +98,17 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
                         int KW, int stride, int pad, const float *scale, const float *bias, const float *res,
                         int relu, const void *w_split, hipStream_t stream);
 
+/* The two contractions in the arithmetic torch.autocast gives the reference (engine/train_loop.py:709 `with autocast():`,
+ * SOLVER.AMP.ENABLED True in every shipped yaml): operands rounded to fp16 (nearest-even), f32 accumulation by ONE fp16 MFMA per
+ * product, f32 out.  Opt-in, for the modules autocast runs in fp16 (the R50 trunk, the video decoder's linear layers, the
+ * mask-logit einsum); the pixel decoder and the matcher force fp32 in the reference (msdeformattn.py:314, matcher.py:266-268) and
+ * never take these.  Same arguments as s2d_gemm_nt_f32 / s2d_conv2d_nhwc_f32 without the pre-split image. */
+int s2d_gemm_nt_amp_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, int batch,
+                        long strideA, long strideB, long strideC, const float *scale, const float *bias, const float *res, long ldr,
+                        long strideR, int res_rows, int res_cols, int relu, hipStream_t stream);
+int s2d_conv2d_nhwc_amp_f32(const float *x, const float *w, float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                            int pad, const float *scale, const float *bias, const float *res, int relu, hipStream_t stream);
+
 /* ---- multi-scale deformable attention (HBM/L2-bound gather, no MFMA) --------------------------------- */
 
 /* Drop-in for MSDA.ms_deform_attn_forward (ops/src/ms_deform_attn.h:25-44, ops/src/vision.cpp:19; kernel

@@ -49,8 +49,30 @@ def _c(a, dt):
 
 
 # --------------------------------------------------------------------------- basic layers
+# AMP: restate the modules torch.autocast runs in fp16 under the reference trainer (engine/train_loop.py:709 `with autocast():`,
+# SOLVER.AMP.ENABLED True) with both operands of every linear / convolution / einsum rounded to fp16 (nearest-even, as `.half()`)
+# and f32 accumulation -- the R50 trunk, the video decoder's linear layers, the mask-logit einsum.  The pixel decoder and the
+# matcher run in fp32 in the reference (msdeformattn.py:314, matcher.py:266-268).  `AMP = True` arms it; resnet50() and
+# video_decoder() switch the rounding on for their own extent.
+AMP = False
+_AMP_ON = [False]
+
+
+def _r16(a):
+    return a.astype(np.float16).astype(np.float32) if _AMP_ON[0] else a
+
+
+class _amp_scope:
+    def __enter__(self):
+        self.prev = _AMP_ON[0]
+        _AMP_ON[0] = bool(AMP)
+
+    def __exit__(self, *a):
+        _AMP_ON[0] = self.prev
+
+
 def linear(x, w, b=None):
-    y = x @ w.T
+    y = _r16(x) @ _r16(w).T
     return y if b is None else y + b
 
 
@@ -83,6 +105,8 @@ def conv2d(x, w, b=None, stride=1, pad=0):
     """x [N,C,H,W], w [O,C,kh,kw] -> [N,O,Ho,Wo]; im2col + one matmul."""
     N, C, H, W = x.shape
     O, _, kh, kw = w.shape
+    dt_in = x.dtype
+    x, w = _r16(x), _r16(w)
     if pad:
         x = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
     Ho = (H + 2 * pad - kh) // stride + 1
@@ -98,7 +122,7 @@ def conv2d(x, w, b=None, stride=1, pad=0):
         y = (w.reshape(O, -1) @ cols).reshape(N, O, Ho, Wo)
     if b is not None:
         y = y + b[None, :, None, None]
-    return y.astype(x.dtype)
+    return y.astype(dt_in)
 
 
 def max_pool_3x3_s2_p1(x):
@@ -353,7 +377,7 @@ def prediction_heads(p, pre, output, mask_features, target_hw, nheads=8):
     d = layer_norm(output, p[pre + "decoder_norm.weight"], p[pre + "decoder_norm.bias"]).transpose(1, 0, 2)
     cls = linear(d, p[pre + "class_embed.weight"], p[pre + "class_embed.bias"])
     emb = mlp3(p, pre + "mask_embed.", d)
-    masks = np.einsum("bqc,btchw->bqthw", emb, mask_features, optimize=True).astype(np.float32)
+    masks = np.einsum("bqc,btchw->bqthw", _r16(emb), _r16(mask_features), optimize=True).astype(np.float32)
     B, Q, T = masks.shape[:3]
     rs = resize_bilinear(masks, target_hw[0], target_hw[1])
     # sigmoid(x) < 0.5  <=>  x < 0 (sigmoid is monotone, sigmoid(0) == 0.5 exactly)
@@ -365,6 +389,11 @@ def prediction_heads(p, pre, output, mask_features, target_hw, nheads=8):
 def video_decoder(p, ms_feats, mask_features, T, pre="", n_layers=9, nheads=8):
     """VideoMultiScaleMaskedTransformerDecoder.forward, video_mask2former_transformer_decoder.py:374-446
     (training mode: bs = BT // T).  Returns logits [n_layers+1,B,Q,K+1], masks [n_layers+1,B,Q,T,h,w]."""
+    with _amp_scope():
+        return _video_decoder(p, ms_feats, mask_features, T, pre, n_layers, nheads)
+
+
+def _video_decoder(p, ms_feats, mask_features, T, pre="", n_layers=9, nheads=8):
     BT, C, hm, wm = mask_features.shape
     B = BT // T
     mf = mask_features.reshape(B, T, C, hm, wm)
@@ -417,6 +446,11 @@ def resnet50(p, x, pre=""):
     """detectron2 build_resnet_backbone, R-50, STRIDE_IN_1X1 False, FrozenBN (d2, not in the reference tree;
     call sites kd_video_maskformer_model.py:132,135; cfg configs/imagenet_video/Base-YouTubeVIS-...yaml:2-16).
     x [N,3,H,W] normalised.  Returns dict res2..res5."""
+    with _amp_scope():
+        return _resnet50(p, x, pre)
+
+
+def _resnet50(p, x, pre=""):
     y = relu(frozen_bn(conv2d(x, p[pre + "stem.conv1.weight"], None, 2, 3), p, pre + "stem.conv1.norm."))
     y = max_pool_3x3_s2_p1(y)
     outs = {}

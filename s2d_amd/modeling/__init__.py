@@ -3,4 +3,4 @@ from .pixel_decoder import MSDeformAttn, MSDeformAttnPixelDecoder
 from .video_decoder import MaskOutputs, VideoMultiScaleMaskedTransformerDecoder
 from .criterion import TargetSet, VideoHungarianMatcher, VideoSetCriterion
 from .meta_arch import (KDVideoMaskFormer, MaskFormerHead, VideoMaskFormer, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,
-                        build_kd_model)
+                        build_kd_model, set_amp_compute)

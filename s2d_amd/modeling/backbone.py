@@ -166,14 +166,18 @@ class ResNet50(nn.Module):
     def output_shape(self):
         return {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
 
+    amp = False      # True: the convolutions take torch.autocast's arithmetic (fp16 operands, f32 accumulate), as the trunk does
+                     # under the reference trainer's `with autocast():` (engine/train_loop.py:709); forward / loss only
+
     def forward(self, x, tape=None):
         """tape: a list that receives what backward() needs (the activations the reference's autograd would keep)"""
-        y = self.stem(x, tape)
-        out = {}
-        for name, *_ in R50_STAGES:
-            for blk in getattr(self, name):
-                y = blk(y, tape)
-            out[name] = y
+        with ops.amp_fp16(self.amp and tape is None):
+            y = self.stem(x, tape)
+            out = {}
+            for name, *_ in R50_STAGES:
+                for blk in getattr(self, name):
+                    y = blk(y, tape)
+                out[name] = y
         return out
 
     def backward(self, tape, grads):

@@ -60,6 +60,18 @@ class _Net(nn.Sequential):
         return self[1](self[0](x), training, aux_masks)
 
 
+def set_amp_compute(model, enabled=True):
+    """Opt-in AMP compute (SOLVER.AMP.ENABLED, engine/train_loop.py:709): the modules torch.autocast runs in fp16 in the reference --
+    the R50 trunk, the video decoder's linear layers and the mask-logit einsum -- take single-pass fp16 MFMA arithmetic (operands
+    rounded to fp16, f32 accumulation) in the forward / loss path; the pixel decoder and the criterion stay fp32-class, as the
+    reference forces them to (msdeformattn.py:314, matcher.py:266-268).  Default off: the library computes in fp32-class
+    arithmetic whatever the autocast state.  Returns the model."""
+    for m in model.modules():
+        if isinstance(m, (ResNet50, VideoMultiScaleMaskedTransformerDecoder)):
+            m.amp = bool(enabled)
+    return model
+
+
 def _test_kwargs(mf, npred_name, eval_student=False):
     """MODEL.MASK_FORMER.TEST.* keys of the eval branch (kd_video_maskformer_model.py:153, 224-230;
     video_maskformer_model.py:112, 179-181); absent TEST node -> the constructors' defaults."""

@@ -273,8 +273,13 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             x = tok.view(B, T * h * w, C)
             kin = ops.add_bcast(x, posl[lvl])                                               # src + level_embed + pos
             ks.append(ops.gemm_nt(kin.view(-1, C), wk, bias=bk).view(B, T * h * w, -1))
-            bvf = ops.gemm_nt(self.level_embed.weight[lvl:lvl + 1].detach().contiguous(), wv, bias=bv).view(-1)
-            vs.append(ops.gemm_nt(x.reshape(-1, C), wv, bias=bvf).view(B, T * h * w, -1))
+            if ops.amp_active():
+                # autocast rounds the value projection's INPUT, src + level_embed, to fp16: the sum is formed, not split over the bias
+                xv = ops.add_bcast(x, self.level_embed.weight[lvl:lvl + 1].detach().contiguous())
+                vs.append(ops.gemm_nt(xv.view(-1, C), wv, bias=bv).view(B, T * h * w, -1))
+            else:
+                bvf = ops.gemm_nt(self.level_embed.weight[lvl:lvl + 1].detach().contiguous(), wv, bias=bv).view(-1)
+                vs.append(ops.gemm_nt(x.reshape(-1, C), wv, bias=bvf).view(B, T * h * w, -1))
             kins.append(kin); xs.append(x)
         if tape is not None:
             tape.append((kins, xs))
@@ -345,6 +350,13 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         aux_masks=False (a frozen network whose intermediate predictions are not supervised: the teacher): the mask logits
         of layers 0..L-2 are evaluated only where the next layer's attention mask reads them; `mask_logits` then holds the
         full-map slots only (the last one is the final prediction, as always)."""
+        with ops.amp_fp16(self.amp and tape is None):
+            return self._forward(multi_scale, mask_features, training, aux_masks, tape)
+
+    amp = False      # True: linear layers and the mask-logit einsum in torch.autocast's arithmetic (fp16 operands, f32 accumulate),
+                     # as under the reference trainer's `with autocast():`; LayerNorm / softmax stay f32 as autocast keeps them
+
+    def _forward(self, multi_scale, mask_features, training=True, aux_masks=True, tape=None):
         BT, hm, wm, C = mask_features.shape
         B = BT // self.num_frames if training else 1   # :376
         T = BT // B

@@ -102,6 +102,30 @@ def set_dense_mode(mode):
     _MODE = mode
 
 
+_AMP = [0]
+
+
+class amp_fp16:
+    """`with ops.amp_fp16(enabled):` -- the dense launches inside take torch.autocast's arithmetic (operands rounded to fp16, f32
+    accumulate, one MFMA pass: s2d_gemm_nt_amp_f32 / s2d_conv2d_nhwc_amp_f32) instead of the fp32-class split.  The modules the
+    reference runs under autocast wrap their forward in it when the model's `amp_compute` is set (engine/train_loop.py:709); the
+    pixel decoder and the criterion never do (msdeformattn.py:314, matcher.py:266-268 force fp32).  Forward / loss only: the
+    gradient kernels stay fp32-class."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        _AMP[0] += 1 if self.enabled else 0
+
+    def __exit__(self, *a):
+        _AMP[0] -= 1 if self.enabled else 0
+
+
+def amp_active():
+    return _AMP[0] > 0 and _MODE == "f16x3"
+
+
 def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_rows=0, res_cols=0, dropout=None):
     """out[..., M, N] = act(A[..., M, K] @ B[(...), N, K]^T * scale + bias + res).
     A may be 2-D or batched 3-D; B 2-D (shared) or 3-D (per batch).  res_rows > 0: res is [res_rows, ldr] and row r of the
@@ -145,10 +169,14 @@ def gemm_nt(A, B, scale=None, bias=None, res=None, relu=False, out=None, res_row
     sA = M * K if batched else 0
     sB = N * K if B.dim() == 3 else 0
     sC = M * ldc
-    Bs = _static_split(B, N, K, K) if B.dim() == 2 else None
+    Bs = _static_split(B, N, K, K) if B.dim() == 2 and not amp_active() else None
     with _Timed(2.0 * bs * M * N * K, ("gemm", bs, M, N, K, 4.0 * bs * (M * K + N * K * (1 if B.dim() == 3 else 1.0 / bs) + M * N * (2 if res is not None else 1)))):
         ldr = res.shape[-1] if res is not None else N
         assert res is None or (ldr >= (res_cols or N) and res.shape[-2] == (res_rows or M))
+        if amp_active():
+            lib().call("s2d_gemm_nt_amp_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, ldr,
+                       res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), _stream())
+            return out
         lib().call("s2d_gemm_nt_f32", A, B, out, M, N, K, K, K, ldc, bs, sA, sB, sC, scale, bias, res, ldr,
                    res.shape[-2] * ldr if res is not None and res.dim() == 3 else 0, res_rows, res_cols, int(relu), Bs, _stream())
     return out
@@ -229,9 +257,12 @@ def conv2d_nhwc(x, w, stride=1, pad=0, scale=None, bias=None, res=None, relu=Fal
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    ws = _static_split(w, Cout, KH * KW * Cin, KH * KW * Cin)
+    ws = None if amp_active() else _static_split(w, Cout, KH * KW * Cin, KH * KW * Cin)
     with _Timed(2.0 * N * Ho * Wo * Cout * KH * KW * (3 if Cin == 4 else Cin),
                 ("conv", KH, N * Ho * Wo, Cout, KH * KW * Cin, 4.0 * (x.numel() + w.numel() + N * Ho * Wo * Cout * (2 if res is not None else 1)))):   # stem: algorithmic Cin is 3
+        if amp_active():
+            lib().call("s2d_conv2d_nhwc_amp_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu), _stream())
+            return y
         lib().call("s2d_conv2d_nhwc_f32", x, w, y, N, H, W, Cin, Cout, KH, KW, stride, pad, scale, bias, res, int(relu), ws,
                    _stream())
     return y

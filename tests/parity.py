@@ -75,7 +75,7 @@ def run_oracle(oracle, params_s, params_t, frames, tg, T, Q, P, coords_gt, coord
                 kd_counts=[k.shape[0] for k in kd], cost_gt=all_costs["gt"], cost_kd=all_costs["kd"])
 
 
-def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), NL=10, weights=(2.0, 5.0, 5.0), kd_want=None):
+def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), NL=10, weights=(2.0, 5.0, 5.0), kd_want=None, amp=False):
     """returns (hip result dict, oracle result dict or None).  kd_want: shift the teacher's class bias (in the model AND in the
     oracle's parameter set) so that about that many queries per clip pass the 0.75 distillation threshold, as SURVEY.md 8d's
     workload does (a seeded random teacher passes ~all of them, and a dense 100 x 100 assignment between unrelated networks
@@ -85,7 +85,19 @@ def run_case(oracle=None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4)
     ps = seeded_load(model.student, seed)
     pt = seeded_load(model.teacher, seed + 1)
     model = model.to(dev)
-    return run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL, weights, kd_want)
+    if not amp:
+        return run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL, weights, kd_want)
+    # AMP compute: the trunk, the video decoder's linear layers and the einsum in autocast's arithmetic, on both sides
+    from s2d_amd.modeling import set_amp_compute
+    set_amp_compute(model, True)
+    prev = getattr(oracle, "AMP", False) if oracle is not None else False
+    if oracle is not None:
+        oracle.AMP = True
+    try:
+        return run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL, weights, kd_want)
+    finally:
+        if oracle is not None:
+            oracle.AMP = prev
 
 
 def run_model_case(model, ps, pt, oracle, seed, B, T, H0, W0, Q, P, ns, NL=10, weights=(2.0, 5.0, 5.0), kd_want=None):

@@ -125,3 +125,58 @@ def test_config2_480p_two_frames_q100_both_meta_archs(oracle):
         np.testing.assert_array_equal(it[layer, :len(ri)], rj)
     print("config 2: proven near-tie assignments (cost difference, differing entries):", TIES)
     print("largest relative difference of a device KD cost matrix from the oracle's:", max(COST_ERR))
+
+
+def test_amp_compute_mode_vs_oracle_with_fp16_operands(oracle):
+    """Opt-in AMP compute (the reference trains under `with autocast():`, engine/train_loop.py:709): the R50 trunk, the video
+    decoder's linear layers and the mask-logit einsum take single-pass fp16 MFMA arithmetic (operands rounded to fp16, f32
+    accumulate); pixel decoder, matcher and losses stay fp32-class.  Against the oracle with the same operands rounded to fp16 at
+    the same layers: class / mask logits 1e-3, KD target counts, all 42 losses 1e-3 -- and the mode really changes the numbers
+    (it differs from the fp32-class forward by far more than that tolerance)."""
+    from tests.parity import run_case
+    hip, ref = run_case(oracle, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), amp=True)
+    for k in ("s_logits", "s_masks"):
+        b = ref[k].astype(np.float64)
+        np.testing.assert_allclose(hip[k], b, rtol=1e-3, atol=1e-3 * np.abs(b).max(), err_msg=k)
+    assert hip["kd_counts"] == ref["kd_counts"]
+    for k, v in ref["losses"].items():
+        np.testing.assert_allclose(hip["losses"][k], float(v), rtol=1e-3, atol=1e-6, err_msg=k)
+    full, _ = run_case(None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4))
+    d = np.abs(full["s_masks"] - hip["s_masks"]).max() / np.abs(full["s_masks"]).max()
+    print(f"AMP vs fp32-class mask logits: {d:.3e} of the largest logit")
+    assert d > 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1000, 256, 256), (4097, 100, 256), (300, 2048, 256), (200, 256, 2048), (77, 64, 196)])
+def test_amp_gemm_kernel_vs_fp16_rounded_reference(shape):
+    """s2d_gemm_nt_amp_f32 == (fp16-rounded A) . (fp16-rounded B)^T accumulated in f32 (+ epilogue), to f32 summation order"""
+    import torch
+    from s2d_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn((M, K), generator=g).cuda(); B = torch.randn((N, K), generator=g).mul_(K ** -0.5).cuda()
+    bias = torch.randn((N,), generator=g).cuda(); R = torch.randn((M, N), generator=g).cuda()
+    with ops.amp_fp16(True):
+        y = ops.gemm_nt(A, B, bias=bias, res=R if N % 4 == 0 else None, relu=True)
+    ref = A.half().double() @ B.half().double().t() + bias.double()
+    if N % 4 == 0:
+        ref = ref + R.double()
+    ref = torch.relu(ref)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    y3 = ops.gemm_nt(A, B, bias=bias, res=R if N % 4 == 0 else None, relu=True)          # outside the scope: fp32-class, a different number
+    assert (y3 - y).abs().max() > 1e-4
+
+
+def test_amp_conv_kernel_vs_fp16_rounded_reference():
+    import torch
+    from s2d_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (N, H, W, Cin, Cout, k, stride, pad) in [(2, 20, 28, 64, 64, 3, 1, 1), (1, 33, 47, 4, 64, 7, 2, 3), (2, 16, 24, 128, 256, 1, 2, 0), (1, 9, 11, 256, 96, 3, 2, 1)]:
+        x = torch.randn((N, H, W, Cin), generator=g).cuda()
+        w = torch.randn((Cout, k, k, Cin), generator=g).mul_((k * k * Cin) ** -0.5).cuda()
+        sc = (torch.rand((Cout,), generator=g) + 0.5).cuda(); sh = torch.randn((Cout,), generator=g).cuda()
+        with ops.amp_fp16(True):
+            y = ops.conv2d_nhwc(x, w, stride, pad, scale=sc, bias=sh, relu=True)
+        ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double().permute(0, 3, 1, 2), None, stride, pad)
+        ref = torch.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+        np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=str((N, H, W, Cin, Cout, k, stride, pad)))
