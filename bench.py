@@ -70,7 +70,7 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
     losses, times, t_ar = [], [], []
-    WARM = 2                                            # the caching allocator still calls hipMalloc in the second iteration
+    WARM = 4                                            # the caching allocator settles over the first iterations (0 hipMalloc from the fifth on)
     st0 = torch.cuda.memory_stats()
     for i in range(iters + WARM):
         if i == WARM:

@@ -153,12 +153,17 @@ def _transposed_weight(w, Np):
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), tuple(w.shape), Np)
     ent = _WT.get(key)
-    if ent is None or ent[1] != base._version or ent[2] is not base:
-        wt = transpose(w.contiguous())
-        if Np != w.shape[0]:
-            wt = torch.nn.functional.pad(wt, (0, Np - w.shape[0]))
-        ent = (ops.mark_static(wt), base._version, base)
-        _WT[key] = ent
+    if ent is None or ent[2] is not base:
+        wt = ops.mark_static(transpose(w.contiguous(), Np if Np != w.shape[0] else None))
+        wt._s2d_version = 0
+        ent = _WT[key] = [wt, base._version, base]
+    elif ent[1] != base._version:
+        # the weight changed (an optimizer step): transpose into the SAME buffer and bump its version -- a fresh tensor per
+        # iteration would enter ops._SPLIT under a new address every time and never leave it (0.5 GB per iteration at c4)
+        wc = w.contiguous()
+        lib().call("s2d_transpose_f32", wc, wc.shape[0], wc.shape[1], wc.shape[1], ent[0], ent[0].shape[1], _st())
+        ent[0]._s2d_version += 1
+        ent[1] = base._version
     return ent[0]
 
 
@@ -173,9 +178,14 @@ def _flipped_weight(w):
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
     ent = _WF.get(key)
-    if ent is None or ent[1] != base._version or ent[2] is not base:
-        ent = (ops.mark_static(w.flip(1, 2).permute(3, 1, 2, 0).contiguous()), base._version, base)
-        _WF[key] = ent
+    if ent is None or ent[2] is not base:
+        wf = ops.mark_static(w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
+        wf._s2d_version = 0
+        ent = _WF[key] = [wf, base._version, base]
+    elif ent[1] != base._version:                          # same buffer, new contents (see _transposed_weight)
+        ent[0].copy_(w.flip(1, 2).permute(3, 1, 2, 0))
+        ent[0]._s2d_version += 1
+        ent[1] = base._version
     return ent[0]
 
 

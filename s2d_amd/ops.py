@@ -1,5 +1,7 @@
 """Torch-tensor front ends of the C ABI (include/s2d_hip.h).  Tensors are plumbing only: device memory,
 the current stream, and the caching allocator for outputs.  Every function launches hand-written HIP."""
+import weakref
+
 import torch
 
 from ._lib import lib
@@ -77,6 +79,18 @@ def clear_weight_cache():
     _SPLIT.clear()
 
 
+_SWEEP = [256]
+
+
+def _sweep_split_cache():
+    """drop the images whose owning tensor is gone (called when a new key enters; amortised)"""
+    if len(_SPLIT) < _SWEEP[0]:
+        return
+    for k in [k for k, e in _SPLIT.items() if e[2]() is None]:
+        del _SPLIT[k]
+    _SWEEP[0] = max(256, 2 * len(_SPLIT))
+
+
 def _static_split(B, N, K, ldb):
     """cached fp16 hi/lo image of a static weight matrix, or None (dynamic tensor / other dense mode)"""
     if _MODE == "f32" or N * ((K + 31) // 32) * 128 > 0xFFFFFF00:
@@ -86,11 +100,17 @@ def _static_split(B, N, K, ldb):
         return None
     key = (B.data_ptr(), N, K, ldb, _MODE)      # the image is fp16 hi / scaled lo or bf16 hi / lo, by the mode in force
     ent = _SPLIT.get(key)
-    if ent is None or ent[1] != base._version or ent[2] is not base:
-        img = torch.empty((lib().call("s2d_split_weights_words", N, K),), device=B.device, dtype=torch.int32)
+    ver = base._version + getattr(base, "_s2d_version", 0)     # _s2d_version: buffers this library rewrites in place (backward.py)
+    if ent is None or ent[1] != ver or ent[2]() is not base:
+        # a stale image of the same tensor is overwritten in place (same size): steady-state training allocates nothing here
+        same = ent is not None and ent[2]() is base
+        img = ent[0] if same else torch.empty((lib().call("s2d_split_weights_words", N, K),), device=B.device, dtype=torch.int32)
         lib().call("s2d_split_weights_f16", B, N, K, ldb, img, _stream())
-        ent = (img, base._version, base)        # holding `base` keeps the address from being recycled under the key
-        _SPLIT[key] = ent
+        if not same:
+            _sweep_split_cache()
+        # a WEAK reference to the owner: a packed copy its module has replaced (every optimizer step re-packs) dies, and its image
+        # with it at the next sweep; an address recycled under the same key fails the identity test above and is split again
+        _SPLIT[key] = ent = (img, ver, weakref.ref(base))
     return ent[0]
 
 
