@@ -801,7 +801,13 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     const PartGeom sg_ = part_geom(p.hm, p.wm);
     if ((int)threadIdx.x < sg_.nparts) { const VRange vr = part_vrange(threadIdx.x, sg_.nparts, sg_.rows_per_part, p.hm); s_v0[threadIdx.x] = vr.v0; s_dv[threadIdx.x] = vr.dv; }
     unsigned int *tb = BWD ? ba.bit_scratch + (long)blockIdx.x * (HW / 32) : tbits;
-    float *gh = reinterpret_cast<float *>(tbits);          // BWD: the dynamic LDS is the gradient tile [hh][wm]
+    // BWD: the dynamic LDS is the gradient tile [hh][wm], accumulated in FIXED POINT (int32, LDS integer atomics): integer sums
+    // do not depend on the order the points arrive in, so the gradient is bitwise reproducible -- float atomics made it the last
+    // gradient of the training step that was not.  Scale per row: a power of two such that FX_CAP tap weights of the largest
+    // possible per-point gradient fit 31 bits (a pixel collects ~11 taps on average at the shipped point counts, a few dozen in
+    // the densest importance-sampled spots); one contribution is then rounded to <= 2^-21 of that bound.
+    int *gh = reinterpret_cast<int *>(tbits);
+    constexpr float FX_CAP = 1024.f;
     const int hh = (p.hm + 1) / 2;
     for (int li = blockIdx.x; li < nrows; li += gridDim.x) {
         const long rowid = p.list[li];
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         const float *xb = p.xbuf + (long)li * (p.n_over + p.n_rand);
         float bce = 0.f, sgt = 0.f, sg = 0.f, ts = 0.f;
         // backward: per-row constants of d(w_mask * loss_mask + w_dice * loss_dice) / d(logit at a point)
-        float g_bce = 0.f, g_dice = 0.f, dA = 0.f, dD = 1.f;
+        float g_bce = 0.f, g_dice = 0.f, dA = 0.f, dD = 1.f, fx_scale = 0.f, fx_inv = 0.f;
         float *gp = nullptr;
         if constexpr (BWD) {
             double num = 0.;
@@ -852,6 +858,10 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             g_bce = ba.w_mask / ((float)num * (float)(p.n_unc + p.n_rand));
             g_dice = ba.w_dice / (float)num;
             gp = ba.gplane + rowid * (long)p.hm * p.wm;
+            // |g| <= |g_bce| |sigma - t| + |g_dice| |2 t D - A| / D^2 sigma (1 - sigma) <= |g_bce| + |g_dice| (2 D + |A|) / (4 D^2)
+            const float gmax = fabsf(g_bce) + fabsf(g_dice) * (2.f * dD + fabsf(dA)) / (4.f * dD * dD);
+            fx_scale = gmax > 0.f ? exp2f(floorf(log2f(2147483648.f / (FX_CAP * gmax)))) : 0.f;
+            fx_inv = fx_scale > 0.f ? 1.f / fx_scale : 0.f;
         }
         int ylo = 0, yhi = p.hm;                              // BWD: the rows of the gradient tile being built
         auto point = [&](float xv, float tt, float u, float v) {
@@ -867,13 +877,14 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 const float x = ((gx + 1.f) * p.wm - 1.f) * 0.5f, y = ((gy + 1.f) * p.hm - 1.f) * 0.5f;
                 const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
                 const float fx = x - x0, fy = y - y0;
+                const float gs = g * fx_scale;
                 if (y0 >= ylo && y0 < yhi) {
-                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x0, g * (1.f - fx) * (1.f - fy));
-                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x1, g * fx * (1.f - fy));
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x0, __float2int_rn(gs * (1.f - fx) * (1.f - fy)));
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x1, __float2int_rn(gs * fx * (1.f - fy)));
                 }
                 if (y1 >= ylo && y1 < yhi) {
-                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x0, g * (1.f - fx) * fy);
-                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x1, g * fx * fy);
+                    if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x0, __float2int_rn(gs * (1.f - fx) * fy));
+                    if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y1 - ylo) * p.wm + x1, __float2int_rn(gs * fx * fy));
                 }
             }
         };
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         if constexpr (BWD) {
             ylo = half == 0 ? 0 : hh; yhi = half == 0 ? hh : p.hm;
             __syncthreads();
-            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gh[i] = 0.f;
+            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gh[i] = 0;
             if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
             __syncthreads();
         }
@@ -1019,7 +1030,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         }
         if constexpr (BWD) {                                  // write the finished half of the row's gradient plane
             __syncthreads();
-            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gp[ylo * p.wm + i] = gh[i];
+            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gp[ylo * p.wm + i] = (float)gh[i] * fx_inv;
         }
         }   // half
         if constexpr (!BWD) {
