@@ -530,6 +530,18 @@ int s2d_aug_warp_frames_u8(const uint8_t *frames, int T, int H0, int W0, void *a
 int s2d_aug_warp_masks_u8(const uint8_t *masks, int N, int T, int H0, int W0, const void *aug_frames_dev, int H1, int W1, uint8_t *out,
                           hipStream_t stream);
 
+/* One target frame of the trainer's video copy-paste loop exactly as written (engine/train_loop.py:445-570): the K copied masks
+ * cur_masks [K][Hc][Wc] -- the source masks at the first frame, the PREVIOUS frame's canvas afterwards (the reference reassigns
+ * copied_instances.gt_masks to the pasted canvas every frame, :512-514, so the masks are transformed cumulatively) -- and the source
+ * frame [3][Hs][Ws] are resized to (h_new, w_new) with F.interpolate(bilinear, align_corners=False) (masks .bool(), image .byte()),
+ * placed at (h_shift, w_shift): canvas u8 [K][H][W]; out_frame = alpha ? pasted source : target; out_tgt [N][H][W] = target masks
+ * minus alpha; inter [K][N] / tarea [N] (before alpha: the ioy matrix of :517-527) and alive [N] (target areas after, :543) as
+ * int32 counts.  K <= 64.  Used by s2d_amd/data/copy_paste.py, which keeps every decision of the loop on these integers. */
+int s2d_copy_paste_frame_u8(const uint8_t *src_frame, int Hs, int Ws, const uint8_t *cur_masks, int K, int Hc, int Wc,
+                            const uint8_t *tgt_frame, const uint8_t *tgt_masks, int N, int H, int W, int h_new, int w_new, int h_shift,
+                            int w_shift, uint8_t *canvas, uint8_t *out_frame, uint8_t *out_tgt, int *inter, int *tarea, int *alive,
+                            hipStream_t stream);
+
 /* Video copy-paste, engine/train_loop.py:441-560: K source masks [K][Hs][Ws] and their frame [3][Hs][Ws] are resized to
  * (h_new, w_new) per target frame with F.interpolate(bilinear, align_corners=False) (image .byte(), masks .bool()), placed at
  * (h_shift, w_shift) and composited over the target clip: out_frames u8 [T][3][H][W]; out_masks u8 [N+K][T][H][W] = the N

@@ -189,9 +189,95 @@ __global__ __launch_bounds__(256) void copy_paste_overlap_kernel(const uint8_t *
     if (threadIdx.x == 0) { counts[k * N + n] = sc[0]; if (k == 0) area[n] = sa[0]; }
 }
 
+// One frame of the reference's loop as it is written (engine/train_loop.py:445-570), including what looks like an accident but is
+// the shipped behaviour: `copied_instances.gt_masks` is REASSIGNED to the pasted canvas at the end of every frame (:512-514), so
+// frame f + 1 deep-copies, resizes and shifts the canvas of frame f -- the copied masks are transformed cumulatively -- while the
+// image patch is resized from the source frame afresh each time (:470).  cur_masks [K][Hc][Wc] is therefore the source masks at
+// the first frame and the previous frame's canvas afterwards.  Outputs: the new canvas [K][H][W] (0 / 1), the composite frame,
+// the target masks minus alpha, and the integers the host's decisions need: inter[k][n] = |canvas_k AND target_n| and
+// tarea[n] = |target_n| (both before alpha is removed: the "ioy" matrix of :517-521), alive[n] = |target_n AND NOT alpha| (:543).
+__global__ __launch_bounds__(256) void copy_paste_frame_kernel(const uint8_t *__restrict__ src_frame, int Hs, int Ws,
+                                                               const uint8_t *__restrict__ cur_masks, int K, int Hc, int Wc,
+                                                               const uint8_t *__restrict__ tgt_frame, const uint8_t *__restrict__ tgt_masks, int N,
+                                                               int H, int W, PasteFrame p, uint8_t *__restrict__ canvas,
+                                                               uint8_t *__restrict__ out_frame, uint8_t *__restrict__ out_tgt,
+                                                               int *__restrict__ inter, int *__restrict__ tarea, int *__restrict__ alive)
+{
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    const bool live = x < W;
+    const int yy = y - p.h_shift, xx = x - p.w_shift;
+    const bool in = live && yy >= 0 && xx >= 0 && yy < p.h_new && xx < p.w_new;
+    int my0 = 0, my1 = 0, mx0 = 0, mx1 = 0, iy0 = 0, iy1 = 0, ix0 = 0, ix1 = 0;
+    float mly = 0.f, mlx = 0.f, ily = 0.f, ilx = 0.f;
+    if (in) {
+        bilin_taps(yy, Hc, p.h_new, my0, my1, mly); bilin_taps(xx, Wc, p.w_new, mx0, mx1, mlx);      // masks: from the current canvas
+        bilin_taps(yy, Hs, p.h_new, iy0, iy1, ily); bilin_taps(xx, Ws, p.w_new, ix0, ix1, ilx);      // image: from the source frame
+    }
+    unsigned long long mbits = 0ull;                                          // bit k: copy k covers this pixel (K <= 64)
+    for (int k = 0; k < K; ++k) {
+        bool m = false;
+        if (in) {
+            const uint8_t *c = cur_masks + (long)k * Hc * Wc;
+            const float v = (1.f - mly) * ((1.f - mlx) * (c[(long)my0 * Wc + mx0] != 0) + mlx * (c[(long)my0 * Wc + mx1] != 0)) +
+                            mly * ((1.f - mlx) * (c[(long)my1 * Wc + mx0] != 0) + mlx * (c[(long)my1 * Wc + mx1] != 0));
+            m = v != 0.f;                                                     // .bool()
+        }
+        if (live) canvas[((long)k * H + y) * W + x] = m;
+        mbits |= (unsigned long long)m << k;
+    }
+    const bool alpha = mbits != 0ull;
+    const int lane = threadIdx.x & 63;
+    for (int n = 0; n < N; ++n) {
+        const bool tv = live && tgt_masks[((long)n * H + y) * W + x] != 0;
+        if (live) out_tgt[((long)n * H + y) * W + x] = tv && !alpha;
+        const unsigned long long bt = __ballot(tv), ba = __ballot(tv && !alpha);
+        if (lane == 0) {
+            if (bt) atomicAdd(tarea + n, (int)__popcll(bt));
+            if (ba) atomicAdd(alive + n, (int)__popcll(ba));
+        }
+        if (bt) {                                                             // wave-uniform
+            for (int k = 0; k < K; ++k) {
+                const unsigned long long bi = __ballot(tv && ((mbits >> k) & 1ull));
+                if (lane == 0 && bi) atomicAdd(inter + k * N + n, (int)__popcll(bi));
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long i = ((long)c * H + y) * W + x;
+        uint8_t v = tgt_frame[i];
+        if (alpha) {
+            const uint8_t *sp = src_frame + (long)c * Hs * Ws;
+            const float f = (1.f - ily) * ((1.f - ilx) * sp[(long)iy0 * Ws + ix0] + ilx * sp[(long)iy0 * Ws + ix1]) +
+                            ily * ((1.f - ilx) * sp[(long)iy1 * Ws + ix0] + ilx * sp[(long)iy1 * Ws + ix1]);
+            v = (uint8_t)f;                                                   // .byte(): truncation
+        }
+        out_frame[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_copy_paste_frame_u8(const uint8_t *src_frame, int Hs, int Ws, const uint8_t *cur_masks, int K, int Hc, int Wc,
+                            const uint8_t *tgt_frame, const uint8_t *tgt_masks, int N, int H, int W, int h_new, int w_new, int h_shift,
+                            int w_shift, uint8_t *canvas, uint8_t *out_frame, uint8_t *out_tgt, int *inter, int *tarea, int *alive,
+                            hipStream_t stream)
+{
+    if (K <= 0 || K > 64 || N < 0 || H <= 0 || W <= 0 || H > 65535 || h_new <= 0 || w_new <= 0) return S2D_ERR_ARG;
+    if (N > 0) {
+        if (s2d_zero_async(inter, sizeof(int) * (size_t)K * N, stream) != S2D_OK || s2d_zero_async(tarea, sizeof(int) * (size_t)N, stream) != S2D_OK ||
+            s2d_zero_async(alive, sizeof(int) * (size_t)N, stream) != S2D_OK)
+            return S2D_ERR_LAUNCH;
+    }
+    PasteFrame p{h_new, w_new, h_shift, w_shift};
+    hipLaunchKernelGGL(copy_paste_frame_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, stream, src_frame, Hs, Ws, cur_masks, K, Hc, Wc, tgt_frame,
+                       tgt_masks, N, H, W, p, canvas, out_frame, out_tgt, inter, tarea, alive);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
 
 int s2d_aug_warp_frames_u8(const uint8_t *frames, int T, int H0, int W0, void *aug_frames_dev, int H1, int W1, uint8_t *out,
                            hipStream_t stream)

@@ -1,6 +1,25 @@
-"""Video copy-paste of the trainer (model_training/mask2former_video/engine/train_loop.py:377-590) for one (source, target)
-clip pair with the clips on the GPU: the random draws and the keep / fall-back rules are the reference's host logic, the
-resize + composite of all T frames is one launch (s2d_copy_paste_u8), the overlap test one small launch and a K x N copy."""
+"""Video copy-paste and sparse-mask densification of the trainer, for clips that live on the GPU: a statement-by-statement mirror of
+model_training/mask2former_video/engine/train_loop.py:30-156 (`propagate_sparse_masks`) and :377-590
+(`CustomSimpleTrainer.copy_and_paste`), pinned by tests/golden/copy_paste.npz (written by the reference's own two functions).
+
+What is mirrored, including what looks accidental in the reference but is what it ships:
+  * the order and number of draws from `random` and `numpy.random` -- also on a rate miss or with no source instance, where the
+    reference still draws the choice, the frame id and every frame's ratio and shifts (:420-441, :461-468);
+  * `copied_instances.gt_masks` is reassigned to the pasted canvas at the end of every frame (:512-514), so the copied masks are
+    resized and shifted CUMULATIVELY from frame to frame while the image patch is resized from the source frame each time;
+  * a frame without target instances appends the running `copied_instances` object itself (:524-525): such frames all show the masks
+    that object holds when the loop ends;
+  * frame 0 decides: a copy covering >= 50 % of a target's area (or a target of zero area: 0/0 is not < 0.5) cancels the paste for
+    every frame (:527-535); on later frames a zero-area target empties the copies from there on (nan is not < 2.0);
+  * COPY_PASTE_DENSIFY_SPARSE with a paste due only densifies (:433-439); otherwise the result is densified at the end (:566-569);
+    a clip whose frames end with different instance counts falls back to the untouched target (:573-580).
+
+Clips are the mapper's dicts (data_video/dataset_mapper.py:306-404) with device tensors: {"image": T x uint8 [3,H,W], "instances":
+T x {"gt_masks": bool [n,H,W], "gt_ids": int64 [n], "gt_classes": int64 [n]}} -- the form KDVideoMaskFormer.forward accepts.  The
+resize / paste / composite of a frame is one launch (s2d_copy_paste_frame_u8); all T frames are enqueued before the single small
+device-to-host copy of the integer overlap / area tables that the loop's decisions are replayed on.  Boxes are not produced (the
+path never reads them)."""
+import copy
 import random
 
 import numpy as np
@@ -13,58 +32,219 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def copy_and_paste_clip(src_frames, src_masks, tgt_frames, tgt_masks, rate=1.0, random_num=False, min_ratio=0.8, max_ratio=1.0):
-    """src_frames u8 [Ts,3,Hs,Ws], src_masks u8 [Ks,Ts,Hs,Ws] (instances of the labelled clip), tgt_frames u8 [T,3,H,W],
-    tgt_masks u8 [N,T,H,W] -> (frames [T,3,H,W], masks [N',T,H,W], info dict).  Follows :417-560 per target clip:
-      * with probability `rate` (DATALOADER.COPY_PASTE_RATE) copy num_copy instances (all, or 1..Ks-1 when random_num) chosen
-        without replacement from ONE random source frame (:420-441);
-      * per target frame a fresh resize ratio in [min_ratio, max_ratio] and shift (:461-468); frame 0 decides which copies
-        survive: a copy covering >= 50 % of some target instance's area cancels the paste for the whole clip (:515-532);
-      * targets lose the pasted area, targets left empty in a frame are dropped there, and a clip whose frames end up with
-        different instance counts falls back to the unmodified target (:549-560, :573-580).
-    `propagate_sparse_masks` (densification of sparse annotations) is not part of this step."""
-    Ts, _, Hs, Ws = src_frames.shape
-    T, _, H, W = tgt_frames.shape
-    Ks, N = src_masks.shape[0], tgt_masks.shape[0]
-    info = {"pasted": False}
-    if not (rate >= random.random() and Ks > 0):
-        return tgt_frames, tgt_masks, info
-    num_copy = (1 if Ks == 1 else int(np.random.randint(1, max(1, Ks)))) if random_num else Ks
-    choice = np.random.choice(Ks, num_copy, replace=False)
-    frame_id = int(np.random.randint(1, max(1, Ts))) - 1
-    sm = src_masks[torch.as_tensor(choice, device=src_masks.device), frame_id].contiguous()      # [K,Hs,Ws]
-    sf = src_frames[frame_id].contiguous()
-    K = num_copy
-    pf = np.zeros((T, 4), np.int32)
-    for f in range(T):
-        ratio = random.uniform(min_ratio, max_ratio)
+def _frame(masks, ids, classes):
+    return {"gt_masks": masks, "gt_ids": ids, "gt_classes": classes}
+
+
+def _ids(fr, key="gt_ids"):
+    v = fr[key]
+    return v.detach().cpu().numpy().astype(np.int64) if isinstance(v, torch.Tensor) else np.asarray(v, np.int64)
+
+
+def _masks(fr, device=None):
+    m = fr["gt_masks"]
+    m = m.tensor if hasattr(m, "tensor") else torch.as_tensor(m)
+    return m.to(device=device or m.device, dtype=torch.bool)
+
+
+# ------------------------------------------------------------------------------------------------ propagate_sparse_masks (:30-156)
+def _translate(mask_hw, dx, dy):
+    """:58-68"""
+    H, W = mask_hw.shape[-2], mask_hw.shape[-1]
+    outm = torch.zeros_like(mask_hw)
+    xs, xt = slice(max(0, dx), min(W, W + dx)), slice(max(0, -dx), min(W, W - dx))
+    ys, yt = slice(max(0, dy), min(H, H + dy)), slice(max(0, -dy), min(H, H - dy))
+    if (xt.stop - xt.start) > 0 and (yt.stop - yt.start) > 0:
+        outm[yt, xt] = mask_hw[ys, xs]
+    return outm
+
+
+def propagate_sparse_masks(instances_per_frame, max_shift=2):
+    """fill a frame where an already-seen instance id is missing with that id's most recent mask, jittered by up to max_shift pixels
+    (two `random.randint` draws per filled instance, x then y).  Returns new per-frame dicts; the inputs are not modified."""
+    if not instances_per_frame:
+        return instances_per_frame
+    out = [_frame(_masks(fr), _ids(fr), _ids(fr, "gt_classes")) for fr in instances_per_frame]
+    last_seen = {}                                                # tid -> (mask [H,W], class): insertion-ordered, as the reference's dict
+    for t, fr in enumerate(out):
+        masks_t, ids_t, cls_t = fr["gt_masks"], fr["gt_ids"], fr["gt_classes"]
+        n = len(ids_t)
+        for i in range(n):
+            if masks_t.numel() > 0:
+                last_seen[int(ids_t[i])] = (masks_t[i], int(cls_t[i]) if i < len(cls_t) else None)
+        present = set(int(x) for x in ids_t.tolist()) if n else set()
+        to_fill = [tid for tid in last_seen if tid not in present]
+        if not to_fill:
+            continue
+        mask_list = [masks_t] if masks_t.numel() > 0 else []
+        new_classes, new_ids = [], []
+        for tid in to_fill:
+            pm, pc = last_seen[tid]
+            dx = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
+            dy = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
+            mask_list.append(_translate(pm, dx, dy)[None])
+            new_ids.append(tid)
+            if pc is not None:
+                new_classes.append(pc)
+        all_masks = torch.cat(mask_list, 0)
+        if n:
+            classes = np.concatenate([cls_t, np.asarray(new_classes, np.int64)]) if new_classes else cls_t
+            ids = np.concatenate([ids_t, np.asarray(new_ids, np.int64)])
+        else:
+            classes, ids = np.asarray(new_classes, np.int64), np.asarray(new_ids, np.int64)
+        out[t] = _frame(all_masks, ids, classes)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ copy_and_paste (:377-590)
+class _Copied:
+    """the loop's `copied_instances`: a mutable object the reference both reassigns fields of and appends to its output list"""
+
+    def __init__(self, masks, ids, classes):
+        self.masks, self.ids, self.classes = masks, ids, classes
+
+    def __len__(self):
+        return len(self.ids)
+
+
+def copy_and_paste(sources, targets, rate=1.0, random_num=False, min_ratio=0.5, max_ratio=1.0, densify_sparse=False):
+    """`CustomSimpleTrainer.copy_and_paste(sources, targets)` with cfg_COPY_PASTE_RATE / _RANDOM_NUM / _MIN_RATIO / _MAX_RATIO /
+    _DENSIFY_SPARSE as keyword arguments.  Returns the new target clips (a clip that was not pasted is returned as it came in)."""
+    outs = []
+    for source, target in zip(sources, targets):
+        outs.append(_pair(source, target, rate, random_num, min_ratio, max_ratio, densify_sparse))
+    return outs
+
+
+def _pair(source, target, rate, random_num, lo, hi, densify):
+    src_inst, src_img = source["instances"], source["image"]
+    tgt_inst, tgt_img = target["instances"], target["image"]
+    T = len(tgt_inst)
+    dev = tgt_img[0].device
+    n_src = len(_ids(src_inst[0]))
+    if rate >= random.random() and n_src > 0:                                            # :420-428
+        num_copy = (1 if n_src == 1 else int(np.random.randint(1, max(1, n_src)))) if random_num else n_src
+    else:
+        num_copy = 0
+    if num_copy > 0 and densify:                                                         # :430-439: densify only
+        new = dict(target)
+        try:
+            new["instances"] = propagate_sparse_masks(tgt_inst, max_shift=2)
+        except Exception:
+            pass
+        return _same_counts_or(new, target)
+    choice = np.random.choice(n_src, num_copy, replace=False)                            # :441
+    frame_id = int(np.random.randint(1, max(1, len(src_inst)))) - 1                      # :443
+    sm = _masks(src_inst[frame_id], dev)[torch.as_tensor(choice, dtype=torch.long, device=dev)]
+    copied = _Copied(sm, _ids(src_inst[frame_id])[choice], _ids(src_inst[frame_id], "gt_classes")[choice])
+    sf = src_img[frame_id].to(dev).contiguous()
+    Hs, Ws = sf.shape[-2:]
+    # every frame's draws first (they do not depend on the data), then all frames enqueued, then ONE copy of the integer tables
+    geo = []
+    for f in range(T):                                                                   # :461-468
+        H, W = tgt_img[f].shape[-2:]
+        ratio = random.uniform(lo, hi)
         w_new, h_new = int(ratio * W), int(ratio * H)
-        pf[f] = (h_new, w_new, random.randint(0, max(0, H - h_new)), random.randint(0, max(0, W - w_new)))
-    dev = tgt_frames.device
-    keep = np.ones(K, np.uint8)
-    if N > 0:
-        counts = torch.empty((K, N), device=dev, dtype=torch.int32)
-        area = torch.empty((N,), device=dev, dtype=torch.int32)
-        lib().call("s2d_copy_paste_overlap", tgt_masks.contiguous(), N, T, H, W, sm, K, Hs, Ws, int(pf[0, 0]), int(pf[0, 1]), int(pf[0, 2]),
-                   int(pf[0, 3]), counts, area, _stream())
-        c, a = counts.cpu().numpy().astype(np.float32), area.cpu().numpy().astype(np.float32)
+        w_shift = random.randint(0, max(0, W - w_new))
+        h_shift = random.randint(0, max(0, H - h_new))
+        geo.append((h_new, w_new, h_shift, w_shift))
+    K = num_copy
+    if K == 0:                                                                           # :475-488: every frame keeps the original
+        return _finish(target, [t for t in tgt_img], [_frame(_masks(fr, dev), _ids(fr), _ids(fr, "gt_classes")) for fr in tgt_inst], target)
+    cur = sm.to(torch.uint8).contiguous()
+    canv, comp, tout, stats, ns = [], [], [], [], []
+    for f in range(T):
+        tm = _masks(tgt_inst[f], dev).to(torch.uint8).contiguous()
+        N = tm.shape[0]
+        H, W = tgt_img[f].shape[-2:]
+        canvas = torch.empty((K, H, W), device=dev, dtype=torch.uint8)
+        of = torch.empty_like(tgt_img[f]); ot = torch.empty_like(tm)
+        st = torch.empty((max(K * N + 2 * N, 1),), device=dev, dtype=torch.int32)
+        lib().call("s2d_copy_paste_frame_u8", sf, Hs, Ws, cur, K, cur.shape[1], cur.shape[2], tgt_img[f].contiguous(), tm, N, H, W, *geo[f], canvas, of,
+                   ot, st, st[K * N:], st[K * N + N:], _stream())
+        canv.append(canvas); comp.append(of); tout.append(ot); stats.append(st); ns.append(N)
+        cur = canvas                                                                     # :512-514: the next frame transforms this canvas
+    host = torch.cat(stats).cpu().numpy()                                                # the one synchronisation of the pair
+    tabs, o = [], 0
+    for f in range(T):
+        N = ns[f]
+        n = max(K * N + 2 * N, 1)
+        tabs.append((host[o:o + K * N].reshape(K, N), host[o + K * N:o + K * N + N], host[o + K * N + N:o + K * N + 2 * N]))
+        o += n
+    # replay of the loop's decisions (:516-560) on the integer tables
+    new_img, new_inst = [], []
+    sum_keep = None
+    for f in range(T):
+        N = ns[f]
+        orig = _frame(_masks(tgt_inst[f], dev), _ids(tgt_inst[f]), _ids(tgt_inst[f], "gt_classes"))
+        if len(copied) == 0:                                                             # :475-488
+            new_img.append(tgt_img[f]); new_inst.append(orig)
+            continue
+        copied.masks = canv[f].bool()                                                    # :512 (mutates the running object)
+        if N == 0:                                                                       # :516-525: the object itself is appended
+            new_img.append(comp[f]); new_inst.append(copied)
+            continue
+        inter, tarea, alive = tabs[f]
         with np.errstate(divide="ignore", invalid="ignore"):
-            ioy = c / a[None, :]                                   # inter / target area, float32 as in the reference (0/0 = nan: not < 0.5)
-        keep = (ioy.max(1) < 0.5).astype(np.uint8)
-        if keep.sum() < K:                                         # :529-532 on frame 0 -> every frame keeps the original
-            info["cancelled"] = "a copy covers half of a target instance"
-            return tgt_frames, tgt_masks, info
-    out_f = torch.empty_like(tgt_frames)
-    out_m = torch.empty((N + K, T, H, W), device=dev, dtype=torch.uint8)
-    lib().call("s2d_copy_paste_u8", tgt_frames.contiguous(), tgt_masks.contiguous(), N, T, H, W, sf, sm, K, Hs, Ws,
-               torch.from_numpy(pf).to(dev), torch.from_numpy(keep).to(dev), out_f, out_m, _stream())
-    if N > 0:
-        alive = out_m[:N].flatten(2).any(-1).bool()                       # [N,T]: targets with area left, per frame (:549)
-        per_frame = alive.sum(0)
-        if int(per_frame.min()) != int(per_frame.max()) or not bool(alive.all(1).eq(alive.any(1)).all()):
-            info["cancelled"] = "instance counts differ between frames"
-            return tgt_frames, tgt_masks, info
-        sel = torch.cat([alive[:, 0], torch.ones(K, dtype=torch.bool, device=dev)])
-        out_m = out_m[sel]
-    info.update(pasted=True, choice=choice.tolist(), frame_id=frame_id, paste_frames=pf.tolist())
-    return out_f, out_m, info
+            ioy = inter.astype(np.float32) / tarea.astype(np.float32)[None, :]           # :394-399 mode 'ioy', float32
+        mx = np.where(np.isnan(ioy).any(1), np.float32("nan"), ioy.max(1))               # torch.max propagates nan
+        if f == 0:
+            keep = mx < 0.5
+            sum_keep = int(keep.sum())
+        else:
+            if sum_keep is None:
+                raise RuntimeError("frame 0 has no target instance but a later frame has: the reference reads `sum_keep` before assignment here")
+            keep = mx < 2.0
+        if sum_keep < len(keep):                                                         # :533-536
+            new_img.append(tgt_img[f]); new_inst.append(orig)
+            continue
+        if keep.all():
+            copied = _Copied(copied.masks, copied.ids, copied.classes)                   # :538 indexing makes a new object
+            live = alive > 0
+            sel = torch.as_tensor(np.nonzero(live)[0], dtype=torch.long, device=dev)
+            masks = torch.cat([tout[f].bool()[sel], copied.masks], 0)
+            new_img.append(comp[f])
+            new_inst.append(_frame(masks, np.concatenate([orig["gt_ids"][live], copied.ids]), np.concatenate([orig["gt_classes"][live], copied.classes])))
+        else:
+            # nan row (a target of zero area on a later frame): every copy is dropped, alpha is empty, the frame keeps its image and
+            # its targets of non-zero area; the following frames see an empty `copied_instances`
+            assert not keep.any()
+            copied = _Copied(copied.masks[:0], copied.ids[:0], copied.classes[:0])
+            live = tarea > 0
+            sel = torch.as_tensor(np.nonzero(live)[0], dtype=torch.long, device=dev)
+            new_img.append(tgt_img[f])
+            new_inst.append(_frame(orig["gt_masks"][sel], orig["gt_ids"][live], orig["gt_classes"][live]))
+    frames = [fr if isinstance(fr, dict) else _frame(fr.masks, fr.ids, fr.classes) for fr in new_inst]   # aliases resolve to their final state
+    return _finish(target, new_img, frames, target)
+
+
+def _finish(target, images, frames, original):
+    new = dict(target)
+    new["image"] = images
+    try:
+        new["instances"] = propagate_sparse_masks(frames, max_shift=2)                   # :566-569
+    except Exception:
+        new["instances"] = frames
+    return _same_counts_or(new, original)
+
+
+def _same_counts_or(new, original):
+    """:573-580: all frames of a clip must end with the same number of instances, else the untouched target is returned"""
+    counts = {len(_ids(fr)) for fr in new["instances"]}
+    return new if len(counts) == 1 else original
+
+
+def copy_and_paste_clip(src_frames, src_masks, tgt_frames, tgt_masks, rate=1.0, random_num=False, min_ratio=0.8, max_ratio=1.0):
+    """dense-tensor convenience form: src_frames u8 [Ts,3,Hs,Ws], src_masks u8 [Ks,Ts,Hs,Ws], tgt_frames u8 [T,3,H,W], tgt_masks u8
+    [N,T,H,W] (every instance present in every frame) -> (frames [T,3,H,W], masks [N',T,H,W], info).  Runs copy_and_paste on the
+    equivalent per-frame clips."""
+    Ks, N, T = src_masks.shape[0], tgt_masks.shape[0], tgt_frames.shape[0]
+    ar = lambda n, o=0: np.arange(n, dtype=np.int64) + o
+    src = {"image": [f for f in src_frames], "instances": [_frame(src_masks[:, t].bool(), ar(Ks), np.zeros(Ks, np.int64)) for t in range(src_frames.shape[0])]}
+    tgt = {"image": [f for f in tgt_frames], "instances": [_frame(tgt_masks[:, t].bool(), ar(N, 1000), np.zeros(N, np.int64)) for t in range(T)]}
+    out = copy_and_paste([src], [tgt], rate, random_num, min_ratio, max_ratio)[0]
+    if out is tgt:
+        return tgt_frames, tgt_masks, {"pasted": False}
+    frames = torch.stack(list(out["image"]))
+    masks = torch.stack([fr["gt_masks"] for fr in out["instances"]], 1).to(torch.uint8)
+    return frames, masks, {"pasted": bool((frames != tgt_frames).any()) or masks.shape[0] != N}

@@ -784,6 +784,182 @@ def g_sampling():
     print("  wrote sampling.json:", {k: len(v) for k, v in out.items()})
 
 
+from copy_paste_cases import COPY_PASTE_CASES, copy_paste_case  # noqa: E402,F401
+
+
+def g_copy_paste():
+    """engine/train_loop.py:30-156 propagate_sparse_masks and :377-590 CustomSimpleTrainer.copy_and_paste, called as they lie.
+    detectron2's structures are absent: Instances / BitMasks / Boxes are stood in for by small classes with the documented
+    behaviour of the few operations the two functions use (field dict + indexing + cat; .tensor + get_bounding_boxes; scale) --
+    the pixel results pinned here (composited frames, instance masks, ids, the fall-back decisions and the state of both RNG
+    streams after the call) do not depend on anything else.  tests/golden/copy_paste.npz."""
+    import copy
+    import random
+    import types
+    R.install()
+
+    class Boxes:
+        def __init__(self, t):
+            self.tensor = t
+
+        device = property(lambda self: self.tensor.device)
+
+        def scale(self, sx, sy):
+            self.tensor[:, 0::2] *= sx
+            self.tensor[:, 1::2] *= sy
+
+        def __getitem__(self, i):
+            t = self.tensor[i]
+            return Boxes(t[None] if t.dim() == 1 else t)
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+        def to(self, *a, **k):
+            return Boxes(self.tensor.to(*a, **k))
+
+        @staticmethod
+        def cat(bs):
+            return Boxes(torch.cat([b.tensor for b in bs], 0))
+
+    class BitMasks:
+        def __init__(self, t):
+            self.tensor = torch.as_tensor(t).to(torch.bool)
+
+        device = property(lambda self: self.tensor.device)
+
+        def __getitem__(self, i):
+            t = self.tensor[i]
+            return BitMasks(t[None] if t.dim() == 2 else t)
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+        def to(self, *a, **k):
+            return BitMasks(self.tensor.to(*a, **k))
+
+        def get_bounding_boxes(self):
+            b = torch.zeros((self.tensor.shape[0], 4), dtype=torch.float32)
+            xa, ya = self.tensor.any(1), self.tensor.any(2)
+            for i in range(self.tensor.shape[0]):
+                x, y = torch.where(xa[i])[0], torch.where(ya[i])[0]
+                if len(x) and len(y):
+                    b[i] = torch.as_tensor([x[0], y[0], x[-1] + 1, y[-1] + 1], dtype=torch.float32)
+            return Boxes(b)
+
+        @staticmethod
+        def cat(ms):
+            return BitMasks(torch.cat([m.tensor for m in ms], 0))
+
+    class Instances:
+        def __init__(self, image_size, **kw):
+            object.__setattr__(self, "_image_size", image_size)
+            object.__setattr__(self, "_fields", {})
+            for k, v in kw.items():
+                self.set(k, v)
+
+        image_size = property(lambda self: self._image_size)
+
+        def __setattr__(self, name, val):
+            if name.startswith("_"):
+                object.__setattr__(self, name, val)
+            else:
+                self.set(name, val)
+
+        def __getattr__(self, name):
+            if name == "_fields" or name not in self._fields:
+                raise AttributeError(name)
+            return self._fields[name]
+
+        def set(self, name, value):
+            self._fields[name] = value
+
+        def has(self, name):
+            return name in self._fields
+
+        def get(self, name):
+            return self._fields[name]
+
+        def get_fields(self):
+            return self._fields
+
+        def to(self, *a, **k):
+            r = Instances(self._image_size)
+            for kk, v in self._fields.items():
+                r.set(kk, v.to(*a, **k) if hasattr(v, "to") else v)
+            return r
+
+        def __getitem__(self, item):
+            if isinstance(item, int):
+                item = slice(item, None, len(self))
+            r = Instances(self._image_size)
+            for k, v in self._fields.items():
+                r.set(k, v[item])
+            return r
+
+        def __len__(self):
+            for v in self._fields.values():
+                return len(v)
+            raise NotImplementedError("Empty Instances does not support __len__!")
+
+        @staticmethod
+        def cat(lst):
+            r = Instances(lst[0]._image_size)
+            for k in lst[0]._fields:
+                vs = [i.get(k) for i in lst]
+                r.set(k, torch.cat(vs, 0) if isinstance(vs[0], torch.Tensor) else type(vs[0]).cat(vs))
+            return r
+
+    for name, attrs in {"detectron2.utils.events": dict(get_event_storage=lambda: None), "detectron2.engine": dict(SimpleTrainer=object),
+                        "detectron2.structures.instances": dict(Instances=Instances)}.items():
+        m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m
+    st = sys.modules["detectron2.structures"]; st.BitMasks = BitMasks; st.Boxes = Boxes; st.Instances = Instances
+    sys.modules["detectron2.utils"].comm = sys.modules["detectron2.utils.comm"]
+    m = types.ModuleType("mask2former_video.data_video.build"); m.get_detection_dataset_dicts = None; m.build_detection_train_loader = None
+    sys.modules["mask2former_video.data_video.build"] = m
+    sys.modules["mask2former_video.data_video.dataset_mapper"].YTVISDatasetMapper = object
+    R._pkg("mask2former_video.engine", os.path.join(R.MT, "mask2former_video", "engine"))
+    tl = R.ref("mask2former_video.engine.train_loop")
+
+    def to_ref(clip, hw):
+        inst = []
+        for fr in clip["instances"]:
+            i = Instances(tuple(hw))
+            m = BitMasks(torch.from_numpy(fr["gt_masks"]))
+            i.gt_masks = m
+            i.gt_boxes = m.get_bounding_boxes()
+            i.gt_classes = torch.from_numpy(fr["gt_classes"])
+            i.gt_ids = torch.from_numpy(fr["gt_ids"])
+            inst.append(i)
+        return {"image": [torch.from_numpy(f.copy()) for f in clip["image"]], "instances": inst}
+
+    out = {}
+    for case in COPY_PASTE_CASES:
+        src, tgt = copy_paste_case(case)
+        c = case["cfg"]
+        self_ = types.SimpleNamespace(cfg_COPY_PASTE_RATE=c["rate"], cfg_COPY_PASTE_RANDOM_NUM=c["random_num"], cfg_COPY_PASTE_MIN_RATIO=c["lo"],
+                                      cfg_COPY_PASTE_MAX_RATIO=c["hi"], cfg_COPY_PASTE_DENSIFY_SPARSE=c["densify"], cfg_VISUALIZE_COPY_PASTE=False)
+        random.seed(case["seed"]); np.random.seed(case["seed"])
+        res = tl.CustomSimpleTrainer.copy_and_paste(self_, [to_ref(src, case["src_hw"])], [to_ref(tgt, case["hw"])])[0]
+        n = case["name"]
+        out[f"{n}.rng"] = np.array([random.random(), np.random.rand()])          # the state both streams are left in
+        out[f"{n}.image"] = np.stack([f.numpy() for f in res["image"]])
+        for t, fr in enumerate(res["instances"]):
+            out[f"{n}.masks{t}"] = np.packbits(fr.gt_masks.tensor.numpy().astype(np.uint8), axis=-1)
+            out[f"{n}.ids{t}"] = fr.gt_ids.numpy().astype(np.int64)
+            out[f"{n}.classes{t}"] = fr.gt_classes.numpy().astype(np.int64)
+        print("  ", n, "instances per frame", [len(fr) for fr in res["instances"]], "image changed", bool((out[f"{n}.image"] != np.stack(tgt["image"])).any()))
+        # propagate_sparse_masks on its own, on the case's raw target clip
+        random.seed(case["seed"] + 1000)
+        pr = tl.propagate_sparse_masks(to_ref(tgt, case["hw"])["instances"], max_shift=2)
+        out[f"{n}.prop_rng"] = np.array([random.random()])
+        for t, fr in enumerate(pr):
+            out[f"{n}.prop_masks{t}"] = np.packbits(fr.gt_masks.tensor.numpy().astype(np.uint8), axis=-1)
+            out[f"{n}.prop_ids{t}"] = fr.gt_ids.numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "copy_paste.npz"), **out)
+
+
+
 def g_config():
     """the shipped KD training configuration as the trainer resolves it: configs/imagenet_video/
     ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml merged over its _BASE_ (yaml data, key -> value; python tuples
@@ -829,7 +1005,7 @@ def main():
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats, g_sampling):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats, g_sampling, g_copy_paste):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -45,78 +45,88 @@ def test_clip_augmentation_vs_oracle(oracle):
     np.testing.assert_array_equal(got_f.cpu().numpy(), oracle.aug_warp_frames(fr, P, hw))
 
 
-def _reference_copy_paste(src_frame, src_masks, tgt_frames, tgt_masks, pf, keep):
-    """engine/train_loop.py:461-548 for one clip, the drawn numbers given: returns (frames [T,3,H,W], masks [N+K,T,H,W])"""
-    T, _, H, W = tgt_frames.shape
-    K, N = src_masks.shape[0], tgt_masks.shape[0]
-    out_f, out_m = [], []
-    for f in range(T):
-        h_new, w_new, h_shift, w_shift = (int(v) for v in pf[f])
-        img_new = F.interpolate(src_frame[None].float(), size=(h_new, w_new), mode="bilinear", align_corners=False).byte().squeeze(0)
-        m_new = F.interpolate(src_masks[None].float(), size=(h_new, w_new), mode="bilinear", align_corners=False).bool().squeeze(0)
-        masks_all = torch.zeros(K, H, W)
-        image_all = torch.zeros_like(tgt_frames[f])
-        image_all[:, h_shift:h_shift + h_new, w_shift:w_shift + w_new] += img_new
-        masks_all[:, h_shift:h_shift + h_new, w_shift:w_shift + w_new] += m_new
-        copied = masks_all.bool() & torch.from_numpy(keep.astype(bool))[:, None, None]
-        alpha = copied.sum(0) > 0
-        out_f.append((alpha * image_all.byte()) + (~alpha * tgt_frames[f]))
-        out_m.append(torch.cat([(~alpha) * tgt_masks[:, f].bool(), copied]))
-    return torch.stack(out_f), torch.stack(out_m, 1).to(torch.uint8)
+def _golden_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from copy_paste_cases import COPY_PASTE_CASES, copy_paste_case
+    return COPY_PASTE_CASES, copy_paste_case
 
 
-def test_copy_paste_vs_reference_arithmetic():
-    from s2d_amd._lib import lib
-    T, H, W, N = 3, 96, 144, 3
-    Hs, Ws, K = 80, 112, 2
-    tf, tm = _clip(31, T, H, W, N)
-    sf, sm = _clip(32, 1, Hs, Ws, K)
-    pf = np.array([[70, 100, 5, 20], [96, 144, 0, 0], [48, 72, 40, 60]], np.int32)
-    for keep in (np.array([1, 1], np.uint8), np.array([0, 1], np.uint8)):
-        dev = "cuda"
-        out_f = torch.empty((T, 3, H, W), device=dev, dtype=torch.uint8)
-        out_m = torch.empty((N + K, T, H, W), device=dev, dtype=torch.uint8)
-        lib().call("s2d_copy_paste_u8", torch.from_numpy(tf).to(dev), torch.from_numpy(tm).to(dev), N, T, H, W, torch.from_numpy(sf[0]).to(dev),
-                   torch.from_numpy(sm[:, 0].copy()).to(dev), K, Hs, Ws, torch.from_numpy(pf).to(dev), torch.from_numpy(keep).to(dev), out_f, out_m,
-                   torch.cuda.current_stream().cuda_stream)
-        ref_f, ref_m = _reference_copy_paste(torch.from_numpy(sf[0]), torch.from_numpy(sm[:, 0].copy()), torch.from_numpy(tf), torch.from_numpy(tm), pf, keep)
-        np.testing.assert_array_equal(out_m.cpu().numpy(), ref_m.numpy())
-        d = (out_f.cpu().int() - ref_f.int()).abs()
-        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3       # .byte() of a float a hair below / above an integer
-    # the overlap integers behind the "copy covers half of a target" rule (:515-527)
-    counts = torch.empty((K, N), device="cuda", dtype=torch.int32)
-    area = torch.empty((N,), device="cuda", dtype=torch.int32)
-    lib().call("s2d_copy_paste_overlap", torch.from_numpy(tm).cuda(), N, T, H, W, torch.from_numpy(sm[:, 0].copy()).cuda(), K, Hs, Ws,
-               int(pf[0, 0]), int(pf[0, 1]), int(pf[0, 2]), int(pf[0, 3]), counts, area, torch.cuda.current_stream().cuda_stream)
-    _, ref_m = _reference_copy_paste(torch.from_numpy(sf[0]), torch.from_numpy(sm[:, 0].copy()), torch.from_numpy(tf), torch.from_numpy(tm), pf,
-                                     np.ones(K, np.uint8))
-    x = ref_m[N:, 0].reshape(K, -1).float(); y = torch.from_numpy(tm[:, 0]).reshape(N, -1).float()
-    np.testing.assert_array_equal(counts.cpu().numpy(), (x @ y.t()).numpy().astype(np.int32))
-    np.testing.assert_array_equal(area.cpu().numpy(), y.sum(1).numpy().astype(np.int32))
+def _to_dev(clip):
+    return {"image": [torch.from_numpy(f.copy()).cuda() for f in clip["image"]],
+            "instances": [{"gt_masks": torch.from_numpy(fr["gt_masks"]).cuda(), "gt_ids": fr["gt_ids"].copy(), "gt_classes": fr["gt_classes"].copy()}
+                          for fr in clip["instances"]]}
 
 
-def test_copy_and_paste_clip_end_to_end():
-    """the driver with the reference's draws: a paste that happens adds K instances to every frame, keeps the untouched pixels,
-    and cancels cleanly when a copy would cover half of a target"""
+def test_copy_and_paste_vs_reference_goldens():
+    """`CustomSimpleTrainer.copy_and_paste` (engine/train_loop.py:377-590) on the device against what the reference's own function
+    returned for the same seeded clips and the same `random` / `numpy.random` seeds (tests/golden/copy_paste.npz): every frame's
+    composite image, every instance mask, ids and classes, the fall-back decisions -- and the state both RNG streams are left in,
+    i.e. the draws are consumed exactly as the reference consumes them (also on a rate miss and with no source instance).  Cases:
+    plain paste, sparse targets, COPY_PASTE_RANDOM_NUM, cancel by overlap, rate miss, DENSIFY_SPARSE, no source / no target
+    instances."""
+    from tests.conftest import golden
+    from s2d_amd.data import copy_and_paste
+    g = golden("copy_paste")
+    cases, make = _golden_cases()
+    for case in cases:
+        n, c = case["name"], case["cfg"]
+        src, tgt = make(case)
+        random.seed(case["seed"]); np.random.seed(case["seed"])
+        out = copy_and_paste([_to_dev(src)], [_to_dev(tgt)], rate=c["rate"], random_num=c["random_num"], min_ratio=c["lo"], max_ratio=c["hi"],
+                             densify_sparse=c["densify"])[0]
+        np.testing.assert_array_equal(np.array([random.random(), np.random.rand()]), g[f"{n}.rng"], err_msg=f"{n}: RNG streams")
+        img = np.stack([f.cpu().numpy() for f in out["image"]])
+        d = np.abs(img.astype(np.int32) - g[f"{n}.image"].astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (n, int(d.max()), float((d != 0).mean()))    # .byte() of a float a hair from an integer
+        W = img.shape[-1]
+        for t, fr in enumerate(out["instances"]):
+            want = np.unpackbits(g[f"{n}.masks{t}"], axis=-1)[..., :W].astype(bool)
+            got = fr["gt_masks"].cpu().numpy().astype(bool)
+            assert got.shape == want.shape, (n, t, got.shape, want.shape)
+            np.testing.assert_array_equal(got, want, err_msg=f"{n}: masks of frame {t}")
+            np.testing.assert_array_equal(np.asarray(fr["gt_ids"]), g[f"{n}.ids{t}"], err_msg=f"{n}: ids of frame {t}")
+            np.testing.assert_array_equal(np.asarray(fr["gt_classes"]), g[f"{n}.classes{t}"], err_msg=f"{n}: classes of frame {t}")
+
+
+def test_propagate_sparse_masks_vs_reference_goldens():
+    """engine/train_loop.py:30-156 on the raw target clips of the same cases: filled masks (the +-2 px jitter draws included), id
+    order, and the RNG state afterwards"""
+    from tests.conftest import golden
+    from s2d_amd.data import propagate_sparse_masks
+    g = golden("copy_paste")
+    cases, make = _golden_cases()
+    for case in cases:
+        n = case["name"]
+        _, tgt = make(case)
+        random.seed(case["seed"] + 1000)
+        out = propagate_sparse_masks(_to_dev(tgt)["instances"], max_shift=2)
+        np.testing.assert_array_equal(np.array([random.random()]), g[f"{n}.prop_rng"])
+        W = tgt["image"][0].shape[-1]
+        for t, fr in enumerate(out):
+            want = np.unpackbits(g[f"{n}.prop_masks{t}"], axis=-1)[..., :W].astype(bool)
+            np.testing.assert_array_equal(fr["gt_masks"].cpu().numpy().astype(bool), want, err_msg=f"{n}: frame {t}")
+            np.testing.assert_array_equal(np.asarray(fr["gt_ids"]), g[f"{n}.prop_ids{t}"])
+
+
+def test_copy_and_paste_clip_dense_form():
+    """the dense-tensor convenience form: a paste that happens adds instances to every frame and leaves the pixels outside the
+    pasted masks alone; a rate miss returns the inputs"""
     from s2d_amd.data import copy_and_paste_clip
     T, H, W = 3, 96, 144
     tf, tm = _clip(41, T, H, W, 2)
-    sf, sm = _clip(42, 2, 80, 112, 2)
+    sf, sm = _clip(42, 3, 80, 112, 2)
     args = [torch.from_numpy(a).cuda() for a in (sf, sm, tf, tm)]
     random.seed(1); np.random.seed(1)
-    seen = {"pasted": 0, "cancelled": 0}
+    pasted = 0
     for _ in range(12):
         f, m, info = copy_and_paste_clip(*args, rate=1.0, min_ratio=0.3, max_ratio=0.6)
         if info["pasted"]:
-            seen["pasted"] += 1
+            pasted += 1
             assert f.shape == args[2].shape and m.shape[1:] == args[3].shape[1:] and m.shape[0] >= 2
             changed = (f != args[2]).any(1)                            # [T,H,W]
-            pasted_area = m[-2:].any(0)
-            assert bool((changed & ~pasted_area).sum() == 0)           # pixels outside the pasted masks are the target's
-            assert bool((m[:-2].bool() & pasted_area[None]).sum() == 0)
-        else:
-            seen["cancelled"] += 1
-            assert f is args[2] and m is args[3]
-    assert seen["pasted"] > 0
+            assert bool((changed & ~m[2:].any(0).bool()).sum() == 0)   # pixels outside the pasted masks are the target's
+    assert pasted > 0
     f, m, info = copy_and_paste_clip(*args, rate=0.0)
-    assert f is args[2] and not info["pasted"]
+    assert not info["pasted"] and torch.equal(f, args[2])
