@@ -92,39 +92,81 @@ __global__ __launch_bounds__(256) void visibility_kernel(const uint8_t *__restri
 
 // K1: corr[t][n][i][j] = sum_c nb[t][n][i][c] * support[n][j][c], nb = bilinear samples of fmap[t] (NHWC) on the
 // (2r+1)^2 integer-offset grid around coords[t][n] (zero padding outside).  One workgroup per (n, t).
+// VALU kernel (north_star: no MFMA in the keymask set).  Both S x C operands are staged in LDS (16-B aligned rows, the
+// neighbourhood sampled with 16-B tap loads along c); the S x S products are register-tiled: a thread (ti, tj) of a TB x TB grid
+// owns outputs (ti + TB a, tj + TB b), a, b < 4, and per 4 channels reads 4 + 4 LDS vectors for 64 multiply-adds -- the untiled
+// form read two LDS words per multiply-add and ran at 0.59 TB/s of the kernel's algorithmic bytes.  The sum over c runs in
+// channel order in one accumulator per output, with fused multiply-adds.
+template <int TB>
 __global__ __launch_bounds__(256) void local_corr_kernel(const float *__restrict__ fmap, const float *__restrict__ coords,
                                                          const float *__restrict__ support, int T, int Np, int H, int W,
                                                          int C, int r, float *__restrict__ corr)
 {
-    extern __shared__ float sm[];
-    const int S = (2 * r + 1) * (2 * r + 1);
-    const int ldc = C + 1;                   // +1: conflict-free column walks
-    float *nb = sm, *sp = sm + S * ldc;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = 2 * r + 1, S = D * D;
+    const int SR = S + 1;                     // staged rows: the S real ones and one row of zeros that every padded (i, j) >= S reads
+    const int ldc = C + 4;                    // 16-B aligned rows; consecutive rows 4 banks apart
+    float *nb = sm, *sp = sm + SR * ldc;
     const int n = blockIdx.x, t = blockIdx.y;
     const float cx = coords[((long)t * Np + n) * 2], cy = coords[((long)t * Np + n) * 2 + 1];
     const float *fm = fmap + (long)t * H * W * C;
-    for (int e = threadIdx.x; e < S * C; e += 256) {
-        const int i = e / C, c = e % C;
-        const int dy = i / (2 * r + 1) - r, dx = i % (2 * r + 1) - r;
-        const float x = cx + dx, y = cy + dy;
-        const int x0 = (int)floorf(x), y0 = (int)floorf(y);
-        const float fx = x - x0, fy = y - y0;
-        float v = 0.f;
+    const int C4 = C >> 2;
+    for (int e = threadIdx.x; e < SR * C4; e += 256) {
+        const int i = e / C4, c = (e - i * C4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = v;
+        if (i < S) {
+            const int dy = i / D - r, dx = i % D - r;
+            const float x = cx + dx, y = cy + dy;
+            const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+            const float fx = x - x0, fy = y - y0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H)
-                v += fm[((long)yy * W + xx) * C + c] * ((k & 1 ? fx : 1.f - fx) * (k >> 1 ? fy : 1.f - fy));
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H)
+                    v += *reinterpret_cast<const f32x4 *>(fm + ((long)yy * W + xx) * C + c) * ((k & 1 ? fx : 1.f - fx) * (k >> 1 ? fy : 1.f - fy));
+            }
+            w = *reinterpret_cast<const f32x4 *>(support + ((long)n * S + i) * C + c);
         }
-        nb[i * ldc + c] = v;
-        sp[i * ldc + c] = support[((long)n * S + i) * C + c];
+        *reinterpret_cast<f32x4 *>(nb + i * ldc + c) = v;
+        *reinterpret_cast<f32x4 *>(sp + i * ldc + c) = w;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < S * S; e += 256) {
-        const int i = e / S, j = e % S;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += nb[i * ldc + c] * sp[j * ldc + c];
-        corr[(((long)t * Np + n) * S + i) * S + j] = acc;
+    if (threadIdx.x >= TB * TB) return;
+    const int ti = threadIdx.x / TB, tj = threadIdx.x - ti * TB;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    int ra[4], rb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        ra[a] = min(ti + TB * a, S) * ldc;
+        rb[a] = min(tj + TB * a, S) * ldc;
+    }
+    for (int c = 0; c < C; c += 4) {
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            va[a] = *reinterpret_cast<const f32x4 *>(nb + ra[a] + c);
+            vb[a] = *reinterpret_cast<const f32x4 *>(sp + rb[a] + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fmaf(va[a][k], vb[b][k], acc[a][b]);   // one v_fma per product (channel order kept)
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ti + TB * a;
+        if (i >= S) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = tj + TB * b;
+            if (j < S) corr[(((long)t * Np + n) * S + i) * S + j] = acc[a][b];
+        }
     }
 }
 
@@ -328,10 +370,35 @@ int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float 
                        int r, float *corr, hipStream_t stream)
 {
     const int S = (2 * r + 1) * (2 * r + 1);
-    const size_t lds = sizeof(float) * 2 * S * (C + 1);
-    if (r < 0 || lds > 64 * 1024) return S2D_ERR_ARG;
+    if (r < 0 || (C & 3) || S > 64) return S2D_ERR_ARG;                   // 16-B channel vectors; at most 16 x 16 threads x 4 x 4 outputs
     if (T == 0 || Np == 0) return S2D_OK;
-    hipLaunchKernelGGL(local_corr_kernel, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr);
+    // thread grid TB x TB with 4 TB >= S: r = 3 (S = 49) -> 13 x 13 threads, 52 staged rows
+    const int TB = (S + 3) / 4;
+    const size_t lds = sizeof(float) * 2 * (S + 1) * (C + 4);
+    if (lds > 96 * 1024 || TB > 16) return S2D_ERR_ARG;
+#define S2D_LC(tb)                                                                                                              \
+    case tb: {                                                                                                                  \
+        static bool set = false;                                                                                                \
+        if (!set && lds > 48 * 1024) {                                                                                          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_kernel<tb>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) \
+                return S2D_ERR_LAUNCH;                                                                                          \
+            set = true;                                                                                                         \
+        }                                                                                                                       \
+        hipLaunchKernelGGL(local_corr_kernel<tb>, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr); \
+    } break;
+    switch (TB) {
+        S2D_LC(1) S2D_LC(3) S2D_LC(7) S2D_LC(13)                              // r = 0, 1, 2, 3
+    default: {
+        static bool set16 = false;
+        if (!set16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return S2D_ERR_LAUNCH;
+            set16 = true;
+        }
+        hipLaunchKernelGGL(local_corr_kernel<16>, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr);
+    }
+    }
+#undef S2D_LC
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -55,12 +55,13 @@ def test_keymask_config3_shapes_vs_oracle(oracle):
     assert km.compute_point_mask_intersection(pm, torch.from_numpy(idm[3] == 1)) == oracle.point_mask_iou(idm[3], 1, pm.numpy())
 
 
-def test_local_correlation_vs_oracle(oracle):
+@pytest.mark.parametrize("r,C", [(3, 128), (2, 128), (1, 64), (0, 32)])
+def test_local_correlation_vs_oracle(oracle, r, C):
     from s2d_amd import keymask as km
-    T, H, W, C, Np, r = 3, 30, 54, 128, 40, 3
+    T, H, W, Np = 3, 30, 54, 40
     fmap = synth.randn(13, 1, (T, H, W, C))
     coords = (synth.rng_for(13, 2).random((T, Np, 2)) * np.array([W + 4, H + 4]) - 2).astype(np.float32)  # some near/over the border
-    sup = synth.randn(13, 3, (Np, 49, C))
+    sup = synth.randn(13, 3, (Np, (2 * r + 1) ** 2, C))
     ref = oracle.local_correlation(fmap, coords, sup, r)
     out = km.local_correlation(torch.from_numpy(fmap).cuda(), torch.from_numpy(coords).cuda(), torch.from_numpy(sup).cuda(), r)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
