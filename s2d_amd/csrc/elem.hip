@@ -78,7 +78,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     double s = 0., ss = 0.;
     if (rslot < tpr) {
         const float *base = x + ((long)n * HW) * C + c4 * 4;
-        for (long r = r0 + rslot; r < r1; r += tpr) {
+        long r = r0 + rslot;
+        for (; r + 3L * tpr < r1; r += 4L * tpr) {           // four rows in flight per thread; added in row order, as the tail below
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4 *>(base + (r + (long)k * tpr) * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s += (double)v[k][0] + (double)v[k][1] + (double)v[k][2] + (double)v[k][3];
+                ss += (double)v[k][0] * v[k][0] + (double)v[k][1] * v[k][1] + (double)v[k][2] * v[k][2] + (double)v[k][3] * v[k][3];
+            }
+        }
+        for (; r < r1; r += tpr) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(base + r * C);
             s += (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
             ss += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
@@ -197,6 +208,54 @@ __global__ void gnb_apply_kernel(const float *__restrict__ x, const float *__res
 }
 
 // y = GN(x) * gamma + beta  [+ bilinear_resize(up)[N,hu,wu,C] -> (H,W)]  [relu]
+// PX consecutive pixels of one frame per thread (H * W % PX == 0): the group's mean / rstd (double divisions and a square root) are
+// formed once for them and PX 16-B loads are in flight per lane
+template <typename I, int PX>
+__global__ void gn_apply_px_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, int N, int H, int W, int C, int G, float eps,
+                                   const float *__restrict__ up, int hu, int wu, int relu, float *__restrict__ y)
+{
+    const int q = C / 4;
+    const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const I total = (I)N * H * W / PX * q;
+    if (i >= total) return;
+    const int c4 = (int)(i % (I)q);
+    const I pix0 = (i / (I)q) * PX;
+    const int n = (int)(pix0 / ((I)H * W));
+    const int g = (c4 * 4) / (C / G);
+    const double cnt = (double)H * W * (C / G);
+    const double mu = stats[((long)n * G + g) * 2] / cnt;
+    const double var = stats[((long)n * G + g) * 2 + 1] / cnt - mu * mu;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mu;
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4 * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4 * 4);
+    f32x4 v[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) v[k] = *reinterpret_cast<const f32x4 *>(x + ((long)pix0 + k) * C + c4 * 4);
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        f32x4 o = (v[k] - mean) * rstd * ga + be;
+        if (up) {
+            // F.interpolate(bilinear, align_corners=False) source index rule (msdeformattn.py:349)
+            const I pix = pix0 + k;
+            const int px = (int)(pix % (I)W), py = (int)((pix / (I)W) % (I)H);
+            float sy = ((float)hu / H) * (py + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = ((float)wu / W) * (px + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < hu - 1 ? 1 : 0), x1 = x0 + (x0 < wu - 1 ? 1 : 0);
+            const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+            const float *ub = up + (long)n * hu * wu * C + c4 * 4;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ub + ((long)y0 * wu + x0) * C);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(ub + ((long)y0 * wu + x1) * C);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(ub + ((long)y1 * wu + x0) * C);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(ub + ((long)y1 * wu + x1) * C);
+            o += hy * (hx * a + lx * b) + ly * (hx * c + lx * d);
+        }
+        if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        *reinterpret_cast<f32x4 *>(y + ((long)pix0 + k) * C + c4 * 4) = o;
+    }
+}
+
 template <typename I>
 __global__ void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, int N, int H, int W, int C, int G, float eps,
@@ -278,6 +337,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4 * 4);
             *reinterpret_cast<f32x4 *>(y + row * C + c4 * 4) = (v[k] - mean) * rstd * ga + be;
         }
+    }
+}
+
+// C == 256 (every LayerNorm of the path): a wave takes RW consecutive rows, one 16-B vector per lane and row, all RW loads in
+// flight before the first reduction -- with one 1-KB row per wave the launch had ~8 MB in flight on the whole chip and ran at
+// 4.9 TB/s of its two passes.  Same arithmetic per row as layernorm_kernel (same bits).
+template <int RW>
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           long rows, float eps, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= rows) return;
+    f32x4 v[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const long row = row0 + i < rows ? row0 + i : rows - 1;              // tail rows are recomputed, not stored
+        v[i] = *reinterpret_cast<const f32x4 *>(x + row * 256 + lane * 4);
+    }
+    if (res) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const long row = row0 + i < rows ? row0 + i : rows - 1;
+            v[i] += *reinterpret_cast<const f32x4 *>(res + row * 256 + lane * 4);
+        }
+    }
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + lane * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + lane * 4);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        float s = 0.f;
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        const float mean = wave_sum(s) / 256.f;
+        const f32x4 d = v[i] - mean;
+        float ss = 0.f;
+        ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        const float rstd = 1.f / sqrtf(wave_sum(ss) / 256.f + eps);
+        if (row0 + i < rows) *reinterpret_cast<f32x4 *>(y + (row0 + i) * 256 + lane * 4) = (v[i] - mean) * rstd * ga + be;
     }
 }
 
@@ -411,7 +509,10 @@ int s2d_groupnorm_nhwc_f32(const float *x, int N, int H, int W, int C, int G, co
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, (int)HW, C, G, rows_per_blk, part);
     hipLaunchKernelGGL(gn_reduce_kernel, dim3(N * G), dim3(64), 0, stream, part, nblk, G, stats_ws);
     const long total = (long)N * HW * (C / 4);
-    if (total < (1L << 31))
+    if (HW % 4 == 0 && total >= (1L << 20) && total < (1L << 31))
+        hipLaunchKernelGGL((gn_apply_px_kernel<unsigned int, 4>), dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H,
+                           W, C, G, eps, up, hu, wu, relu, y);
+    else if (total < (1L << 31))
         hipLaunchKernelGGL(gn_apply_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, stats_ws, gamma, beta, N, H, W,
                            C, G, eps, up, hu, wu, relu, y);
     else
@@ -459,7 +560,10 @@ int s2d_layernorm_f32(const float *x, const float *res, const float *gamma, cons
 {
     if ((C & 3) || C > 1024) return S2D_ERR_ARG;
     if (rows == 0) return S2D_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, res, gamma, beta, rows, C, eps, y);
+    if (C == 256 && rows >= 4096)
+        hipLaunchKernelGGL(layernorm256_kernel<4>, dim3(cdiv(rows, 16)), dim3(256), 0, stream, x, res, gamma, beta, rows, eps, y);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, res, gamma, beta, rows, C, eps, y);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
