@@ -549,7 +549,7 @@ def main():
             # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (scripts/pmc_traffic.py; fetch corrected x2 as MI355X_MICROARCH.md prescribes), stamped with the commit it was taken at
             traffic, traffic_src = None, None
-            for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
                 if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
                     j = json.load(open(tp))

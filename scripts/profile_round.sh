@@ -7,7 +7,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/${1:-prof}; C=${2:-unrecorded}; mkdir -p $O
-BF="--no-other-schedule --no-cpu-baseline --no-train-step --no-keymask"
+BF="--no-other-schedule --no-cpu-baseline --no-train-step --no-keymask --no-amp"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/one -o one -- python3 bench.py --one-stream $BF --steps 5 --warmup 2 > $O/bench_one.json 2> $O/bench_one.err; echo "one rc=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/two -o two -- python3 bench.py $BF --steps 5 --warmup 2 > $O/bench_two.json 2> $O/bench_two.err; echo "two rc=$?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_FETCH -o run -- python3 bench.py --one-stream $BF --no-kernel-events --steps 2 --warmup 1 > $O/pmc_f.json 2> $O/pmc_f.err; echo "pmcF rc=$?"
