@@ -332,7 +332,8 @@ __device__ __forceinline__ const float *coord_rows(const LossParams &p, long row
 // part): the workgroup copies one horizontal part of the map (<= 120 KB, + 1 overlap row) into LDS once, regenerates
 // the row's points from the counter RNG and handles those whose upper tap row falls in its part; all four taps
 // are then LDS reads.  v (the y coordinate) is drawn first so foreign points are dropped after one hash.
-constexpr int PART_BYTES = 120 * 1024;
+constexpr int PART_BYTES = 124 * 1024;
+constexpr int PADC = 4;                 // zero columns either side of a staged row (16-B aligned copies; x0 = -1 / x1 = wm land on them)
 constexpr int LTHREADS = 512;
 struct PartGeom {
     int rows_per_part, nparts;
@@ -340,7 +341,9 @@ struct PartGeom {
 __host__ __device__ inline PartGeom part_geom(int hm, int wm)
 {
     PartGeom g;
-    g.rows_per_part = PART_BYTES / (wm * 4) - 1;
+    // RNG mode stages a part with a zero border -- rows_per_part + 1 map rows, a zero row above and below, PADC zero columns either
+    // side -- so that the bilinear taps need no border tests (stage_part_padded); that block must fit PART_BYTES
+    g.rows_per_part = PART_BYTES / ((wm + 2 * PADC) * 4) - 3;
     if (g.rows_per_part > hm) g.rows_per_part = hm;
     g.nparts = (hm + g.rows_per_part - 1) / g.rows_per_part;
     return g;
@@ -452,6 +455,40 @@ __device__ __forceinline__ void stage_part(const float *__restrict__ map, int wm
     for (int i = threadIdx.x; i < n4; i += LTHREADS) dst[i] = src[i];
 }
 
+// The same rows with a zero border: LDS row 1 + (y - r0), column PADC + x.  Row 0 (y = r0 - 1: the row above the map for part 0)
+// and the row after the last staged one (y = hm for the last part) are zero, as are PADC columns either side of every row.
+__device__ __forceinline__ void stage_part_padded(const float *__restrict__ map, int wm, int r0, int nr, float *__restrict__ sm)
+{
+    const int wp = wm + 2 * PADC, w4 = wm / 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < wp / 4; i += LTHREADS) {
+        reinterpret_cast<f32x4 *>(sm)[i] = z;
+        reinterpret_cast<f32x4 *>(sm + (long)(nr + 1) * wp)[i] = z;
+    }
+    for (int i = threadIdx.x; i < nr; i += LTHREADS) {
+        *reinterpret_cast<f32x4 *>(sm + (long)(i + 1) * wp) = z;
+        *reinterpret_cast<f32x4 *>(sm + (long)(i + 1) * wp + PADC + wm) = z;
+    }
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(map + (long)r0 * wm);
+    for (int e = threadIdx.x; e < nr * w4; e += LTHREADS) {
+        const int row = e / w4, c4 = e - row * w4;
+        *reinterpret_cast<f32x4 *>(sm + (long)(row + 1) * wp + PADC + 4 * c4) = src[e];
+    }
+}
+
+// bilinear sample from the padded block: no border tests, no clamps (a tap outside the map reads a zero).  Same products and the
+// same order of additions as sample_part, whose out-of-map taps carry weight 0: same bits.
+__device__ __forceinline__ float sample_part_padded(const float *__restrict__ sm, int wp, int r0, float x, float y, int x0, int y0)
+{
+    const float fx = x - x0, fy = y - y0;
+    const float *b = sm + (y0 - r0 + 1) * wp + x0 + PADC;
+    float acc = b[0] * ((1.f - fx) * (1.f - fy));
+    acc += b[1] * (fx * (1.f - fy));
+    acc += b[wp] * ((1.f - fx) * fy);
+    acc += b[wp + 1] * (fx * fy);
+    return acc;
+}
+
 // bilinear sample from the staged part; (y0 - r0, y0 + 1 - r0) are guaranteed inside the part for owned points
 __device__ __forceinline__ float sample_part(const float *__restrict__ sm, int hm, int wm, int r0, int nr, float x, float y, int x0, int y0)
 {
@@ -487,10 +524,13 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         for (int i = threadIdx.x; i < nb; i += LTHREADS) h[i] = 0u;
         const int r0 = part * g.rows_per_part;
         const int nr = min(g.rows_per_part + 1, p.hm - r0);
-        stage_part(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
+        const float *cr = coord_rows(p, rowid, true);
+        const bool padded = cr == nullptr;                        // RNG mode (uniform over the workgroup)
+        const int wp = p.wm + 2 * PADC;
+        if (padded) stage_part_padded(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
+        else stage_part(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
         __syncthreads();
         const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
-        const float *cr = coord_rows(p, rowid, true);
         const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
         // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
@@ -516,7 +556,7 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
                 const int y0 = min(max((int)floorf(y), ylo), y0max);
-                tally(i, sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0));
+                tally(i, sample_part_padded(sm, wp, r0, x, y, (int)floorf(x), y0));
             }
         } else {
         // Parity mode (injected coordinates, any order): a part owns about half of the row's points (those whose upper tap row
@@ -573,7 +613,8 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
                 const int y0 = (int)floorf(y);
                 if (y0 >= ylo && y0 < yhi)
-                    p.xbuf[(long)li * (p.n_over + p.n_rand) + p.n_over + i] = sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
+                    p.xbuf[(long)li * (p.n_over + p.n_rand) + p.n_over + i] =
+                        padded ? sample_part_padded(sm, wp, r0, x, y, (int)floorf(x), y0) : sample_part(sm, p.hm, p.wm, r0, nr, x, y, (int)floorf(x), y0);
             }
         }
         __syncthreads();
@@ -1270,7 +1311,7 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     const PartGeom pg = part_geom(hm, wm);
     static_assert(PB_STRIDE == LOSS_CHUNKS + 1, "one bound per part + the end");
     if (!coords_over) hipLaunchKernelGGL(row_strata_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, p, pg.nparts, pg.rows_per_part);
-    const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 1) * wm;
+    const size_t lds_map = sizeof(float) * (size_t)(pg.rows_per_part + 3) * (wm + 2 * PADC);      // the padded block (>= the plain (rows + 1) x wm one)
     const size_t lds_hist = lds_map + sizeof(float) * 2048;
     if (int e = loss_attrs()) return e;
     const dim3 g(512);      // persistent: 2 blocks per CU's worth of items in flight

@@ -315,7 +315,7 @@ def test_rng_mode_points_are_iid_uniform_in_law():
         scratch = torch.empty((nrows + 1,), device="cuda", dtype=torch.int32)
         lib().call("s2d_point_loss_rng_points", 0xC0FFEE + hm, hm, wm, 0, nrows, n_over, uv, bounds, scratch, torch.cuda.current_stream().cuda_stream)
         uvh, bh = uv.cpu().numpy().astype(np.float64), bounds.cpu().numpy()
-        rpp = min(120 * 1024 // (wm * 4) - 1, hm)
+        rpp = min(124 * 1024 // ((wm + 8) * 4) - 3, hm)
         nparts = -(-hm // rpp)
         assert (uvh >= 0).all() and (uvh < 1).all()
         counts = []
