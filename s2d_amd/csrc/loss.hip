@@ -302,10 +302,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(LossParams p)
     // the tile is one contiguous run of npix * ldq floats (ldq % 4 == 0, 16-B aligned): 16-B loads, scalar LDS writes
     // (odd row stride: the column reads below stay conflict-free)
     const int l4 = p.ldq >> 2;
-    for (int e = threadIdx.x; e < npix * l4; e += 256) {
-        const int px = e / l4, q = (e - px * l4) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long)e * 4);
-        if (q < 128) { tile[px][q] = v[0]; tile[px][q + 1] = v[1]; tile[px][q + 2] = v[2]; tile[px][q + 3] = v[3]; }
+    // all of a thread's 16-B loads first (64 pixels x ldq <= 128 floats: at most 8 per thread), then the LDS writes: with one load
+    // per loop trip the kernel read its 3.8 GB at 3.7 TB/s
+    f32x4 v[8];
+    const int tot = npix * l4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < tot) v[k] = *reinterpret_cast<const f32x4 *>(src + (long)e * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < tot) {
+            const int px = e / l4, q = (e - px * l4) * 4;
+            if (q < 128) { tile[px][q] = v[k][0]; tile[px][q + 1] = v[k][1]; tile[px][q + 2] = v[k][2]; tile[px][q + 3] = v[k][3]; }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
