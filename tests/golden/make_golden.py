@@ -707,15 +707,16 @@ def _sampling_cases():
     return cases
 
 
-def g_sampling():
-    """dataset_mapper.py:223-289 dense_frame_selection / random_frame_selection and augmentation.py:51-75 (the size rule of
-    ResizeShortestEdge) called on the reference's own classes.  detectron2 / fvcore names the two files import are stood in for
-    by name only (none of them is touched by these methods)."""
-    import json
-    import random
-    import types
-    R.install()
+_DM = []
 
+
+def _load_dataset_mapper():
+    """the reference's data_video/dataset_mapper.py, loaded where it lies; detectron2 / fvcore names it imports are stood in for by
+    name only (none of them is touched by the functions the generators call)"""
+    import types
+    if _DM:
+        return _DM[0]
+    R.install()
     class _Aug:
         def _init(self, params=None):
             if params:
@@ -752,7 +753,20 @@ def g_sampling():
     ft.transform = ftt
     sys.modules["fvcore.transforms"], sys.modules["fvcore.transforms.transform"] = ft, ftt
     del sys.modules["mask2former_video.data_video.dataset_mapper"]          # the shim's name-only stand-in: load the real file here
-    dm = R.ref("mask2former_video.data_video.dataset_mapper")
+    _DM.append(R.ref("mask2former_video.data_video.dataset_mapper"))
+    return _DM[0]
+
+
+def g_sampling():
+    """dataset_mapper.py:223-289 dense_frame_selection / random_frame_selection and augmentation.py:51-75 (the size rule of
+    ResizeShortestEdge) called on the reference's own classes.  detectron2 / fvcore names the two files import are stood in for
+    by name only (none of them is touched by these methods)."""
+    import json
+    import random
+    import types
+    R.install()
+
+    dm = _load_dataset_mapper()
     au = R.ref("mask2former_video.data_video.augmentation")
     out = {"dense": [], "random": [], "resize": []}
     for ci, (L, annos) in enumerate(_sampling_cases()):
@@ -787,17 +801,10 @@ def g_sampling():
 from copy_paste_cases import COPY_PASTE_CASES, copy_paste_case  # noqa: E402,F401
 
 
-def g_copy_paste():
-    """engine/train_loop.py:30-156 propagate_sparse_masks and :377-590 CustomSimpleTrainer.copy_and_paste, called as they lie.
-    detectron2's structures are absent: Instances / BitMasks / Boxes are stood in for by small classes with the documented
-    behaviour of the few operations the two functions use (field dict + indexing + cat; .tensor + get_bounding_boxes; scale) --
-    the pixel results pinned here (composited frames, instance masks, ids, the fall-back decisions and the state of both RNG
-    streams after the call) do not depend on anything else.  tests/golden/copy_paste.npz."""
-    import copy
-    import random
-    import types
-    R.install()
-
+def _d2_structures():
+    """Stand-ins for detectron2.structures.{Boxes, BitMasks, Instances} (third party, absent): the documented behaviour of the few
+    operations the reference's data-side functions call -- field dict + indexing + cat; .tensor, nonempty, get_bounding_boxes;
+    scale, nonempty.  Test infrastructure of the golden generators only."""
     class Boxes:
         def __init__(self, t):
             self.tensor = t
@@ -807,6 +814,10 @@ def g_copy_paste():
         def scale(self, sx, sy):
             self.tensor[:, 0::2] *= sx
             self.tensor[:, 1::2] *= sy
+
+        def nonempty(self, threshold=0.0):
+            box = self.tensor
+            return ((box[:, 2] - box[:, 0]) > threshold) & ((box[:, 3] - box[:, 1]) > threshold)
 
         def __getitem__(self, i):
             t = self.tensor[i]
@@ -837,6 +848,9 @@ def g_copy_paste():
 
         def to(self, *a, **k):
             return BitMasks(self.tensor.to(*a, **k))
+
+        def nonempty(self):
+            return self.tensor.flatten(1).any(dim=1)
 
         def get_bounding_boxes(self):
             b = torch.zeros((self.tensor.shape[0], 4), dtype=torch.float32)
@@ -910,6 +924,21 @@ def g_copy_paste():
                 r.set(k, torch.cat(vs, 0) if isinstance(vs[0], torch.Tensor) else type(vs[0]).cat(vs))
             return r
 
+    return Boxes, BitMasks, Instances
+
+
+def g_copy_paste():
+    """engine/train_loop.py:30-156 propagate_sparse_masks and :377-590 CustomSimpleTrainer.copy_and_paste, called as they lie.
+    detectron2's structures are absent: Instances / BitMasks / Boxes are stood in for by small classes with the documented
+    behaviour of the few operations the two functions use (field dict + indexing + cat; .tensor + get_bounding_boxes; scale) --
+    the pixel results pinned here (composited frames, instance masks, ids, the fall-back decisions and the state of both RNG
+    streams after the call) do not depend on anything else.  tests/golden/copy_paste.npz."""
+    import copy
+    import random
+    import types
+    R.install()
+
+    Boxes, BitMasks, Instances = _d2_structures()
     for name, attrs in {"detectron2.utils.events": dict(get_event_storage=lambda: None), "detectron2.engine": dict(SimpleTrainer=object),
                         "detectron2.structures.instances": dict(Instances=Instances)}.items():
         m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m
@@ -960,6 +989,40 @@ def g_copy_paste():
 
 
 
+from make_golden_cases import assemble_cases  # noqa: E402,F401
+
+
+def g_assemble():
+    """dataset_mapper.py:29-56 `filter_empty_instances` -- the reference's own function in that file -- applied to the per-frame
+    Instances of seeded clips (BitMasks / Boxes stand-ins as above), slots numbered as :297-303 number them.  Pins the gt_ids the
+    mapper hands to the model (absent, crowd, empty-mask and degenerate-box instances become -1).  tests/golden/assemble.json."""
+    import json
+    Boxes, BitMasks, Instances = _d2_structures()
+    dm = _load_dataset_mapper()
+    out = []
+    for (H, W), video, sel in assemble_cases():
+        _ids = set()
+        for f in sel:
+            _ids.update([a["id"] for a in video[f]])
+        ids = {_id: i for i, _id in enumerate(_ids)}
+        frames = []
+        for f in sel:
+            masks = torch.zeros((len(ids), H, W), dtype=torch.bool)
+            gt = [-1] * len(ids)
+            for a in video[f]:
+                if a.get("iscrowd", 0) == 0:
+                    masks[ids[a["id"]]] = torch.from_numpy(a["mask"]); gt[ids[a["id"]]] = a["id"]
+            inst = Instances((H, W))
+            inst.gt_masks = BitMasks(masks)
+            inst.gt_ids = torch.tensor(gt)
+            inst.gt_boxes = inst.gt_masks.get_bounding_boxes()
+            inst = dm.filter_empty_instances(inst)
+            frames.append([int(v) for v in inst.gt_ids.tolist()])
+        out.append({"slots": {str(k): v for k, v in ids.items()}, "gt_ids": frames})
+    with open(os.path.join(HERE, "assemble.json"), "w") as f:
+        json.dump(out, f)
+
+
 def g_config():
     """the shipped KD training configuration as the trainer resolves it: configs/imagenet_video/
     ytvis2021_kd_video_mask2former_R50_cls_agnostic.yaml merged over its _BASE_ (yaml data, key -> value; python tuples
@@ -1005,7 +1068,7 @@ def main():
     R.install()
     only = set(sys.argv[1:])
     for fn in (g_msda, g_pe, g_pixel_decoder, g_video_decoder, g_matcher, g_loss, g_kd_and_criterion,
-               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats, g_sampling, g_copy_paste):
+               g_prepare_targets, g_keymask, g_grouping, g_inference, g_idmaps, g_config, g_formats, g_sampling, g_copy_paste, g_assemble):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -73,3 +73,28 @@ def test_augmentation_parameters_respect_the_policy():
         assert ((P[:, 8] >= 600) & (P[:, 8] <= 720) & (P[:, 9] >= 600) & (P[:, 9] <= 720)).all()
         assert ((P[:, 10] >= 0.9) & (P[:, 10] <= 1.1) & (P[:, 11] >= 0.9) & (P[:, 11] <= 1.1)).all()
         assert len(set(np.sign(P[:, 0] * np.cos(0.3)).tolist())) == 1          # one flip decision per clip (rotation <= 15 deg keeps a11's sign)
+
+
+def test_instance_assembly_matches_the_reference_filter():
+    """the mapper's per-frame slots (dataset_mapper.py:297-303: ids numbered in `set` iteration order; dummy slots for frames
+    where an instance is not annotated; crowd annotations dropped) and `filter_empty_instances` (:29-56: gt_ids -> -1 for an
+    empty mask or a degenerate box), against the reference's own filter function run on the same seeded clips
+    (tests/golden/assemble.json, make_golden.py g_assemble)"""
+    import torch
+    from make_golden_cases import assemble_cases
+    from s2d_amd.data import assemble_clip_instances, clip_id_slots
+    g = json.load(open(os.path.join(HERE, "golden", "assemble.json")))
+    for ((H, W), video, sel), want in zip(assemble_cases(), g):
+        ids = clip_id_slots(video, sel)
+        assert {str(k): v for k, v in ids.items()} == want["slots"]
+        frames = assemble_clip_instances(video, sel, (H, W), num_classes=1, device="cpu")
+        assert len(frames) == len(sel)
+        for fr, ref_ids, f in zip(frames, want["gt_ids"], sel):
+            assert fr["gt_ids"].tolist() == ref_ids
+            assert fr["gt_masks"].shape == (len(ids), H, W) and fr["gt_masks"].dtype == torch.bool
+            for a in video[f]:
+                if a.get("iscrowd", 0) == 0:
+                    assert torch.equal(fr["gt_masks"][ids[a["id"]]], torch.from_numpy(a["mask"]))
+                    assert fr["gt_classes"][ids[a["id"]]] == a["category_id"]
+            absent = [s for s in range(len(ids)) if s not in {ids[a["id"]] for a in video[f] if a.get("iscrowd", 0) == 0}]
+            assert all(fr["gt_classes"][s] == 1 and not fr["gt_masks"][s].any() for s in absent)
