@@ -1808,6 +1808,7 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         p.kblocks = (p.K + 31) / 32;
     }
     if (!f16 && (p.Asplit || p.gate || p.drop_thresh)) return S2D_ERR_ARG;
+    if (s2d_gemm_small_m_ok(p, conv, batch, f16)) return s2d_launch_gemm_small_m(p, st);      // the video decoder's query side (M = 200)
     static int ws = -1;
     if (ws < 0) { const char *e = getenv("S2D_GEMM_WS"); ws = e ? atoi(e) : 0; }
 

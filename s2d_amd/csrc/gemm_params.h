@@ -41,3 +41,6 @@ struct GemmParams {
 
 int s2d_split_weights_launch(const float *W, int N, int K, long ldw, unsigned int *out, hipStream_t st, int bf16);
 int s2d_launch_gemm_bf16x3(const GemmParams &p, bool conv, int batch, hipStream_t st, int f16);
+// gemm_small.hip: one-round-trip kernel for launches of a handful of rows (M <= 256) against static pre-split weights
+bool s2d_gemm_small_m_ok(const GemmParams &p, bool conv, int batch, int f16);
+int s2d_launch_gemm_small_m(const GemmParams &p, hipStream_t st);

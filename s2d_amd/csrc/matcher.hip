@@ -258,7 +258,12 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
 
 constexpr int SPANMAX = 24;     // staged logit rows per tap row (upper / lower): a 32-point batch spans ~12 cells at S2D density
 constexpr int ROWS = 2 * SPANMAX + 3;   // LDS rows of one staged block: slack, upper run, slack, lower run, slack
-__global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
+// Q16: 16-query row tiles (v_mfma_f32_16x16x32_f16), one per wave, ceil(Q / 16) waves (at least the four the target side needs):
+// Q = 100 pads to 112 rows instead of 128 -- the sigmoid / softplus work per (query, point) is what bounds the kernel -- and a
+// workgroup brings 7 waves instead of 4 to hide its LDS latency.  Lane (query l & 15, point group l >> 4) evaluates points
+// 8 (l >> 4) .. + 7 of a 32-point batch: the A fragment of one MFMA over the whole batch; targets in one or two 16-column tiles.
+template <bool Q16>
+__device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
 {
     constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
     constexpr int TROW = 20;                               // words per target row: 16 data (32 fp16) + 4 pad
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     __shared__ int bmeta[3][4];                                                  // cmin, span, staged
     __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int l16 = lane & 15, g16 = lane >> 4;
     const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
     const int pair = (bslot / CHM) * 8 + xcd, c = bslot % CHM;
     if (pair >= p.NL * p.B * p.T) return;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     const int b = prob % p.B;
     const int N = min(p.tgt_count[b], p.Nmax);
     if (N == 0 || N > 32) return;                           // N > 32: matcher_cost_kernel<4>
-    const int q = wv * 32 + l32;
+    const int q = Q16 ? wv * 16 + l16 : wv * 32 + l32;
     // Rows q >= Q and target columns >= N are computed on clamped (valid) data and never read by the finalize kernel:
     // a row of the contraction depends on its own query only, a column on its own target only.  All global accesses are
     // buffer loads with 32-bit byte offsets.
@@ -312,6 +318,10 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     f32x16 aAm, aAx, aDm, aDx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aAm[r] = 0.f; aAx[r] = 0.f; aDm[r] = 0.f; aDx[r] = 0.f; }
+    f32x4 bAm[2], bAx[2], bDm[2], bDx[2];                  // Q16: [target tile]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { bAm[t] = f32x4{0.f, 0.f, 0.f, 0.f}; bAx[t] = bAm[t]; bDm[t] = bAm[t]; bDx[t] = bAm[t]; }
+    const bool two = N > 16;
     float relusum = 0.f, lg2sum = 0.f, sgsum = 0.f, tsum = 0.f;
 
     // out-of-image corners (zero padding): the offset is clamped to a valid element and the weight zeroed, so every
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     // instruction fills two 512-B LDS rows (lanes 0..31 / 32..63; ldq / 4 <= 32 float4s of each are real data)
     auto rows_dma = [&](int tb, int buf) {
         const int cmin = bmeta[tb][0], span = bmeta[tb][1];
-        if (!bmeta[tb][2]) return;
+        if (!bmeta[tb][2] || wv >= 4) return;
         const int c4 = lane & 31;
 #pragma unroll
         for (int r = 0; r < SPANMAX / 4; ++r) {
@@ -395,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
     // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and stores them
     // as two fp16 pairs (hi / scaled lo) of row tn
     auto target_gather = [&](int tb, unsigned char (&tv)[SPT][4]) {
+        if (tid >= 256) return;
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[tb][slot * SPT + j]);
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         }
     };
     auto target_tile = [&](int tb, int buf, const unsigned char (&tv)[SPT][4]) {
+        if (tid >= 256) return;
         float val[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         if ((setq || sett) && !tail) { u = cr[2 * (base + l32)]; v = cr[2 * (base + l32) + 1]; }
     };
 
-    for (int i = tid; i < 2 * ROWS * 128 / 4; i += 256) reinterpret_cast<f32x4 *>(rowbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite slack rows
+    for (int i = tid; i < 2 * ROWS * 128 / 4; i += blockDim.x) reinterpret_cast<f32x4 *>(rowbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite slack rows
     __syncthreads();
     const int base0 = c * SB, bstep = CHM * SB;
     if (base0 < p.P) {
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
             if constexpr (!decltype(staged)::value) {
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][16 * st + 8 * h + s8]);
+                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][(Q16 ? 8 * g16 : 16 * st + 8 * h) + s8]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         m[s8][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, (int)((unsigned int)qi[e] + q4), 0, 0));
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
                 float xv[2], sv[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int s8 = 2 * jp + e, k = 16 * st + 8 * h + s8;
+                    const int s8 = 2 * jp + e, k = (Q16 ? 8 * g16 : 16 * st + 8 * h) + s8;
                     const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
                     float m0, m1, m2, m3;
                     if constexpr (decltype(staged)::value) {
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
             lg2sum += __builtin_amdgcn_logf(dprod);
         };
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < (Q16 ? 1 : 2); ++st) {
             if (staged_now) {
                 if (nvalid == SB) query_half(st, std::false_type{}, std::true_type{}); else query_half(st, std::true_type{}, std::true_type{});
             } else {
@@ -510,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         setup(r2, un, vn, tailn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target gathers) have landed
         __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1] and taps [r2] complete
+        if constexpr (!Q16) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[cur][l32][8 * st + 4 * h]);
@@ -526,23 +539,61 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
             aDx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, tl, aDx, 0, 0, 0);
             aDm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghv, th, aDm, 0, 0, 0);
         }
+        } else {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 a0 = {xh[0][0], xh[0][1], xh[0][2], xh[0][3]}, a1 = {xl[0][0], xl[0][1], xl[0][2], xl[0][3]};
+            const u32x4 g0 = {gh[0][0], gh[0][1], gh[0][2], gh[0][3]}, g1 = {gl[0][0], gl[0][1], gl[0][2], gl[0][3]};
+            const f16x8 xhv = __builtin_bit_cast(f16x8, a0), xlv = __builtin_bit_cast(f16x8, a1);
+            const f16x8 ghv = __builtin_bit_cast(f16x8, g0), glv = __builtin_bit_cast(f16x8, g1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;                 // block-uniform: at most 16 targets
+                const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[cur][16 * t + l16][4 * g16]);
+                const f16x8 tl = *reinterpret_cast<const f16x8 *>(&Tl[cur][16 * t + l16][4 * g16]);
+                bAx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlv, th, bAx[t], 0, 0, 0);
+                bAx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhv, tl, bAx[t], 0, 0, 0);
+                bAm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhv, th, bAm[t], 0, 0, 0);
+                bDx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(glv, th, bDx[t], 0, 0, 0);
+                bDx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ghv, tl, bDx[t], 0, 0, 0);
+                bDm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ghv, th, bDm[t], 0, 0, 0);
+            }
+        }
         target_tile(r1, cur ^ 1, tv);
     }
     const long pc = (long)prob * p.chunks + (long)t * CHM + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        p.wsA[(pc * QP + qq) * NP + l32] = aAm[r] + aAx[r] * (1.0f / 2048.0f);
-        p.wsD[(pc * QP + qq) * NP + l32] = aDm[r] + aDx[r] * (1.0f / 2048.0f);
-    }
     float spsum = relusum + 0.693147181f * lg2sum;
-    spsum += __shfl_xor(spsum, 32, 64);
-    sgsum += __shfl_xor(sgsum, 32, 64);
-    if (h == 0) {
-        p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
-        p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
+    if constexpr (!Q16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            p.wsA[(pc * QP + qq) * NP + l32] = aAm[r] + aAx[r] * (1.0f / 2048.0f);
+            p.wsD[(pc * QP + qq) * NP + l32] = aDm[r] + aDx[r] * (1.0f / 2048.0f);
+        }
+        spsum += __shfl_xor(spsum, 32, 64);
+        sgsum += __shfl_xor(sgsum, 32, 64);
+        if (h == 0) {
+            p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
+            p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !two) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = wv * 16 + 4 * g16 + r;
+                p.wsA[(pc * QP + qq) * NP + 16 * t + l16] = bAm[t][r] + bAx[t][r] * (1.0f / 2048.0f);
+                p.wsD[(pc * QP + qq) * NP + 16 * t + l16] = bDm[t][r] + bDx[t][r] * (1.0f / 2048.0f);
+            }
+        }
+        spsum += __shfl_xor(spsum, 16, 64); spsum += __shfl_xor(spsum, 32, 64);
+        sgsum += __shfl_xor(sgsum, 16, 64); sgsum += __shfl_xor(sgsum, 32, 64);
+        if (g16 == 0) {
+            p.wsV[(pc * 3 + 0) * 128 + q] = spsum;
+            p.wsV[(pc * 3 + 1) * 128 + q] = sgsum;
+        }
     }
-    tpart[slot][tn] = tsum;
+    if (tid < 256) tpart[slot][tn] = tsum;
     __syncthreads();
     if (tid < TN) {
         float sacc = 0.f;
@@ -551,6 +602,10 @@ __global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p)
         p.wsV[(pc * 3 + 2) * 128 + tid] = sacc;
     }
 }
+
+__global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p) { matcher_cost_f16_body<false>(p); }
+// two 7-wave workgroups per CU: 128 registers
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void matcher_cost_f16_q16_kernel(CostParams p) { matcher_cost_f16_body<true>(p); }
 
 // C[prob][q][n] = w_mask*cost_mask + w_class*(-softmax(logits)[q][0]) + w_dice*cost_dice   (matcher.py:280-287)
 __global__ void matcher_finalize_kernel(CostParams p, const float *__restrict__ cls, float wc, float wm_, float wd,
@@ -754,11 +809,18 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_rows) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_q16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_rows) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), lds_rows, stream, p);
+    // opt-in (read per call): measured slower, profiles/r3_experiments/not_adopted.txt -- four point groups per wave read four staged
+    // logit rows at once and every row starts at bank 0
+    int q16 = 0;
+    if (const char *e = getenv("S2D_MATCHER_Q16")) q16 = atoi(e);
+    if (q16) hipLaunchKernelGGL(matcher_cost_f16_q16_kernel, dim3(grid), dim3(64 * max(4, cdiv(Q, 16))), lds_rows, stream, p);
+    else hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), lds_rows, stream, p);
     if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,
                        class_logits, w_class, w_mask, w_dice, C);

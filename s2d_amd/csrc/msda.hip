@@ -177,20 +177,23 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 template <int LP_, bool HM = false, bool SHARE = false, bool TILED = false>
 __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
-                                                         int P, int blk_per_n, float *__restrict__ out)
+                                                         int P, int blk_per_n, float *__restrict__ out, int skip = -1)
 {
     constexpr int D = 32, V = 4, dv = D / V;
     const int n = blockIdx.y;
     const int bid = xcd_band(blockIdx.x, blk_per_n);
     int c, m, q, lq = 0, qy, qx;
     if constexpr (TILED) {
+        // `skip`: a level whose queries another launch takes (msda_fused_win_kernel); its patches are not numbered
         int tb = bid, ntx = 1;
-        for (;; ++lq) {
+        for (; lq < L; ++lq) {
+            if (lq == skip) continue;
             ntx = (lv.W[lq] + 3) >> 2;
             const int nt = ntx * ((lv.H[lq] + 3) >> 2);
-            if (tb < nt || lq == L - 1) break;
+            if (tb < nt) break;
             tb -= nt;
         }
+        if (lq >= L) return;
         const int w = threadIdx.x >> 6;
         qy = (tb / ntx) * 4 + (w >> 2);
         qx = (tb % ntx) * 4 + (w & 3);
@@ -342,6 +345,224 @@ __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const fl
     }
     }
     *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
+}
+
+// Windowed form of the fused kernel for the queries of the LAST level when it is the finest (three quarters of the pyramid's
+// queries at the S2D geometry).  The gather above is bound by the line rate of the vector L1 (every bilinear tap of a head is one
+// 128-B line; 48 taps per (query, head)), not by HBM.  Deformable offsets are local -- at the reference's initialisation
+// (ms_deform_attn.py:66-80) they are the constant grid (+-1 .. +-4 px on every level), trained ones stay within a few pixels -- so
+// the taps of an 8 x 8 patch of queries fall, per target level, into the patch's footprint on that level grown by a margin R.  A
+// 512-thread workgroup = one patch (wave = a patch row, 8 lanes x float4 = a query's 32 channels of the current head) walks the
+// heads; per head it brings the three windows (pixels outside the map as zeros) into LDS -- 629 lines for 64 x 48 = 3 072 taps at
+// R = 4 -- and takes every tap whose 2 x 2 footprint lies inside its window from there (ds_read_b128: 128 B/clk/CU against the
+// L1's 64).  A sample whose footprint leaves the window (offsets beyond R) takes the original global path, so any input gives the
+// same result as msda_fused_kernel: same formulas, same order of accumulation.
+// Windows go global -> LDS directly (buffer_load ... lds: no staging registers) into two regions that are refilled half a head
+// apart: X = the coarser levels (samples 0 .. 7), Y = the last level (samples 8 .. 11).  While a head's X samples run, its Y
+// window lands; while its Y samples and the next head's sample set-up run, the next head's X windows land.
+struct WinGeo {
+    int lq, R;
+    int nx, ny, basey;             // pixels of region X / Y, first LDS pixel of region Y (a multiple of 8)
+    int ww[4], wh[4], base[4];     // window extent and first LDS pixel of level l
+    float sx[4], sy[4];            // W_l / W_lq, H_l / H_lq
+};
+
+template <int L_, int P_>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_fused_win_kernel(
+    const float *__restrict__ value, int ldv, Levels lv, WinGeo wg, const float *__restrict__ oa, int ldoa, int S, int M, int blk_per_n,
+    float *__restrict__ out)
+{
+    constexpr int LP_ = L_ * P_, D = 32, MAXX = 6, MAXY = 5;
+    static_assert(L_ == 3 && P_ == 4, "three levels of four points: lane j of a query owns samples j (levels 0 / 1) and 8 + j (level 2)");
+    extern __shared__ __attribute__((aligned(16))) f32x4 win[];          // [pixel][8]
+    const int n = blockIdx.y, bid = xcd_band(blockIdx.x, blk_per_n);
+    constexpr int lq = L_ - 1;
+    const int Wq = lv.W[lq], Hq = lv.H[lq];
+    const int ntx = (Wq + 7) >> 3;
+    const int qx0 = (bid % ntx) * 8, qy0 = (bid / ntx) * 8;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, c = lane & 7;
+    const int qy = qy0 + wv, qx = qx0 + (lane >> 3);
+    const bool valid = qy < Hq && qx < Wq;                               // overhanging queries compute on a clamped query, store nothing
+    const int qyc = min(qy, Hq - 1), qxc = min(qx, Wq - 1);
+    const int q = (int)lv.start[lq] + qyc * Wq + qxc;
+    const float ref_x = ((float)qxc + 0.5f) / (float)Wq;
+    const float ref_y = ((float)qyc + 0.5f) / (float)Hq;
+    int ox[L_], oy[L_];
+#pragma unroll
+    for (int l = 0; l < L_; ++l) {
+        ox[l] = (int)floorf(((float)qx0 + 0.5f) * wg.sx[l] - 0.5f) - wg.R;
+        oy[l] = (int)floorf(((float)qy0 + 0.5f) * wg.sy[l] - 0.5f) - wg.R;
+    }
+    // this thread's window pixels (the same for every head): LDS pixel (region base) + it * 64 + slot <- byte offset of its 16 B
+    // in the frame; a pixel outside the map or past the region: an offset beyond the buffer (the load brings zeros or nothing:
+    // the regions are zeroed once)
+    const int slot = tid >> 3;
+    auto pixel_off = [&](int l, int loc) -> unsigned int {
+        const int wwl = l == 0 ? wg.ww[0] : (l == 1 ? wg.ww[1] : wg.ww[2]);
+        const int oxl = l == 0 ? ox[0] : (l == 1 ? ox[1] : ox[2]), oyl = l == 0 ? oy[0] : (l == 1 ? oy[1] : oy[2]);
+        const int Hl = l == 0 ? lv.H[0] : (l == 1 ? lv.H[1] : lv.H[2]), Wl = l == 0 ? lv.W[0] : (l == 1 ? lv.W[1] : lv.W[2]);
+        const int stl = (int)(l == 0 ? lv.start[0] : (l == 1 ? lv.start[1] : lv.start[2]));
+        const int wy = loc / wwl, wx = loc - wy * wwl;
+        const int gy = oyl + wy, gx = oxl + wx;
+        const bool ok = gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+        return ok ? (unsigned int)(((stl + gy * Wl + gx) * ldv + c * 4) * 4) : 0x80000000u;
+    };
+    unsigned int soffx[MAXX], soffy[MAXY];
+#pragma unroll
+    for (int it = 0; it < MAXX; ++it) {
+        const int pi = it * 64 + slot;
+        const int l = pi >= wg.base[1] ? 1 : 0;
+        soffx[it] = pi < wg.nx ? pixel_off(l, pi - (l ? wg.base[1] : 0)) : 0x80000000u;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXY; ++it) {
+        const int pi = it * 64 + slot;
+        soffy[it] = pi < wg.ny ? pixel_off(2, pi) : 0x80000000u;
+    }
+    const float *vn = value + (long)n * S * ldv;
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vn), 0, (int)((long)S * ldv * 4), 0x00020000);
+    auto issue_x = [&](int m) {
+#pragma unroll
+        for (int it = 0; it < MAXX; ++it) {
+            if (it * 64 + wv * 8 >= wg.nx) break;          // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void *)(win + (it * 64 + wv * 8) * 8), 16, (int)soffx[it],
+                                                     m * (D * 4), 0, 0);
+        }
+    };
+    auto issue_y = [&](int m) {
+#pragma unroll
+        for (int it = 0; it < MAXY; ++it) {
+            if (it * 64 + wv * 8 >= wg.ny) break;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void *)(win + (wg.basey + it * 64 + wv * 8) * 8), 16,
+                                                     (int)soffy[it], m * (D * 4), 0, 0);
+        }
+    };
+    const float *row = oa + ((long)n * S + q) * ldoa;
+    const int sj = c;
+    // the lane's own two samples: i0 = sj on level l0 = sj >> 2 (0 or 1), i1 = 8 + sj on level 2 (lanes 0..3; lanes 4..7 repeat sample 11)
+    const bool lvl1 = sj >= 4, live1 = sj < 4;
+    const int i1 = live1 ? 8 + sj : LP_ - 1;
+    const int H0_ = lvl1 ? lv.H[1] : lv.H[0], W0_ = lvl1 ? lv.W[1] : lv.W[0];
+    const int gH[2] = {H0_, lv.H[2]}, gW[2] = {W0_, lv.W[2]};
+    const int gww[2] = {lvl1 ? wg.ww[1] : wg.ww[0], wg.ww[2]}, gwh[2] = {lvl1 ? wg.wh[1] : wg.wh[0], wg.wh[2]};
+    const int gox[2] = {lvl1 ? ox[1] : ox[0], ox[2]}, goy[2] = {lvl1 ? oy[1] : oy[0], oy[2]};
+    const int gbase[2] = {lvl1 ? wg.base[1] : wg.base[0], wg.base[2]};
+    // offsets and logits of the lane's own two samples, one head ahead
+    float2 no0, no1;
+    float nl0, nl1;
+    auto issue_own = [&](int m) {
+        const float *offp_g = row + m * (LP_ * 2);
+        const float *lgp = row + M * LP_ * 2 + m * LP_;
+        no0 = *reinterpret_cast<const float2 *>(offp_g + 2 * sj);
+        no1 = *reinterpret_cast<const float2 *>(offp_g + 2 * i1);
+        nl0 = lgp[sj];
+        nl1 = lgp[i1];
+    };
+    float sw1[2], sw2[2], sw3[2], sw4[2], saw[2];
+    int spix[2], smask[2], swin[2];
+    bool fast;
+    auto setup = [&]() {
+        const float own_ox[2] = {no0.x, no1.x}, own_oy[2] = {no0.y, no1.y};
+        const float own_lg[2] = {nl0, live1 ? nl1 : -INFINITY};
+        float mx = fmaxf(own_lg[0], own_lg[1]);
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+        float own_e[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) own_e[r] = expf(own_lg[r] - mx);
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) den += __shfl(own_e[i >> 3], i & 7, 8);
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int H = gH[r], W = gW[r];
+            const float lx = ref_x + own_ox[r] / (float)W, ly = ref_y + own_oy[r] / (float)H;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // cuh:293
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+            sw1[r] = hh * hw; sw2[r] = hh * lw; sw3[r] = lh * hw; sw4[r] = lh * lw;
+            saw[r] = own_e[r] * inv;
+            spix[r] = h0 * W + w0;
+            smask[r] = !in ? 0 : ((h0 >= 0 && w0 >= 0) ? 1 : 0) | ((h0 >= 0 && w1 <= W - 1) ? 2 : 0) | ((h1 <= H - 1 && w0 >= 0) ? 4 : 0) |
+                                 ((h1 <= H - 1 && w1 <= W - 1) ? 8 : 0);
+            const int wx = w0 - gox[r], wy = h0 - goy[r];
+            const bool inw = wx >= 0 && wx + 1 < gww[r] && wy >= 0 && wy + 1 < gwh[r];
+            swin[r] = inw ? (gbase[r] + wy * gww[r] + wx) * 8 + c : -1;      // float4 index of the upper left tap, this lane's channel column
+        }
+        // Branch-free form when every sample of the wave has its 2 x 2 footprint inside the windows.  A sample outside the map
+        // (`in` false, skipped by the general path) then reads zeros (staged for pixels outside the map) or, at h_im == -1 /
+        // w_im == -1 exactly, map pixels under a weight of exactly 0: it adds +0 either way.
+        fast = __all((swin[0] >= 0) && (!live1 || swin[1] >= 0));
+    };
+    f32x4 acc;
+    auto samples = [&](int m, auto FIRST, auto LAST) {
+        constexpr int i_lo = decltype(FIRST)::value, i_hi = decltype(LAST)::value;
+        if (fast) {
+#pragma unroll
+            for (int i = i_lo; i < i_hi; ++i) {
+                const int r = i >> 3, src = i & 7, l = i / P_;
+                const int wi = __shfl(swin[r], src, 8) - src + c;       // the owner's index is for its own channel column
+                const float c1 = __shfl(sw1[r], src, 8), c2 = __shfl(sw2[r], src, 8), c3 = __shfl(sw3[r], src, 8), c4 = __shfl(sw4[r], src, 8);
+                const float aw = __shfl(saw[r], src, 8);
+                const f32x4 *pw = win + wi;
+                const f32x4 *pl = pw + wg.ww[l] * 8;
+                const f32x4 v1 = pw[0], v2 = pw[8], v3 = pl[0], v4 = pl[8];
+                acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
+            }
+        } else {
+#pragma unroll
+            for (int i = i_lo; i < i_hi; ++i) {
+                const int r = i >> 3, src = i & 7, l = i / P_;
+                const int W = lv.W[l];
+                const int mask = __shfl(smask[r], src, 8);
+                if (mask == 0) continue;                           // uniform over the query's 8 lanes
+                const int wi = __shfl(swin[r], src, 8);
+                const float c1 = __shfl(sw1[r], src, 8), c2 = __shfl(sw2[r], src, 8), c3 = __shfl(sw3[r], src, 8), c4 = __shfl(sw4[r], src, 8);
+                const float aw = __shfl(saw[r], src, 8);
+                f32x4 v1 = f32x4(0.f), v2 = f32x4(0.f), v3 = f32x4(0.f), v4 = f32x4(0.f);
+                if (wi >= 0) {
+                    const f32x4 *pw = win + (wi - src + c);
+                    const int up = wg.ww[l] * 8;
+                    v1 = pw[0]; v2 = pw[8]; v3 = pw[up]; v4 = pw[up + 8];
+                } else {
+                    const int pix = __shfl(spix[r], src, 8);
+                    const float *p1 = vn + ((long)lv.start[l] + pix) * ldv + m * D + c * 4;
+                    if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
+                    if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + ldv);
+                    if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * ldv);
+                    if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * ldv);
+                }
+                acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 2 * P_>;
+    using I12 = std::integral_constant<int, LP_>;
+
+    for (int i = tid; i < (wg.basey + ((wg.ny + 7) & ~7)) * 8; i += 512) win[i] = f32x4(0.f);
+    issue_own(0);
+    __syncthreads();                                        // zeros written
+    issue_x(0);
+    setup();
+    for (int m = 0; m < M; ++m) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's X lines of head m have landed
+        __syncthreads();                                    // X(m) complete; every wave is done with Y(m - 1)
+        issue_y(m);
+        if (m + 1 < M) issue_own(m + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = f32x4(0.f);
+        samples(m, I0{}, I8{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // Y(m) complete; every wave is done with X(m)
+        if (m + 1 < M) issue_x(m + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        samples(m, I8{}, I12{});
+        if (valid) *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * 4) = acc;
+        if (m + 1 < M) setup();
+    }
 }
 
 // Backward (ms_deform_im2col_cuda.cuh:92-164 formulas; the reference launches 32-thread blocks with a serial
@@ -1076,7 +1297,53 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
         static int share = -1, tiled = -1;
         if (share < 0) { const char *e = getenv("S2D_MSDA_SHARE"); share = e ? atoi(e) : 1; }
         if (tiled < 0) { const char *e = getenv("S2D_MSDA_TILED"); tiled = e ? atoi(e) : 1; }
-        if (tiled && M == 8) {
+        // opt-in (S2D_MSDA_WIN=1; read per call: tests and scripts/mb_msda_win.py switch it inside one process): faster only while
+        // the offsets are as regular as at initialisation, see profiles/r3_experiments/not_adopted.txt
+        int winmode = 0, winR = 4;
+        if (const char *e = getenv("S2D_MSDA_WIN")) winmode = atoi(e);
+        if (const char *r = getenv("S2D_MSDA_WIN_R")) winR = min(max(atoi(r), 1), 8);
+        int lq = 0;
+        for (int l = 1; l < L; ++l) if ((long)lv.H[l] * lv.W[l] > (long)lv.H[lq] * lv.W[lq]) lq = l;
+        WinGeo wg;
+        // the windowed kernel takes the last level's queries when that level is the finest and holds most of the pyramid
+        bool win_ok = winmode && tiled && M == 8 && L == 3 && P == 4 && lq == L - 1 && 2L * lv.H[lq] * lv.W[lq] > S && (long)S * ldv * 4 < 0x7fffffffL;
+        if (win_ok) {
+            // the largest margin R <= winR whose windows fit the two staging regions (640 pixels = 80 KB: two workgroups per CU)
+            int R = winR;
+            for (; R >= 1; --R) {
+                wg.lq = lq; wg.R = R; wg.nx = 0;
+                for (int l = 0; l < 4; ++l) { wg.ww[l] = wg.wh[l] = 1; wg.base[l] = 0; wg.sx[l] = wg.sy[l] = 1.f; }
+                for (int l = 0; l < L; ++l) {
+                    wg.sx[l] = (float)lv.W[l] / (float)lv.W[lq];
+                    wg.sy[l] = (float)lv.H[l] / (float)lv.H[lq];
+                    wg.ww[l] = (int)ceilf(7.f * wg.sx[l]) + 2 * R + 2;      // floor((x0 + 0.5) s - 0.5) .. floor((x0 + 7.5) s - 0.5), +-R, + the right tap
+                    wg.wh[l] = (int)ceilf(7.f * wg.sy[l]) + 2 * R + 2;
+                    if (l != lq) { wg.base[l] = wg.nx; wg.nx += wg.ww[l] * wg.wh[l]; }
+                }
+                wg.basey = (wg.nx + 7) & ~7;
+                wg.base[lq] = wg.basey;
+                wg.ny = wg.ww[lq] * wg.wh[lq];
+                if (wg.nx <= 384 && wg.ny <= 320 && wg.basey + ((wg.ny + 7) & ~7) <= 640) break;
+            }
+            win_ok = R >= 1;
+        }
+        if (win_ok) {
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_win_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 640 * 128) != hipSuccess)
+                    return S2D_ERR_LAUNCH;
+                attr = true;
+            }
+            const int npatch = ((lv.W[lq] + 7) / 8) * ((lv.H[lq] + 7) / 8);
+            hipLaunchKernelGGL((msda_fused_win_kernel<3, 4>), dim3(npatch, N), dim3(512), (size_t)(wg.basey + ((wg.ny + 7) & ~7)) * 128, stream, value, ldv, lv, wg, offs_logits,
+                               ldoa, S, M, npatch, out);
+            S2D_CHECK_LAUNCH();
+            int ntile = 0;
+            for (int l = 0; l < L; ++l) if (l != lq) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);
+            if (ntile > 0)
+                hipLaunchKernelGGL((msda_fused_kernel<12, false, true, true>), dim3(ntile, N), dim3(1024), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P,
+                                   ntile, out, lq);
+        } else if (tiled && M == 8) {
             int ntile = 0;
             for (int l = 0; l < L; ++l) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);
             hipLaunchKernelGGL((msda_fused_kernel<12, false, true, true>), dim3(ntile, N), dim3(1024), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, ntile, out);

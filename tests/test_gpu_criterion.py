@@ -246,6 +246,29 @@ def test_matcher_cost_vs_oracle_odd_shapes(oracle, B, Q, T, h, w, P, ns, dense):
         np.testing.assert_allclose(C[b][:, :ns[b]], ref, rtol=3e-5, atol=3e-5 * np.abs(ref).max())
 
 
+def test_matcher_16_row_tile_kernel_opt_in(monkeypatch):
+    """S2D_MATCHER_Q16=1 (16-query MFMA tiles, ceil(Q / 16) waves): same cost matrices as the default 32-row kernel to f32 summation
+    order, same assignments -- Q = 100 (7 waves), Q = 16 (4 waves, the target side's minimum), one and two target tiles"""
+    import torch
+    from s2d_amd import ops
+    dev = torch.device("cuda")
+    for (NL, B, Q, T, hm, wm, N, P) in [(3, 2, 100, 2, 40, 56, 10, 4096), (2, 1, 16, 1, 24, 32, 20, 1000), (2, 2, 37, 2, 24, 40, 3, 777)]:
+        g = torch.Generator(device=dev).manual_seed(Q)
+        ml = (torch.randn((NL, B, T * hm * wm, Q), generator=g, device=dev) * 4).contiguous()
+        cls = torch.randn((NL, B, Q, 2), generator=g, device=dev)
+        tgt = (torch.rand((B, N, T, hm * 4, wm * 4), generator=g, device=dev) < 0.3).to(torch.uint8)
+        cnt = torch.full((B,), N, dtype=torch.int32, device=dev)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("S2D_MATCHER_Q16", mode)
+            C = ops.matcher_cost(ml, cls, tgt, cnt, (Q, T, hm, wm), P, (2.0, 5.0, 5.0), seed=5)
+            out[mode] = (C, ops.lsap(C, cnt, B))
+        a, b = out["0"][0], out["1"][0]
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+        for x, y in zip(out["0"][1], out["1"][1]):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("P,H,W", [(250, 64, 96), (256, 64, 96), (1000, 32, 128)])
 def test_point_loss_vs_oracle_both_paths(oracle, P, H, W):
     """point loss vs the CPU restatement where the sampled logits cannot be kept (3P or P/4 not a multiple of 4: the

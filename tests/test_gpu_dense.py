@@ -54,6 +54,39 @@ def test_gemm_row_periodic_residual(oracle, frames, S, N, K, rc):
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (200, 2048, 256), (200, 256, 2048), (200, 2, 256), (1, 768, 256), (126, 288, 256), (96, 256, 1024),
+                                   (37, 70, 64), (256, 320, 128), (33, 65, 192)])
+def test_gemm_few_rows_static_weights(oracle, dense_mode, M, N, K):
+    """M <= 256 against static (pre-split) weights: in the split-fp16 mode the one-round-trip kernel of gemm_small.hip (the video
+    decoder's query side); every epilogue form -- scale, bias, ReLU, a row-periodic residual on the first columns, an output
+    wider than N -- against float64, and the result does not depend on the run (waves add their K slices in a fixed order)"""
+    from s2d_amd import ops
+    tol = {"f16x3": 2e-6, "bf16x3": 1e-4, "f32": 1e-4}[dense_mode]
+    A = _dev(synth.randn(4, 1, (M, K)))
+    W = torch.nn.Parameter(_dev(synth.randn(4, 2, (N, K)) * K ** -0.5), requires_grad=False)
+    sc = _dev(synth.randn(4, 3, (N,)) * 0.5 + 1)
+    bi = _dev(synth.randn(4, 4, (N,)))
+    R = _dev(synth.randn(4, 5, (M, N)))
+    ref = A.double() @ W.double().t()
+    y = ops.gemm_nt(A, W, sc, bi, R, relu=True)
+    r = torch.relu(ref * sc.double() + bi.double() + R.double())
+    np.testing.assert_allclose(y.cpu().numpy(), r.cpu().numpy(), rtol=tol, atol=tol * float(r.abs().max()))
+    assert torch.equal(ops.gemm_nt(A, W, sc, bi, R, relu=True), y)
+    # plain product into a wider output (padded row stride); the padding stays untouched
+    wide = torch.full((M, N + 3), 7.0, device="cuda")
+    ops.gemm_nt(A, W, out=wide)
+    np.testing.assert_allclose(wide[:, :N].cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+    assert bool((wide[:, N:] == 7.0).all())
+    # residual of S rows repeated down the output, on the first rc columns only
+    if M % 2 == 0 and N >= 8:
+        S, rc = M // 2, (N // 2) // 4 * 4
+        res = _dev(synth.randn(4, 6, (S, rc)))
+        y2 = ops.gemm_nt(A, W, bias=bi, res=res, res_rows=S, res_cols=rc)
+        r2 = ref + bi.double()
+        r2[:, :rc] += res.double().repeat(2, 1)
+        np.testing.assert_allclose(y2.cpu().numpy(), r2.cpu().numpy(), rtol=tol, atol=tol * float(r2.abs().max()))
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(2, 16, 24, 64, 64, 3, 1, 1), (1, 33, 47, 4, 64, 7, 2, 3),
                                                    (2, 16, 24, 256, 128, 1, 2, 0), (1, 20, 20, 128, 128, 3, 2, 1),
                                                    (1, 8, 12, 512, 2048, 1, 1, 0)])

