@@ -1025,8 +1025,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
 // registers), single LDS buffer (27.6 KB operands, 36.9 KB with the epilogue staging).  ~4 workgroups = 16 waves per
 // CU: while one workgroup splits / stores / waits at its barriers, three others keep the matrix pipe busy (the
 // 128 x 128 kernel above is limited to 2 waves/SIMD by its 128 accumulator registers and leaves the pipe ~2/3 idle).
-template <bool CONV, bool BSPLIT>
-__global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
+// PRE (short K with a residual: two to four k-steps, where the launch is a stream of tiles and the epilogue's residual read was a
+// third dependent memory round trip per tile): the residual tile is fetched into registers before the first k-tile.
+template <bool CONV, bool BSPLIT, bool PRE = false>
+__global__ __launch_bounds__(256, PRE ? 3 : 4) void gemm_f16x3_hi_kernel(GemmParams p)
 {
     constexpr int BM = 128, BNs = 64, RPT = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
@@ -1135,6 +1137,19 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
         for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accx[i][r] = 0.f; }
 
     const int nk = (p.K + BK - 1) / BK;
+    f32x4 rres[8];
+    if constexpr (PRE) {
+        // the epilogue's mapping: lane (c4e, rr) owns columns n0 + wn * 32 + 4 c4e .. + 3 of rows m0 + wm * 64 + 8 it + rr
+        const float *resp = p.res + (long)bz * p.sR;
+        const int col = n0 + wn * 32 + (lane & 7) * 4, rbase = m0 + wm * 64 + (lane >> 3);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = rbase + it * 8;
+            rres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < p.M && col < p.N && col < p.res_cols)
+                rres[it] = *reinterpret_cast<const f32x4 *>(resp + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
+        }
+    }
     load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
         store_tile();                                  // tile kt: registers -> (split) -> LDS
@@ -1172,13 +1187,14 @@ __global__ __launch_bounds__(256, 4) void gemm_f16x3_hi_kernel(GemmParams p)
             if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
             if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
             const int rbase = m0 + wm * 64 + rr;
-#pragma unroll 4
+#pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = rbase + it * 8;
                 if (row >= p.M) break;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 8 + rr) * 36 + c4e * 4]);
                 v = v * sc + bi;
-                if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
+                if constexpr (PRE) v += rres[it];
+                else if (res && col < p.res_cols) v += *reinterpret_cast<const f32x4 *>(res + (long)(p.res_rows ? row % p.res_rows : row) * p.ldr + col);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 if (p.gate) {
                     const f32x4 g = *reinterpret_cast<const f32x4 *>(p.gate + (long)row * p.ldg + col);
@@ -1605,7 +1621,12 @@ int launch_f16_hi(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(float) * 4 * 64 * 36;   // 36.9 KB: epilogue staging >= operand tiles (27.6 KB)
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, 64);
-    if (p.Bsplit) hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, true>), dim3(nwg, batch), dim3(256), lds, st, p);
+    static int pre = -1;
+    if (pre < 0) { const char *e = getenv("S2D_GEMM_HI_PRE"); pre = e ? atoi(e) : 1; }
+    // residual prefetch: short K (the 1 x 1 convolutions of res2 / res3 that close a bottleneck), vector epilogue, no gate
+    if (pre && p.Bsplit && p.res && !p.gate && p.K <= 4 * BK && ((p.N | p.ldc | p.ldr | p.res_cols) & 3) == 0)
+        hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, true, true>), dim3(nwg, batch), dim3(256), lds, st, p);
+    else if (p.Bsplit) hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, true>), dim3(nwg, batch), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemm_f16x3_hi_kernel<CONV, false>), dim3(nwg, batch), dim3(256), lds, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;

@@ -87,6 +87,28 @@ def test_gemm_few_rows_static_weights(oracle, dense_mode, M, N, K):
         np.testing.assert_allclose(y2.cpu().numpy(), r2.cpu().numpy(), rtol=tol, atol=tol * float(r2.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K,periodic", [(1000, 256, 64, False), (777, 512, 128, False), (900, 72, 96, True), (515, 256, 32, False)])
+def test_short_k_static_weights_with_residual(oracle, dense_mode, M, N, K, periodic):
+    """K <= 128 against static weights with a residual: in the split-fp16 mode the 128 x 64 kernel's variant that fetches the
+    residual tile before the first k-tile (the 1 x 1 convolutions closing a res2 / res3 bottleneck); ragged M, a column count that
+    is not a whole tile, a row-periodic residual"""
+    from s2d_amd import ops
+    tol = {"f16x3": 2e-6, "bf16x3": 1e-4, "f32": 1e-4}[dense_mode]
+    A = _dev(synth.randn(6, 1, (M, K)))
+    W = torch.nn.Parameter(_dev(synth.randn(6, 2, (N, K)) * K ** -0.5), requires_grad=False)
+    sc = _dev(synth.randn(6, 3, (N,)) * 0.5 + 1)
+    bi = _dev(synth.randn(6, 4, (N,)))
+    S = M // 3 if periodic else M
+    R = _dev(synth.randn(6, 5, (S, N)))
+    y = ops.gemm_nt(A, W, sc, bi, R, relu=True, res_rows=S if periodic else 0)
+    Rf = R.double().repeat(3, 1) if periodic else R.double()
+    ref = torch.relu((A.double() @ W.double().t()) * sc.double() + bi.double() + Rf)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+    # in place on the residual (the trunk's bottleneck output overwrites nothing it still needs: element-wise read before write)
+    y2 = ops.gemm_nt(A, W, sc, bi, R if not periodic else Rf.float().contiguous(), relu=True)
+    np.testing.assert_allclose(y2.cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(2, 16, 24, 64, 64, 3, 1, 1), (1, 33, 47, 4, 64, 7, 2, 3),
                                                    (2, 16, 24, 256, 128, 1, 2, 0), (1, 20, 20, 128, 128, 3, 2, 1),
                                                    (1, 8, 12, 512, 2048, 1, 1, 0)])
