@@ -128,24 +128,97 @@ __global__ __launch_bounds__(256) void kd_upsample_kernel(const float *__restric
     if (threadIdx.x < cnt && anyset[threadIdx.x]) nonempty[((long)b * Nmax + threadIdx.x) * T + t] = 1;
 }
 
-// nonempty[b][n][t] = any(tgt[b][n][t])   (the DropLoss predicate, criterion.py:310-313)
+// The same masks, tiled: a workgroup owns 16 output rows x 256 output columns of a frame.  The logits are pixel-major
+// ([pixel][query]) and only the kept queries are wanted, so the form above re-fetches every source pixel's lines for each of the
+// output rows and columns it feeds (x 4 upsampling: 16 outputs per source pixel, spread over 4 workgroups): 3.9 GB through L1 for a
+// 0.38 GB tensor.  Here the tile's source window (<= 8 x 72 pixels) is read once per chunk of 8 kept queries -- lanes along the
+// query index, so a pixel's lines are fetched by neighbouring lanes -- into LDS planes, and every output takes its 4 taps from
+// there; 4 output columns per thread, one 32-bit store.  Same arithmetic per output, bit for bit.
+constexpr int KDT_H = 16, KDT_W = 256, KDT_SH = 8, KDT_SW = 72, KDT_KC = 8;
+__global__ __launch_bounds__(256) void kd_upsample_tile_kernel(const float *__restrict__ ml, int ldq, int T, int hm, int wm, int H,
+                                                               int W, int Nmax, const int *__restrict__ count,
+                                                               const int *__restrict__ kept, uint8_t *__restrict__ tgt,
+                                                               int *__restrict__ nonempty)
+{
+    __shared__ int kq[128];
+    __shared__ unsigned int anyset[128];
+    __shared__ float src[KDT_KC][KDT_SH][KDT_SW];
+    const int bt = blockIdx.z, b = bt / T, t = bt % T;
+    const int Y0 = blockIdx.y * KDT_H, X0 = blockIdx.x * KDT_W;
+    const int cnt = count[b];
+    if (threadIdx.x < 128) {
+        kq[threadIdx.x] = threadIdx.x < cnt ? kept[b * Nmax + threadIdx.x] : 0;
+        anyset[threadIdx.x] = 0u;
+    }
+    auto srcpos = [](int o, int n_out, int n_in, int &i0, int &i1, float &l) {
+        float s = ((float)n_in / n_out) * (o + 0.5f) - 0.5f; if (s < 0.f) s = 0.f;
+        i0 = (int)s; i1 = i0 + (i0 < n_in - 1 ? 1 : 0); l = s - i0;
+    };
+    int ya, yb_, xa, xb_; float dummy;
+    srcpos(Y0, H, hm, ya, yb_, dummy);
+    srcpos(X0, W, wm, xa, xb_, dummy);
+    const float *fr = ml + ((long)b * T + t) * hm * wm * ldq;
+    // this thread's outputs: rows Y0 + (tid >> 6) + 4 p (p = 0 .. 3), columns X0 + 4 (tid & 63) .. + 3
+    const int xg = X0 + 4 * (threadIdx.x & 63);
+    int x0[4], x1[4]; float lx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) srcpos(min(xg + e, W - 1), W, wm, x0[e], x1[e], lx[e]);
+    __syncthreads();
+    for (int k0 = 0; k0 < cnt; k0 += KDT_KC) {
+        const int kc = min(KDT_KC, cnt - k0);
+        for (int i = threadIdx.x; i < KDT_SH * KDT_SW * KDT_KC; i += 256) {
+            const int kk = i % KDT_KC, pix = i / KDT_KC, sx = pix % KDT_SW, sy = pix / KDT_SW;
+            const int gy = min(ya + sy, hm - 1), gx = min(xa + sx, wm - 1);
+            if (kk < kc) src[kk][sy][sx] = fr[((long)gy * wm + gx) * ldq + kq[k0 + kk]];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {
+            const int Y = Y0 + (threadIdx.x >> 6) + 4 * pss;
+            if (Y >= H || xg >= W) continue;
+            int y0, y1; float ly;
+            srcpos(Y, H, hm, y0, y1, ly);
+            const float hy = 1.f - ly;
+            for (int kk = 0; kk < kc; ++kk) {
+                unsigned int word = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hx = 1.f - lx[e];
+                    const float val = hy * (hx * src[kk][y0 - ya][x0[e] - xa] + lx[e] * src[kk][y0 - ya][x1[e] - xa]) +
+                                      ly * (hx * src[kk][y1 - ya][x0[e] - xa] + lx[e] * src[kk][y1 - ya][x1[e] - xa]);
+                    word |= (val > 0.f ? 1u : 0u) << (8 * e);
+                }
+                *reinterpret_cast<unsigned int *>(tgt + ((((long)b * Nmax + k0 + kk) * T + t) * H + Y) * W + xg) = word;
+                if (word) anyset[k0 + kk] = 1u;  // benign race: all writers store 1
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < cnt && anyset[threadIdx.x]) atomicOr(&nonempty[((long)b * Nmax + threadIdx.x) * T + t], 1);
+}
+
+// nonempty[b][n][t] = any(tgt[b][n][t])   (the DropLoss predicate, criterion.py:310-313).  A plane is cut into NE_CHUNKS pieces
+// (one workgroup each: 160 planes alone leave a third of the CUs idle); `nonempty` is zeroed by the launcher and pieces OR into it.
+constexpr int NE_CHUNKS = 8;
 __global__ __launch_bounds__(256) void nonempty_kernel(const uint8_t *__restrict__ tgt, const int *__restrict__ count, int Nmax,
                                                        int T, long HW, int *__restrict__ nonempty)
 {
     const int plane = blockIdx.x;  // (b*Nmax + n)*T + t
     const int n = (plane / T) % Nmax, b = plane / (T * Nmax);
-    if (n >= count[b]) { if (threadIdx.x == 0) nonempty[plane] = 0; return; }
+    if (n >= count[b]) return;
     const uint8_t *p = tgt + (long)plane * HW;
     int any = 0;
-    const long n16 = HW / 16;
+    const long n16 = HW / 16, per = (n16 + NE_CHUNKS - 1) / NE_CHUNKS;
+    const long lo = blockIdx.y * per, hi = min(lo + per, n16);
     const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
-    for (long i = threadIdx.x; i < n16; i += 256) {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
         const uint4 v = p4[i];
         any |= (v.x | v.y | v.z | v.w) != 0u;
     }
-    for (long i = n16 * 16 + threadIdx.x; i < HW; i += 256) any |= p[i] != 0;
+    if (blockIdx.y == 0)
+        for (long i = n16 * 16 + threadIdx.x; i < HW; i += 256) any |= p[i] != 0;
     any = __syncthreads_or(any);
-    if (threadIdx.x == 0) nonempty[plane] = any ? 1 : 0;
+    if (threadIdx.x == 0 && any) atomicOr(&nonempty[plane], 1);
 }
 
 // ------------------------------------------------------------------------------------------------ rows
@@ -1208,8 +1281,14 @@ int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, f
     if (s2d_zero_async(nonempty, sizeof(int) * (size_t)B * Nmax * T, stream) != S2D_OK) return S2D_ERR_LAUNCH;
     hipLaunchKernelGGL(kd_select_kernel, dim3(B), dim3(128), 0, stream, t_class_logits, Q, topk < Q ? topk : Q, score_thr,
                        Nmax, count, kept_q);
-    hipLaunchKernelGGL(kd_upsample_kernel, dim3(cdiv(W, 256), H, B * T), dim3(256), 0, stream, t_mask_logits, ldq, T, hm, wm,
-                       H, W, Nmax, count, kept_q, tgt, nonempty);
+    // tiled form: whole 4-column groups, 32-bit stores, and a tile's source window inside the staged 8 x 72 pixels
+    // (floor(s (o + 15.5) - 0.5) + 1 - floor(s (o + 0.5) - 0.5) <= 16 s + 2 rows, 256 s + 2 columns)
+    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(tgt) & 3) == 0 && 16L * hm + 2L * H <= (long)KDT_SH * H && 256L * wm + 2L * W <= (long)KDT_SW * W)
+        hipLaunchKernelGGL(kd_upsample_tile_kernel, dim3(cdiv(W, KDT_W), cdiv(H, KDT_H), B * T), dim3(256), 0, stream, t_mask_logits, ldq, T, hm, wm,
+                           H, W, Nmax, count, kept_q, tgt, nonempty);
+    else
+        hipLaunchKernelGGL(kd_upsample_kernel, dim3(cdiv(W, 256), H, B * T), dim3(256), 0, stream, t_mask_logits, ldq, T, hm, wm,
+                           H, W, Nmax, count, kept_q, tgt, nonempty);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1219,7 +1298,8 @@ int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, i
 {
     if (B * Nmax * T == 0) return S2D_OK;
     if (((long)H * W) % 16) return S2D_ERR_ARG;
-    hipLaunchKernelGGL(nonempty_kernel, dim3(B * Nmax * T), dim3(256), 0, stream, tgt, count, Nmax, T, (long)H * W, nonempty);
+    if (s2d_zero_async(nonempty, sizeof(int) * (size_t)B * Nmax * T, stream) != S2D_OK) return S2D_ERR_LAUNCH;
+    hipLaunchKernelGGL(nonempty_kernel, dim3(B * Nmax * T, NE_CHUNKS), dim3(256), 0, stream, tgt, count, Nmax, T, (long)H * W, nonempty);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
