@@ -932,9 +932,17 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     // gradient of the training step that was not.  Scale per row: a power of two such that FX_CAP tap weights of the largest
     // possible per-point gradient fit 31 bits (a pixel collects ~11 taps on average at the shipped point counts, a few dozen in
     // the densest importance-sampled spots); one contribution is then rounded to <= 2^-21 of that bound.
+    // The tile is one MAP PART of the forward's geometry (part_geom: rows [j rpp, (j + 1) rpp)) plus one row above and two below:
+    // a part owns the points whose upper tap row y0 lies in it, so both tap rows of an owned point are inside the tile -- also for a
+    // point the RNG mode generated for this part whose v sits on the band edge and whose y0 rounds one row out of it.  In RNG mode the
+    // oversampled points of a part are an INDEX RANGE of the row (row_strata_kernel), so the part walks only that range; the random
+    // points (and, with injected coordinates, all points) are tested for ownership before they are queued.  Every point is
+    // evaluated once per row -- the first version cut the map in two halves and evaluated every point in both -- and any map size
+    // fits ((rpp + 3) wm ints <= PART_BYTES by part_geom).  The up-to-three rows two consecutive tiles share are carried over as
+    // integers, so a pixel's sum is still one integer sum over all its taps.
     int *gh = reinterpret_cast<int *>(tbits);
     constexpr float FX_CAP = 1024.f;
-    const int hh = (p.hm + 1) / 2;
+    __shared__ unsigned int tie_before;                      // ties with a smaller point index than the current part's (earlier parts)
     for (int li = blockIdx.x; li < nrows; li += gridDim.x) {
         const long rowid = p.list[li];
         const int layer = (int)(rowid / rows_l);
@@ -989,7 +997,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             fx_scale = gmax > 0.f ? exp2f(floorf(log2f(2147483648.f / (FX_CAP * gmax)))) : 0.f;
             fx_inv = fx_scale > 0.f ? 1.f / fx_scale : 0.f;
         }
-        int ylo = 0, yhi = p.hm;                              // BWD: the rows of the gradient tile being built
+        int ylo = 0, yhi = p.hm;                              // BWD: the rows [ylo, yhi) of the gradient tile being built
+        int own_lo = -1, own_hi = p.hm;                       // ... and the y0 range of the points the current part owns
+        auto y0_of = [&](float v) { return (int)floorf((((2.f * v - 1.f) + 1.f) * p.hm - 1.f) * 0.5f); };   // as point() forms it
         auto point = [&](float xv, float tt, float u, float v) {
             if constexpr (!BWD) {
                 acc_point(xv, tt, bce, sgt, sg, ts);
@@ -1004,7 +1014,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
                 const float fx = x - x0, fy = y - y0;
                 const float gs = g * fx_scale;
-                if (y0 >= ylo && y0 < yhi) {
+                if (y0 >= ylo && y0 < yhi) {                   // rows outside [0, hm) are outside every tile
                     if (x0 >= 0 && x0 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x0, __float2int_rn(gs * (1.f - fx) * (1.f - fy)));
                     if (x1 >= 0 && x1 < p.wm) atomicAdd(gh + (y0 - ylo) * p.wm + x1, __float2int_rn(gs * fx * (1.f - fy)));
                 }
@@ -1014,14 +1024,39 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
             }
         };
+        const int nparts_b = BWD ? sg_.nparts : 1;
+        if (BWD && threadIdx.x == 0) tie_before = 0u;
 #pragma unroll 1
-        for (int half = 0; half < (BWD ? 2 : 1); ++half) {
+        for (int part = 0; part < nparts_b; ++part) {
+        int r_lo = 0, r_hi = 0;                               // RNG mode, BWD: the part's index range of the oversampled points
+        bool ranged = false;
         if constexpr (BWD) {
-            ylo = half == 0 ? 0 : hh; yhi = half == 0 ? hh : p.hm;
+            const int rpp = sg_.rows_per_part;
+            const int nlo = max(part * rpp - 1, 0), nhi = min((part + 1) * rpp + 2, p.hm);
+            // rows [nlo, yhi) of the previous tile are this tile's first rows: carry their integer sums over
             __syncthreads();
+            const int ncarry = part > 0 ? max(yhi - nlo, 0) * p.wm : 0;
+            constexpr int CARRY = 4;                            // <= 3 rows x wm ints over LTHREADS threads (wm <= 4 * 512 / 3)
+            int keep[CARRY];
+#pragma unroll
+            for (int c = 0; c < CARRY; ++c) {
+                const int i = threadIdx.x + c * LTHREADS;
+                keep[c] = i < ncarry ? gh[(nlo - ylo) * p.wm + i] : 0;
+            }
+            __syncthreads();
+            ylo = nlo; yhi = nhi;
+            own_lo = part == 0 ? -1 : part * rpp; own_hi = part == nparts_b - 1 ? p.hm : (part + 1) * rpp;
             for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gh[i] = 0;
             if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
             __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CARRY; ++c) {
+                const int i = threadIdx.x + c * LTHREADS;
+                if (i < ncarry) gh[i] = keep[c];
+            }
+            __syncthreads();
+            ranged = coord_rows(p, rowid, true) == nullptr;
+            r_lo = s_pb[part]; r_hi = s_pb[part + 1];
         }
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
@@ -1030,6 +1065,8 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
             const int cnt = over ? p.n_over : p.n_rand;
             const float *xs = xb + (over ? 0 : p.n_over);
+            const bool walk_range = BWD && over && ranged;    // only the part's own index range; its points need no ownership test
+            const int lo = walk_range ? r_lo : 0, hi = walk_range ? r_hi : cnt;
             auto heavy = [&](int i, float xv) {           // one selected point: regenerate (u,v), sample the target bits
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
@@ -1065,11 +1102,21 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
             };
             auto test = [&](int i, float xv, bool live) {
-                bool sel = live;
+                const bool inr = live && i >= lo && i < hi;
+                bool owned = inr;
+                if (BWD && !walk_range && inr) {              // ownership by the upper tap row, before the point is queued
+                    float v;
+                    if (cr) v = cr[2 * i + 1];
+                    else if (over) { float u; over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v); }
+                    else v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                    const int y0 = y0_of(v);
+                    owned = y0 >= own_lo && y0 < own_hi;
+                }
+                bool sel = owned;
                 if (over) {
                     const unsigned int key = __float_as_uint(fabsf(xv));
-                    sel = live && key < thr;
-                    if (live && key == thr) {
+                    sel = owned && key < thr;
+                    if (inr && key == thr) {                  // every tie of the walked range is listed (ranks are by index); tie_point tests ownership
                         const unsigned int slot = atomicAdd(&tie_n, 1u);
                         if (slot < TIECAP) tie_idx[slot] = i;
                     }
@@ -1079,11 +1126,12 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             // the stored logits are streamed 16 B per lane (4 consecutive points), two loads in flight: with one
             // workgroup per CU the loop is bound by the round trip of each load, not by bandwidth
             const int cnt4 = ((reinterpret_cast<uintptr_t>(xs) & 15) == 0) ? cnt >> 2 : 0;
-            const int it4 = (cnt4 + LTHREADS - 1) / LTHREADS;         // uniform trip counts: ballots need whole waves
+            const int b4 = min(lo >> 2, cnt4), e4 = min((hi + 3) >> 2, cnt4);    // the 4-point groups that overlap [lo, hi)
+            const int it4 = (e4 - b4 + LTHREADS - 1) / LTHREADS;      // uniform trip counts: ballots need whole waves
             auto load4 = [&](int k) {
-                const int i4 = k * LTHREADS + threadIdx.x;
+                const int i4 = b4 + k * LTHREADS + threadIdx.x;
                 f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
-                if (i4 < cnt4) x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
+                if (i4 < e4) x4 = *reinterpret_cast<const f32x4 *>(xs + 4 * i4);
                 return x4;
             };
             // DEPTH loads ahead of the consumer (a ring in registers, the loop unrolled over it): one workgroup per CU streams its
@@ -1097,8 +1145,8 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 for (int d = 0; d < DEPTH; ++d) {
                     const int k = k0 + d;
                     if (k >= it4) break;                           // uniform over the workgroup
-                    const int i4 = k * LTHREADS + threadIdx.x;
-                    const bool live = i4 < cnt4;
+                    const int i4 = b4 + k * LTHREADS + threadIdx.x;
+                    const bool live = i4 < e4;
                     const f32x4 x4 = ring[d];
                     ring[d] = load4(k + DEPTH);
 #pragma unroll
@@ -1115,13 +1163,20 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         }
         __syncthreads();
         const unsigned int nties = tie_n;
-        if (nties > 0u && take > 0u) {                        // uniform over the workgroup
+        // ties are kept by ascending point index over the whole row; a part that walked only its own index range holds the ties of
+        // that range, and the earlier parts' ranges lie below it: `before` of the row's first `take` ties are already spent
+        const bool ranged_ties = BWD && ranged;
+        const unsigned int before = ranged_ties ? tie_before : 0u;
+        __syncthreads();
+        if (ranged_ties && threadIdx.x == 0) tie_before = before + nties;
+        if (nties > 0u && take > before) {                    // uniform over the workgroup
             const float *cr = coord_rows(p, rowid, true);
             const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
             auto tie_point = [&](int i) {
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
+                if (BWD && !ranged_ties) { const int y0 = y0_of(v); if (y0 < own_lo || y0 >= own_hi) return; }
                 point(xb[i], sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
@@ -1132,16 +1187,17 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     tie_sorted[rank] = mine;
                 }
                 __syncthreads();
-                for (unsigned int j = threadIdx.x; j < min(nties, take); j += LTHREADS) tie_point(tie_sorted[j]);
+                for (unsigned int j = threadIdx.x; j < min(nties, take - before); j += LTHREADS) tie_point(tie_sorted[j]);
             } else {
                 const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-                for (int i0 = 0; i0 < p.n_over; i0 += LTHREADS) {
+                const int t_lo = ranged_ties ? r_lo : 0, t_hi = ranged_ties ? r_hi : p.n_over;
+                for (int i0 = t_lo; i0 < t_hi; i0 += LTHREADS) {
                     const int i = i0 + threadIdx.x;
-                    const bool istie = i < p.n_over && __float_as_uint(fabsf(xb[i])) == thr;
+                    const bool istie = i < t_hi && __float_as_uint(fabsf(xb[i])) == thr;
                     const unsigned long long bal = __ballot(istie);
                     if (lane_ == 0) wtie[wv_] = (unsigned int)__popcll(bal);
                     __syncthreads();
-                    unsigned int rank = tie_base + (unsigned int)__popcll(bal & ((1ull << lane_) - 1ull));
+                    unsigned int rank = before + tie_base + (unsigned int)__popcll(bal & ((1ull << lane_) - 1ull));
                     for (int w = 0; w < wv_; ++w) rank += wtie[w];
                     if (istie && rank < take) tie_point(i);
                     __syncthreads();
@@ -1154,11 +1210,12 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 }
             }
         }
-        if constexpr (BWD) {                                  // write the finished half of the row's gradient plane
+        if constexpr (BWD) {                                  // write the rows of the tile that no later tile adds to
             __syncthreads();
-            for (int i = threadIdx.x; i < (yhi - ylo) * p.wm; i += LTHREADS) gp[ylo * p.wm + i] = (float)gh[i] * fx_inv;
+            const int nxt = part + 1 < nparts_b ? max((part + 1) * sg_.rows_per_part - 1, 0) : p.hm;
+            for (int i = threadIdx.x; i < (min(nxt, yhi) - ylo) * p.wm; i += LTHREADS) gp[ylo * p.wm + i] = (float)gh[i] * fx_inv;
         }
-        }   // half
+        }   // part
         if constexpr (!BWD) {
             bce = wave_sum(bce); sgt = wave_sum(sgt); sg = wave_sum(sg); ts = wave_sum(ts);
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1442,8 +1499,9 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
                                                        // the caller checks that the ACTIVE rows, lcount[NL], fit xcap = min(rows, 4096))
     if (int e = loss_attrs()) return e;
     if (s2d_zero_async(grad_rows, sizeof(float) * (size_t)rows * hm * wm, stream) != S2D_OK) return S2D_ERR_LAUNCH;
-    const size_t lds = sizeof(float) * (size_t)((hm + 1) / 2) * wm;
-    if (lds > 140 * 1024) return S2D_ERR_ARG;
+    const PartGeom pg = part_geom(hm, wm);
+    const size_t lds = sizeof(int) * (size_t)(pg.rows_per_part + 3 < hm ? pg.rows_per_part + 3 : hm) * wm;     // one map part + 3 shared rows
+    if (lds > 140 * 1024 || 3L * wm > 4L * LTHREADS || pg.nparts + 1 > PB_STRIDE) return S2D_ERR_ARG;
     // the bit-packed target planes of the rows in flight: the tail of the workspace's sample buffer is not used by the
     // backward walk beyond xcap rows; a dedicated scratch keeps it simple
     hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), lds, stream, p,

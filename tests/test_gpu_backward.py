@@ -440,6 +440,72 @@ def test_point_and_class_loss_backward_vs_autograd():
     assert rel(dcl.cpu().numpy(), cd.grad.numpy()) < 2e-6
 
 
+def test_point_loss_backward_walks_map_parts():
+    """The point-loss scatter builds a row's gradient one MAP PART at a time (the forward's staging geometry: a part owns the
+    points whose upper tap row lies in it; the rows two consecutive tiles share are carried over as integers).  On maps of 2
+    and 5 parts (100 x 400 and the 1080p-shaped 272 x 480, whose halves the first version's two-tile split could not hold in LDS):
+    injected points against float64 autograd through the torch restatement of loss_masks (criterion.py:292-356), and the
+    generator mode -- where a part walks only its own index range of the oversampled points -- against the injected mode fed
+    with the very points the generator emits (s2d_point_loss_rng_points), IMPORTANCE_SAMPLE_RATIO 1 so that no other point
+    enters: same losses, same gradient."""
+    import torch.nn.functional as F
+    from s2d_amd import ops
+    from s2d_amd._lib import lib
+    from s2d_amd.utils import synth
+    from tests.test_gpu_criterion import make_targets, pad_targets, pixel_major, _dev
+    for (h, w, P, up) in ((100, 400, 2048, 4), (272, 480, 1024, 2)):      # 1080p-shaped map; target planes 2x (their bit planes must fit LDS)
+        H, W = up * h, up * w
+        B, Q, T = 1, 4, 1
+        ns, seed = [2], 77 + h
+        masks = synth.smooth_logits(seed, 2, (B, Q, T), (h, w))
+        tg = make_targets(seed, 100, ns, T, H, W)
+        tgt, cnt = pad_targets(tg, 2, T, H, W)
+        iq = np.array([[1, 3]], np.int32); it = np.array([[1, 0]], np.int32); nm = np.array(ns, np.int32)
+        kept = [(0, s, 0) for s in range(2) if tg[0][it[0, s], 0].any()]
+        assert len(kept) == 2
+        rng = np.random.default_rng(seed)
+        n_unc, n_rand = int(0.75 * P), P - int(0.75 * P)
+        cov = rng.random((2, 3 * P, 2), dtype=np.float32); crd = rng.random((2, n_rand, 2), dtype=np.float32)
+        tgt_d, cnt_d = _dev(tgt), _dev(cnt)
+        ne = ops.target_nonempty(tgt_d, cnt_d)
+        ml = _dev(pixel_major(masks)[None])
+        wm_, wd_ = 5.0, 2.5
+        L, ctx = ops.point_loss(ml, tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P, coords_over=_dev(cov[None]),
+                                coords_rand=_dev(crd[None]), keep=True)
+        g = ops.point_loss_backward(ctx, wm_, wd_).cpu().numpy().reshape(2, h, w)
+        src = torch.tensor(np.stack([masks[0][iq[0, s], 0] for s in range(2)]), dtype=torch.float64, requires_grad=True)
+        tt = torch.tensor(np.stack([tg[0][it[0, s], 0] for s in range(2)]).astype(np.float64))
+        ps = lambda inp, c: F.grid_sample(inp[:, None], 2.0 * c[:, :, None, :] - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False)[:, 0, :, 0]
+        cov_t, crd_t = torch.tensor(cov, dtype=torch.float64), torch.tensor(crd, dtype=torch.float64)
+        with torch.no_grad():
+            idx = (-ps(src, cov_t).abs()).topk(n_unc, dim=1)[1]
+            coords = torch.cat([torch.gather(cov_t, 1, idx[..., None].expand(-1, -1, 2)), crd_t], 1)
+            labels = ps(tt, coords)
+        lg = ps(src, coords)
+        loss_mask = F.binary_cross_entropy_with_logits(lg, labels, reduction="none").mean(1).sum() / 2.0
+        sg = lg.sigmoid()
+        loss_dice = (1 - (2 * (sg * labels).sum(-1) + 1) / (sg.sum(-1) + labels.sum(-1) + 1)).sum() / 2.0
+        np.testing.assert_allclose(L.cpu().numpy()[0], [float(loss_mask), float(loss_dice)], rtol=1e-4)
+        (wm_ * loss_mask + wd_ * loss_dice).backward()
+        assert rel(g, src.grad.numpy()) < 2e-5, (h, rel(g, src.grad.numpy()))
+
+        # generator mode against the injected mode on the generator's own points
+        S = 4242 + h
+        uv = torch.empty((2, 3 * P, 2), device="cuda", dtype=torch.float32)
+        bounds = torch.zeros((2, 9), device="cuda", dtype=torch.int32)
+        scratch = torch.empty((3,), device="cuda", dtype=torch.int32)
+        lib().call("s2d_point_loss_rng_points", S, h, w, 0, 2, 3 * P, uv, bounds, scratch, torch.cuda.current_stream().cuda_stream)
+        La, ca = ops.point_loss(ml, tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P, importance=1.0, seed=S, keep=True)
+        ga = ops.point_loss_backward(ca, wm_, wd_)
+        Lb, cb = ops.point_loss(ml, tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P, importance=1.0, coords_over=uv[None].contiguous(),
+                                coords_rand=torch.zeros((1, 2, 0, 2), device="cuda"), keep=True)
+        gb = ops.point_loss_backward(cb, wm_, wd_)
+        np.testing.assert_allclose(La.cpu().numpy(), Lb.cpu().numpy(), rtol=2e-6)
+        assert float(ga.abs().max()) > 0
+        assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
+        assert torch.equal(ga, ops.point_loss_backward(ca, wm_, wd_))            # integer sums: the same bits every time
+
+
 def test_video_decoder_backward_vs_autograd():
     """VideoMultiScaleMaskedTransformerDecoder.backward (3 layers, one per memory level; masked cross-attention with the
     forward's own detached masks, self-attention, FFN, class / mask heads incl. the mask-logit einsum, batched key / value
