@@ -458,15 +458,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams p)
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < QW; ++w) mw[w] &= ~ign[w];     // bit set = this (query, key) pair does not attend
+    // two channels per vector instruction (v_pk_fma_f32): the loop is bound by its 128 multiply-adds per (query, key) pair.  Even /
+    // odd channels accumulate separately and are added at the end: a fixed order.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     for (int qq = quarter; qq < p.Q; qq += 4) {
         if ((mw[qq >> 5] >> (qq & 31)) & 1u) continue;
-        float s2 = 0.f, dp = 0.f;
+        f32x2 s2v = {0.f, 0.f}, dpv = {0.f, 0.f};
 #pragma unroll
-        for (int d = 0; d < 32; ++d) { s2 += qs[qq][d] * kr[d]; dp += dos[qq][d] * vr[d]; }
+        for (int d = 0; d < 32; d += 2) {
+            const f32x2 q2 = {qs[qq][d], qs[qq][d + 1]}, g2 = {dos[qq][d], dos[qq][d + 1]};
+            const f32x2 k2 = {kr[d], kr[d + 1]}, v2 = {vr[d], vr[d + 1]};
+            s2v = __builtin_elementwise_fma(q2, k2, s2v); dpv = __builtin_elementwise_fma(g2, v2, dpv);
+        }
+        const float s2 = s2v[0] + s2v[1], dp = dpv[0] + dpv[1];
         const float pr = kok ? exp2f(s2 - lses[qq]) : 0.f;
         const float ds = pr * (dp - delta[qq]);
+        const f32x2 pr2 = {pr, pr}, ds2 = {ds, ds};
 #pragma unroll
-        for (int d = 0; d < 32; ++d) { dV[d] += pr * dos[qq][d]; dK[d] += ds * qs[qq][d]; }
+        for (int d = 0; d < 32; d += 2) {
+            const f32x2 q2 = {qs[qq][d], qs[qq][d + 1]}, g2 = {dos[qq][d], dos[qq][d + 1]};
+            f32x2 a = {dV[d], dV[d + 1]}, c = {dK[d], dK[d + 1]};
+            a = __builtin_elementwise_fma(pr2, g2, a); c = __builtin_elementwise_fma(ds2, q2, c);
+            dV[d] = a[0]; dV[d + 1] = a[1]; dK[d] = c[0]; dK[d + 1] = c[1];
+        }
     }
     __syncthreads();
     // add the four query quarters (fixed order) through LDS: reuse qs / dos as [4][64][33] would not fit -> two rounds
@@ -546,12 +560,23 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdParams p)
             const uint32_t w = ms[r][qq >> 5];
             const bool beyond = (long)t * BT + r >= p.K;
             if (beyond || (use_mask && ((w >> (qq & 31)) & 1u))) continue;
-            float s2 = 0.f, dp = 0.f;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 s2v = {0.f, 0.f}, dpv = {0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { s2 += qr[d] * ks[r][d]; dp += gr[d] * vs[r][d]; }
-            const float ds = exp2f(s2 - ls) * (dp - dl);
+            for (int d = 0; d < 32; d += 2) {
+                const f32x2 k2 = {ks[r][d], ks[r][d + 1]}, v2 = {vs[r][d], vs[r][d + 1]};
+                const f32x2 q2 = {qr[d], qr[d + 1]}, g2 = {gr[d], gr[d + 1]};
+                s2v = __builtin_elementwise_fma(q2, k2, s2v); dpv = __builtin_elementwise_fma(g2, v2, dpv);
+            }
+            const float ds = exp2f((s2v[0] + s2v[1]) - ls) * ((dpv[0] + dpv[1]) - dl);
+            const f32x2 ds2 = {ds, ds};
 #pragma unroll
-            for (int d = 0; d < 32; ++d) dq[d] += ds * ks[r][d];
+            for (int d = 0; d < 32; d += 2) {
+                const f32x2 k2 = {ks[r][d], ks[r][d + 1]};
+                f32x2 a = {dq[d], dq[d + 1]};
+                a = __builtin_elementwise_fma(ds2, k2, a);
+                dq[d] = a[0]; dq[d + 1] = a[1];
+            }
         }
     }
     __syncthreads();
