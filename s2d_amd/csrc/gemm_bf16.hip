@@ -851,18 +851,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 // is (channel block, tap) instead of (tap, channel block), so sums differ from the implicit-GEMM kernel in the last bits.
 //   LDS: halo 180 rows (25.9 KB, single: replaced between channel blocks) + two weight buffers (36.9 KB); 69.6 KB with the
 //   epilogue staging -> two workgroups per CU.
-constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * (HT_W + 2);
+// PH x 16 output pixels and BNT = 64 WNW output channels per workgroup, a wave = 64 pixels x 64 channels either way:
+//   <8, 2>: 8 x 16 patch x 128 channels (Cout > 64);  <16, 1>: 16 x 16 patch x 64 channels (Cout <= 64: the res2 bottlenecks'
+//   3 x 3 convolutions, which the implicit-GEMM 128 x 64 kernel ran at 234 TFLOP/s with 9 x the input traffic through L2).
+constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2;
+template <int PH, int WNW>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p)
 {
+    constexpr int HALO_ROWS = (PH + 2) * HALO_W, BNT = 64 * WNW, WROWS = BNT / 32;      // WROWS: weight rows a thread copies per step
+    static_assert(PH * HT_W == 64 * (4 / WNW), "four waves of 64 pixels x 64 channels");
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
     unsigned int *Ah = lds;                              // [HALO_ROWS][ROWW]
-    unsigned int *Bs = lds + HALO_ROWS * ROWW;           // [2][BN][ROWW]
+    unsigned int *Bs = lds + HALO_ROWS * ROWW;           // [2][BNT][ROWW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int l32 = lane & 31, h = lane >> 5;
     const int H = p.Hin, W = p.Win, Cin = p.Cin;
-    const int tiles_x = (W + HT_W - 1) / HT_W, tiles_y = (H + HT_H - 1) / HT_H;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M / (H * W)) * tiles_y * tiles_x;
+    const int tiles_x = (W + HT_W - 1) / HT_W, tiles_y = (H + PH - 1) / PH;
+    const int tiles_n = (p.N + BNT - 1) / BNT, tiles_m = (p.M / (H * W)) * tiles_y * tiles_x;
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -870,16 +876,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     }
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-    const int n0 = tile_n * BN;
+    const int n0 = tile_n * BNT;
     const int img = tile_m / (tiles_y * tiles_x), trem = tile_m % (tiles_y * tiles_x);
-    const int y0 = (trem / tiles_x) * HT_H, x0 = (trem % tiles_x) * HT_W;
+    const int y0 = (trem / tiles_x) * PH, x0 = (trem % tiles_x) * HT_W;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000);
     // every load is in range (see the wave-specialised kernel): pixels outside the image read offset 0 and are zeroed when the
     // halo is stored; weight rows past Cout read the last row (their columns are never stored)
     // halo staging: item = (halo row, 16-B piece); 1440 items over 256 threads
-    constexpr int A_IT = (HALO_ROWS * 8 + 255) / 256;     // 6
+    constexpr int A_IT = (HALO_ROWS * 8 + 255) / 256;     // 6 (PH = 8), 11 (PH = 16)
     unsigned int ha_off[A_IT];
     int ha_dst[A_IT];
     bool ha_zero[A_IT];
@@ -898,14 +904,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
     const int c4 = tid & 7, g = tid >> 3;
     const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
     const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;
-    unsigned int b_off[4];
+    unsigned int b_off[WROWS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WROWS; ++i) {
         const int n = n0 + r0 + 32 * i;
         b_off[i] = (unsigned int)((long)(n < p.N ? n : p.N - 1) * p.kblocks * 128L + wsel * 4);
     }
     const int cblocks = Cin / 32;
-    f32x4 ra[A_IT], rb[4];
+    f32x4 ra[A_IT], rb[WROWS];
     auto load_halo = [&](int cb) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
@@ -925,13 +931,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
     auto load_w = [&](int tap, int cb) {                   // k block of (tap, channel block) in the [Cout][3][3][Cin] weights
         const unsigned int kb = (unsigned int)(tap * cblocks + cb) * 128u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WROWS; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], (int)kb, 0));
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4 *>(Bs + (buf * BN + r0 + 32 * i) * ROWW + wsel) = rb[i];
+        for (int i = 0; i < WROWS; ++i)
+            *reinterpret_cast<f32x4 *>(Bs + (buf * BNT + r0 + 32 * i) * ROWW + wsel) = rb[i];
     };
     // fragment rows: output pixel (py, px) of the patch reads halo row (py + dy) * 18 + px + dx for tap (dy, dx)
     int a_row[2];
@@ -949,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
             for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
     auto compute = [&](int tap, int buf) {
         const int toff = ((tap / 3) * HALO_W + (tap % 3)) * ROWW;
-        const unsigned int *bs = Bs + (buf * BN + wn * 64 + l32) * ROWW + 4 * h;
+        const unsigned int *bs = Bs + (buf * BNT + wn * 64 + l32) * ROWW + 4 * h;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 bh[2], bl[2];
@@ -1711,16 +1717,22 @@ int launch_f16(const GemmParams &p, int batch, hipStream_t st)
 
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 KB)
+    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 / 65.1 KB)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
     const int imgs = p.M / (p.Hin * p.Win);
-    const int nwg = imgs * cdiv(p.Hin, HT_H) * cdiv(p.Win, HT_W) * cdiv(p.N, BN);
-    hipLaunchKernelGGL(conv3x3_f16x3_halo_kernel, dim3(nwg), dim3(256), lds, st, p);
+    if (p.N <= 64) {
+        const int nwg = imgs * cdiv(p.Hin, 16) * cdiv(p.Win, HT_W);
+        hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<16, 1>), dim3(nwg), dim3(256), lds, st, p);
+    } else {
+        const int nwg = imgs * cdiv(p.Hin, HT_H) * cdiv(p.Win, HT_W) * cdiv(p.N, BN);
+        hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<8, 2>), dim3(nwg), dim3(256), lds, st, p);
+    }
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1874,9 +1886,12 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         if (halo < 0) { const char *e = getenv("S2D_CONV_HALO"); halo = e ? atoi(e) : 1; }
         // 3 x 3 / stride 1 / pad 1 on whole 32-channel blocks with static weights: the input-halo kernel
         // ... when its 8 x 16 patches cover the image without much overhang (23 x 40 -> 24 x 48 wastes 20 %: implicit GEMM wins)
-        if (halo && conv && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin % 32 == 0 && p.Bsplit && batch == 1 && p.N > 64 &&
+        static int halo64 = -1;
+        if (halo64 < 0) { const char *e = getenv("S2D_CONV_HALO64"); halo64 = e ? atoi(e) : 1; }
+        const int ph = p.N <= 64 ? 16 : HT_H;                 // Cout <= 64: 16 x 16 patches x 64 channels
+        if (halo && conv && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin % 32 == 0 && p.Bsplit && batch == 1 && (p.N > 64 || (halo64 && p.N > 32)) &&
             ((p.N | p.ldc | p.ldr) & 3) == 0 && !p.res_rows && p.res_cols == p.N && !p.gate &&
-            (halo == 2 || (long)p.Hin * p.Win * 100 >= (long)cdiv(p.Hin, HT_H) * HT_H * cdiv(p.Win, HT_W) * HT_W * 88))
+            (halo == 2 || (long)p.Hin * p.Win * 100 >= (long)cdiv(p.Hin, ph) * ph * cdiv(p.Win, HT_W) * HT_W * 88))
             return launch_conv3x3_halo(p, st);
         static int hi = -1;
         if (hi < 0) { const char *e = getenv("S2D_GEMM_HI"); hi = e ? atoi(e) : 2; }

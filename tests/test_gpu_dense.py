@@ -202,10 +202,12 @@ def test_gemm_presplit_a(oracle, dense_mode, M, N, K, with_res, relu):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,with_res", [(2, 16, 32, 64, 128, False), (1, 23, 40, 128, 192, True), (3, 9, 17, 32, 68, True),
-                                                      (1, 46, 80, 256, 256, False)])
+                                                      (1, 46, 80, 256, 256, False), (2, 40, 48, 64, 64, True), (1, 33, 50, 64, 48, False),
+                                                      (1, 16, 16, 32, 64, False)])
 def test_conv3x3_halo(oracle, dense_mode, N, H, W, Cin, Cout, with_res):
     """3x3 / stride 1 / pad 1 with static weights (the input-halo kernel in the default mode): image borders, patches that hang
-    over the bottom / right edge, Cout that is not a multiple of the 128-wide tile, scale + bias + residual + ReLU"""
+    over the bottom / right edge, Cout that is not a multiple of the 128-wide tile, Cout <= 64 (16 x 16 patches x 64 channels: the res2
+    bottlenecks), scale + bias + residual + ReLU"""
     from s2d_amd import ops
     x = synth.randn(7, 1, (N, H, W, Cin))
     w = (synth.randn(7, 2, (Cout, 3, 3, Cin)) / np.sqrt(9.0 * Cin)).astype(np.float32)
