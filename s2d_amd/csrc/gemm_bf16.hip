@@ -1027,6 +1027,154 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The R50 stem: 7 x 7 / stride 2 / pad 3 on the 4-channel NHWC input (3 colours + a zero), 64 output channels.  As an implicit
+// GEMM its A operand is 49 taps x 4 channels gathered 16 B at a time with a division per tap and a border test per load, for a
+// K of 196 that is all staging (139 TFLOP/s).  Here a workgroup owns a 16 x 16 patch of output pixels, stages the 37 x 37 input
+// halo ONCE (22 KB as fp16 hi / lo planes, pixels outside the image as zeros), and every tap pair of the MFMA's k range is two
+// 8-B LDS reads at a constant offset from the lane's pixel; the weights keep the implicit GEMM's image ([64][7 k-blocks] of
+// k = (kh 7 + kw) 4 + c, zero past 196) and stream through two LDS buffers.  Same products, same k order within a k-block.
+constexpr int ST_P = 16, ST_HW = 2 * ST_P + 5, ST_PLANE = ST_HW * ST_HW * 2;     // patch side, halo side (37), words of one fp16 plane
+__global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    unsigned int *Ah = lds;                              // [37][37][2 words]: 4 channels as fp16
+    unsigned int *Al = lds + ST_PLANE;                   // the scaled low parts
+    unsigned int *Bs = lds + 2 * ST_PLANE;               // [2][64][ROWW]   (2 x 2738 words = 1369 x 16 B: rows stay 16-B aligned)
+    static_assert((2 * ST_PLANE) % 4 == 0, "weight rows are copied 16 B at a time");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int H = p.Hin, W = p.Win, Ho = p.Hout, Wo = p.Wout;
+    const int tiles_x = (Wo + ST_P - 1) / ST_P, tiles_y = (Ho + ST_P - 1) / ST_P;
+    const int nwg = (p.M / (Ho * Wo)) * tiles_y * tiles_x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int img = bid / (tiles_y * tiles_x), trem = bid % (tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * ST_P, x0 = (trem % tiles_x) * ST_P;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000);
+    // halo: pixel (hy, hx) of the 37 x 37 window = input pixel (2 y0 - 3 + hy, 2 x0 - 3 + hx): one 16-B load, two 8-B LDS stores
+    constexpr int A_IT = (ST_HW * ST_HW + 255) / 256;     // 6
+    f32x4 ra[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int item = tid + 256 * i;
+        const int hy = item / ST_HW, hx = item - hy * ST_HW;
+        const int iy = 2 * y0 - 3 + hy, ix = 2 * x0 - 3 + hx;
+        const bool ok = item < ST_HW * ST_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (int)((((long)img * H + iy) * W + ix) * 16L) : (int)0x80000000, 0, 0));
+    }
+    // weights: row r0 + 32 i of the 64 channels, 16-B piece wsel of its k-block (as the other split-fp16 kernels copy them)
+    const int c4 = tid & 7, g = tid >> 3;
+    const int r0 = (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3);
+    const int wsel = (c4 & 3) * 4 + (c4 >> 2) * 16;
+    unsigned int b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b_off[i] = (unsigned int)((long)min(r0 + 32 * i, p.N - 1) * p.kblocks * 128L + wsel * 4);
+    // all seven k-blocks of the weights are requested up front, with the halo (one memory round trip per workgroup), and go to LDS
+    // one block ahead of their use.  (Measured equal to a one-block lookahead: at two 256-register workgroups per CU the kernel is
+    // bound by the sequence halo load -> 156 MFMAs per wave -> 64 KB of output per workgroup, matrix pipe 31 % busy, LDS 30 %.)
+    f32x4 rb[7][2];
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[kb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], kb * 128, 0));
+    auto store_w = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(Bs + ((kb & 1) * 64 + r0 + 32 * i) * ROWW + wsel) = rb[kb][i];
+    };
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int item = tid + 256 * i;
+        if (item >= ST_HW * ST_HW) continue;
+        u32x2 hi, lo;
+        split4_f16(ra[i], hi, lo);
+        *reinterpret_cast<u32x2 *>(Ah + item * 2) = hi;
+        *reinterpret_cast<u32x2 *>(Al + item * 2) = lo;
+    }
+    store_w(0);
+    __syncthreads();
+    // the lane's two output pixels (row tiles i = 0, 1 of the wave's 64) and, per k16 step, its two taps t = 4 step + 2 h, + 1
+    int a_pix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pix = wave * 64 + i * 32 + l32;
+        a_pix[i] = ((2 * (pix / ST_P)) * ST_HW + 2 * (pix % ST_P)) * 2;
+    }
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+    constexpr int NSTEP = 13;                              // 49 taps in steps of 4; taps 49 .. 51 meet zero weights
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+        const unsigned int *bs = Bs + ((kb & 1) * 64 + l32) * ROWW + 4 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int step = 2 * kb + s;
+            if (step >= NSTEP) break;
+            const int ta = min(4 * step + 2 * h, 48), tb = min(4 * step + 2 * h + 1, 48);
+            const int oa = ((ta / 7) * ST_HW + ta % 7) * 2, ob = ((tb / 7) * ST_HW + tb % 7) * 2;
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                bh[t2] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 8 * s);
+                bl[t2] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 16 + 8 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+                const u32x2 h0 = *reinterpret_cast<const u32x2 *>(Ah + a_pix[i] + oa), h1 = *reinterpret_cast<const u32x2 *>(Ah + a_pix[i] + ob);
+                const u32x2 l0 = *reinterpret_cast<const u32x2 *>(Al + a_pix[i] + oa), l1 = *reinterpret_cast<const u32x2 *>(Al + a_pix[i] + ob);
+                const f16x8 ah = __builtin_bit_cast(f16x8, u32x4v{h0[0], h0[1], h1[0], h1[1]});
+                const f16x8 al = __builtin_bit_cast(f16x8, u32x4v{l0[0], l0[1], l1[0], l1[1]});
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accx[i][0], 0, 0, 0);
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accx[i][1], 0, 0, 0);
+                accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accx[i][0], 0, 0, 0);
+                accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accx[i][1], 0, 0, 0);
+                accm[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], accm[i][0], 0, 0, 0);
+                accm[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], accm[i][1], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < 7) store_w(kb + 1);
+        __syncthreads();
+    }
+    // epilogue: the wave's 64 pixels x 64 channels through LDS, 16-B rows (Cout % 4 == 0 host-checked)
+    float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 68;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + tn * 32 + l32] = accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+    const int c4e = lane & 15, rr = lane >> 4;
+    const int col = c4e * 4;
+    if (col < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
+        if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int pix = wave * 64 + it * 4 + rr;
+            const int oy = y0 + pix / ST_P, ox = x0 + pix % ST_P;
+            if (oy >= Ho || ox >= Wo) continue;
+            const long row = ((long)img * Ho + oy) * Wo + ox;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&ep[(it * 4 + rr) * 68 + c4e * 4]);
+            v = v * sc + bi;
+            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + row * p.ldr + col);
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            *reinterpret_cast<f32x4 *>(p.C + row * p.ldc + col) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // High-occupancy split-fp16 x3 variant: 128 x 64 x 32 tile, 4 waves of 64 x 32 (two f32 accumulator sets = 64
 // registers), single LDS buffer (27.6 KB operands, 36.9 KB with the epilogue staging).  ~4 workgroups = 16 waves per
 // CU: while one workgroup splits / stores / waits at its barriers, three others keep the matrix pipe busy (the
@@ -1715,6 +1863,21 @@ int launch_f16(const GemmParams &p, int batch, hipStream_t st)
     return p.Bsplit ? launch_f16_v<CONV, PIPE, true>(p, batch, st) : launch_f16_v<CONV, PIPE, false>(p, batch, st);
 }
 
+int launch_conv7x7s2_stem(const GemmParams &p, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= two halo planes + two weight buffers (40.3 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv7x7s2_c4_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nwg = (p.M / (p.Hout * p.Wout)) * cdiv(p.Hout, ST_P) * cdiv(p.Wout, ST_P);
+    hipLaunchKernelGGL(conv7x7s2_c4_halo_kernel, dim3(nwg), dim3(256), lds, st, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t st)
 {
     const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 / 65.1 KB)
@@ -1886,6 +2049,12 @@ int s2d_launch_gemm_bf16x3(const GemmParams &pin, bool conv, int batch, hipStrea
         if (halo < 0) { const char *e = getenv("S2D_CONV_HALO"); halo = e ? atoi(e) : 1; }
         // 3 x 3 / stride 1 / pad 1 on whole 32-channel blocks with static weights: the input-halo kernel
         // ... when its 8 x 16 patches cover the image without much overhang (23 x 40 -> 24 x 48 wastes 20 %: implicit GEMM wins)
+        static int stem = -1;
+        if (stem < 0) { const char *e = getenv("S2D_CONV_STEM"); stem = e ? atoi(e) : 1; }
+        // the R50 stem geometry: its own halo kernel
+        if (stem && conv && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.Cin == 4 && p.N <= 64 && p.N > 32 && p.Bsplit && batch == 1 &&
+            ((p.N | p.ldc | p.ldr) & 3) == 0 && !p.res_rows && p.res_cols == p.N && !p.gate && (long)p.Hin * p.Win * 16L * (p.M / ((long)p.Hout * p.Wout)) < 0x7fffffffL)
+            return launch_conv7x7s2_stem(p, st);
         static int halo64 = -1;
         if (halo64 < 0) { const char *e = getenv("S2D_CONV_HALO64"); halo64 = e ? atoi(e) : 1; }
         const int ph = p.N <= 64 ? 16 : HT_H;                 // Cout <= 64: 16 x 16 patches x 64 channels

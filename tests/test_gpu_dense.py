@@ -225,6 +225,23 @@ def test_conv3x3_halo(oracle, dense_mode, N, H, W, Cin, Cout, with_res):
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("N,H,W,Cout", [(1, 33, 47, 64), (2, 64, 96, 64), (1, 70, 130, 48), (3, 32, 32, 64)])
+def test_stem_conv_halo(oracle, dense_mode, N, H, W, Cout):
+    """the R50 stem geometry (7 x 7 / stride 2 / pad 3, NHWC4 input) with static weights -- in the split-fp16 mode its own input-halo
+    kernel: image borders on all four sides, patches overhanging the output, odd sizes, FrozenBN scale / bias + ReLU"""
+    from s2d_amd import ops
+    x = synth.randn(8, 1, (N, H, W, 4)); x[..., 3] = 0
+    w = (synth.randn(8, 2, (Cout, 7, 7, 4)) / 12.0).astype(np.float32)
+    sc = (synth.randn(8, 3, (Cout,)) * 0.5 + 1).astype(np.float32)
+    bi = synth.randn(8, 4, (Cout,))
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w).double().permute(0, 3, 1, 2)
+    ref = np.maximum(torch.nn.functional.conv2d(xt, wt, stride=2, padding=3).permute(0, 2, 3, 1).numpy() * sc + bi, 0)
+    out = ops.conv2d_nhwc(_dev(x), ops.mark_static(_dev(w)), 2, 3, scale=_dev(sc), bias=_dev(bi), relu=True).cpu().numpy()
+    tol = {"f16x3": 2e-6, "bf16x3": 1e-4, "f32": 1e-4}[dense_mode]
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("switch,select", [("S2D_GEMM_WS", "gemm or conv or dropout"), ("S2D_GEMM_W128", "bf16x3 and (gemm or presplit)"),
                                            ("S2D_CONV_HALO", "f16x3 and conv")])
 def test_forced_kernel_subprocess(dense_mode, switch, select):
