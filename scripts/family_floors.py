@@ -47,7 +47,7 @@ def main():
 
     out = []
     # dense contractions (GEMM / conv kernels; the decoder's query side included)
-    t, n = fam("gemm_f16x3", "conv3x3_f16x3", "gemm_small_m")
+    t, n = fam("gemm_f16x3", "conv3x3_f16x3", "conv7x7s2", "gemm_small_m")
     enc_rows = F * S                                                     # rows of one network's encoder activations
     # floors of the dense launches: from the per-shape table when given (it includes msda / attention rows: subtract those)
     out.append(("dense contractions (NT GEMM, implicit-GEMM / halo conv; the decoder's query side included)", t, n, dense_floor,
@@ -91,7 +91,7 @@ def main():
     t, n = fam("cross_attn_kernel", "attn_merge_kernel", "attn_mask_kernel", "self_attn")
     out.append(("decoder attention (masked cross-attention, merges, attention-mask bits)", t, n, None, "small launches (200 queries); see roofline.per_kernel.cross_attn"))
     # the rest
-    named = ("gemm_f16x3", "conv3x3_f16x3", "gemm_small_m", "msda_fused_kernel", "layernorm256_kernel", "gn_", "maxpool_kernel", "matcher_cost_f16_kernel",
+    named = ("gemm_f16x3", "conv3x3_f16x3", "conv7x7s2", "gemm_small_m", "msda_fused_kernel", "layernorm256_kernel", "gn_", "maxpool_kernel", "matcher_cost_f16_kernel",
              "hist_kernel<0>", "accumulate_stream_kernel<false>", "gather_rows_kernel", "hist_stream_kernel", "loss_finalize", "select_kernel", "row_",
              "kd_upsample", "nonempty_kernel", "cross_attn_kernel", "attn_merge_kernel", "attn_mask_kernel", "self_attn")
     t = sum(ms for k, (ms, c) in per.items() if not any(s in k for s in named))
