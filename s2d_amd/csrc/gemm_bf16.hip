@@ -1033,18 +1033,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
 // halo ONCE (22 KB as fp16 hi / lo planes, pixels outside the image as zeros), and every tap pair of the MFMA's k range is two
 // 8-B LDS reads at a constant offset from the lane's pixel; the weights keep the implicit GEMM's image ([64][7 k-blocks] of
 // k = (kh 7 + kw) 4 + c, zero past 196) and stream through two LDS buffers.  Same products, same k order within a k-block.
-constexpr int ST_P = 16, ST_HW = 2 * ST_P + 5, ST_PLANE = ST_HW * ST_HW * 2;     // patch side, halo side (37), words of one fp16 plane
-__global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
+// PH: patch height.  16: a wave = 64 pixels x 64 channels (128 accumulator registers, two workgroups per CU); 8: a wave = 32 pixels
+// x 64 channels (64 accumulator registers, four workgroups per CU -- the kernel is a sequence halo load -> MFMAs -> store per
+// workgroup, so more workgroups in flight is what it lacks).
+constexpr int ST_P = 16, ST_HW = 2 * ST_P + 5;          // patch width, halo width (37)
+template <int PH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PH == 16 ? 2 : 4, PH == 16 ? 2 : 4))) void conv7x7s2_c4_halo_kernel(GemmParams p)
 {
+    constexpr int ST_HH = 2 * PH + 5, ST_PLANE = ST_HH * ST_HW * 2, RT = PH / 8, WPIX = 32 * RT;   // halo height, words of one fp16 plane, row tiles and pixels per wave
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
     unsigned int *Ah = lds;                              // [37][37][2 words]: 4 channels as fp16
     unsigned int *Al = lds + ST_PLANE;                   // the scaled low parts
-    unsigned int *Bs = lds + 2 * ST_PLANE;               // [2][64][ROWW]   (2 x 2738 words = 1369 x 16 B: rows stay 16-B aligned)
+    unsigned int *Bs = lds + 2 * ST_PLANE;               // [2][64][ROWW]   (whole 16-B units: rows stay 16-B aligned)
     static_assert((2 * ST_PLANE) % 4 == 0, "weight rows are copied 16 B at a time");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, h = lane >> 5;
     const int H = p.Hin, W = p.Win, Ho = p.Hout, Wo = p.Wout;
-    const int tiles_x = (Wo + ST_P - 1) / ST_P, tiles_y = (Ho + ST_P - 1) / ST_P;
+    const int tiles_x = (Wo + ST_P - 1) / ST_P, tiles_y = (Ho + PH - 1) / PH;
     const int nwg = (p.M / (Ho * Wo)) * tiles_y * tiles_x;
     int bid = blockIdx.x;
     {
@@ -1052,18 +1057,18 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     }
     const int img = bid / (tiles_y * tiles_x), trem = bid % (tiles_y * tiles_x);
-    const int y0 = (trem / tiles_x) * ST_P, x0 = (trem % tiles_x) * ST_P;
+    const int y0 = (trem / tiles_x) * PH, x0 = (trem % tiles_x) * ST_P;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.A), 0, (int)p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.Bsplit), 0, (int)((long)p.N * p.kblocks * 128L), 0x00020000);
     // halo: pixel (hy, hx) of the 37 x 37 window = input pixel (2 y0 - 3 + hy, 2 x0 - 3 + hx): one 16-B load, two 8-B LDS stores
-    constexpr int A_IT = (ST_HW * ST_HW + 255) / 256;     // 6
+    constexpr int A_IT = (ST_HH * ST_HW + 255) / 256;     // 6 / 4
     f32x4 ra[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int item = tid + 256 * i;
         const int hy = item / ST_HW, hx = item - hy * ST_HW;
         const int iy = 2 * y0 - 3 + hy, ix = 2 * x0 - 3 + hx;
-        const bool ok = item < ST_HW * ST_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const bool ok = item < ST_HH * ST_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (int)((((long)img * H + iy) * W + ix) * 16L) : (int)0x80000000, 0, 0));
     }
     // weights: row r0 + 32 i of the 64 channels, 16-B piece wsel of its k-block (as the other split-fp16 kernels copy them)
@@ -1076,19 +1081,22 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
     // all seven k-blocks of the weights are requested up front, with the halo (one memory round trip per workgroup), and go to LDS
     // one block ahead of their use.  (Measured equal to a one-block lookahead: at two 256-register workgroups per CU the kernel is
     // bound by the sequence halo load -> 156 MFMAs per wave -> 64 KB of output per workgroup, matrix pipe 31 % busy, LDS 30 %.)
-    f32x4 rb[7][2];
+    constexpr int WSETS = PH == 16 ? 7 : 2;               // PH = 8 (128 registers): one block ahead, two register sets
+    f32x4 rb[WSETS][2];
+    auto load_w = [&](int kb) {
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb)
+        for (int i = 0; i < 2; ++i) rb[kb % WSETS][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], kb * 128, 0));
+    };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[kb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[i], kb * 128, 0));
+    for (int kb = 0; kb < (WSETS == 7 ? 7 : 1); ++kb) load_w(kb);
     auto store_w = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(Bs + ((kb & 1) * 64 + r0 + 32 * i) * ROWW + wsel) = rb[kb][i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(Bs + ((kb & 1) * 64 + r0 + 32 * i) * ROWW + wsel) = rb[kb % WSETS][i];
     };
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int item = tid + 256 * i;
-        if (item >= ST_HW * ST_HW) continue;
+        if (item >= ST_HH * ST_HW) continue;
         u32x2 hi, lo;
         split4_f16(ra[i], hi, lo);
         *reinterpret_cast<u32x2 *>(Ah + item * 2) = hi;
@@ -1097,15 +1105,15 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
     store_w(0);
     __syncthreads();
     // the lane's two output pixels (row tiles i = 0, 1 of the wave's 64) and, per k16 step, its two taps t = 4 step + 2 h, + 1
-    int a_pix[2];
+    int a_pix[RT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pix = wave * 64 + i * 32 + l32;
+    for (int i = 0; i < RT; ++i) {
+        const int pix = wave * WPIX + i * 32 + l32;
         a_pix[i] = ((2 * (pix / ST_P)) * ST_HW + 2 * (pix % ST_P)) * 2;
     }
-    f32x16 accm[2][2], accx[2][2];
+    f32x16 accm[RT][2], accx[RT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1113,6 +1121,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
     constexpr int NSTEP = 13;                              // 49 taps in steps of 4; taps 49 .. 51 meet zero weights
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) {
+        if (WSETS != 7 && kb + 1 < 7) load_w(kb + 1);
         const unsigned int *bs = Bs + ((kb & 1) * 64 + l32) * ROWW + 4 * h;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
                 bl[t2] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 16 + 8 * s);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
                 const u32x2 h0 = *reinterpret_cast<const u32x2 *>(Ah + a_pix[i] + oa), h1 = *reinterpret_cast<const u32x2 *>(Ah + a_pix[i] + ob);
                 const u32x2 l0 = *reinterpret_cast<const u32x2 *>(Al + a_pix[i] + oa), l1 = *reinterpret_cast<const u32x2 *>(Al + a_pix[i] + ob);
@@ -1145,9 +1154,9 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
         __syncthreads();
     }
     // epilogue: the wave's 64 pixels x 64 channels through LDS, 16-B rows (Cout % 4 == 0 host-checked)
-    float *ep = reinterpret_cast<float *>(lds) + wave * 64 * 68;
+    float *ep = reinterpret_cast<float *>(lds) + wave * WPIX * 68;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < RT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -1160,8 +1169,8 @@ __global__ __launch_bounds__(256, 2) void conv7x7s2_c4_halo_kernel(GemmParams p)
         if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + col);
         if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + col);
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int pix = wave * 64 + it * 4 + rr;
+        for (int it = 0; it < 8 * RT; ++it) {
+            const int pix = wave * WPIX + it * 4 + rr;
             const int oy = y0 + pix / ST_P, ox = x0 + pix % ST_P;
             if (oy >= Ho || ox >= Wo) continue;
             const long row = ((long)img * Ho + oy) * Wo + ox;
@@ -1865,15 +1874,18 @@ int launch_f16(const GemmParams &p, int batch, hipStream_t st)
 
 int launch_conv7x7s2_stem(const GemmParams &p, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= two halo planes + two weight buffers (40.3 KB)
+    static int ph = -1;
+    if (ph < 0) { const char *e = getenv("S2D_CONV_STEM_PH"); ph = e ? atoi(e) : 8; }
+    const size_t lds16 = sizeof(float) * 4 * 64 * 68, lds8 = sizeof(float) * 4 * 32 * 68;       // epilogue staging >= halo planes + two weight buffers
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv7x7s2_c4_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv7x7s2_c4_halo_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set = true;
     }
-    const int nwg = (p.M / (p.Hout * p.Wout)) * cdiv(p.Hout, ST_P) * cdiv(p.Wout, ST_P);
-    hipLaunchKernelGGL(conv7x7s2_c4_halo_kernel, dim3(nwg), dim3(256), lds, st, p);
+    const int imgs = p.M / (p.Hout * p.Wout);
+    if (ph == 16) hipLaunchKernelGGL(conv7x7s2_c4_halo_kernel<16>, dim3(imgs * cdiv(p.Hout, 16) * cdiv(p.Wout, ST_P)), dim3(256), lds16, st, p);
+    else hipLaunchKernelGGL(conv7x7s2_c4_halo_kernel<8>, dim3(imgs * cdiv(p.Hout, 8) * cdiv(p.Wout, ST_P)), dim3(256), lds8, st, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
