@@ -146,9 +146,29 @@ def calibrate_teacher(model, images, want=10):
         bias[1] -= (need - thr) / 2
 
 
+def _usable_cores():
+    """host cores this process may really run on: the affinity mask, capped by the cgroup's CPU quota (a GPU box gives a 1-GPU job
+    a 16-core share of a 256-thread host: sizing thread pools by os.cpu_count() oversubscribes 16x)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return max(n, 1)
+
+
 def _oracle_sample(cfg_name, Ts):
-    """seconds the CPU oracle needs for one Ts-frame clip at the workload's resolution: student forward (cross-frame attention
-    over the Ts frames included) + the 10-layer GT criterion"""
+    """seconds PER STAGE the CPU oracle needs for one Ts-frame clip at the workload's resolution (BASELINE.md section 4 / SURVEY 8d's
+    stage list): normalise + pad, R50 trunk, pixel decoder, video decoder (cross-frame attention over the Ts frames included),
+    prepare_targets, matcher (cost matrices + LSAP) and loss_labels + loss_masks over the 10 prediction layers, KD target preparation"""
     from oracle import oracle_np as O
     from s2d_amd.utils import synth
     from s2d_amd.utils.seeded import seeded_state
@@ -159,45 +179,81 @@ def _oracle_sample(cfg_name, Ts):
                      [("1.predictor." + k, s) for k, s in video_decoder_shapes(Q)], 0)
     fr = synth.smooth_frames_u8(0, 1, Ts, H0, W0)
     m, ids = synth.ellipse_targets(0, 2, N, Ts, H0, W0, sparse=0.0)
-    t0 = time.perf_counter()
-    x = O.normalize_pad(fr)
-    feats = O.resnet50(p, x, "0.")
-    mf, ms = O.pixel_decoder(p, feats, "1.pixel_decoder.")
-    logits, masks = O.video_decoder(p, ms, mf, Ts, "1.predictor.")
-    tg = [O.prepare_targets(m, ids, x.shape[2], x.shape[3])[0]]
+    st = {}
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        st[name] = st.get(name, 0.0) + now - clock[0]
+        clock[0] = now
+
+    x = O.normalize_pad(fr); lap("normalize_pad")
+    feats = O.resnet50(p, x, "0."); lap("r50_trunk")
+    mf, ms = O.pixel_decoder(p, feats, "1.pixel_decoder."); lap("pixel_decoder")
+    logits, masks = O.video_decoder(p, ms, mf, Ts, "1.predictor."); lap("video_decoder")
+    tg = [O.prepare_targets(m, ids, x.shape[2], x.shape[3])[0]]; lap("prepare_targets")
     rng = np.random.default_rng(0)
     NL = logits.shape[0]
     num_masks = float(max(tg[0].shape[0], 1))
     for layer in range(NL):
         coords = [rng.random((1, P, 2), dtype=np.float32)]
-        idx = O.matcher(logits[layer], masks[layer], tg, coords, 0.0, 5.0, 5.0)
-        O.loss_masks(masks[layer], tg, idx, num_masks, P=P, rng=rng)
-    return time.perf_counter() - t0
+        clock[0] = time.perf_counter()
+        idx = O.matcher(logits[layer], masks[layer], tg, coords, 0.0, 5.0, 5.0); lap("matcher_incl_lsap")
+        if layer == NL - 1:
+            O.loss_labels(logits[layer], idx)
+        O.loss_masks(masks[layer], tg, idx, num_masks, P=P, rng=rng); lap("loss_labels_masks")
+    clock[0] = time.perf_counter()
+    O.kd_targets(logits[-1][0], masks[-1][0], x.shape[2], x.shape[3]); lap("kd_target_prep")
+    return st
+
+
+def _warm_oracle(cores, threadpool_limits):
+    from oracle import oracle_np as O
+    O.lib().orc_set_threads(cores)
+    if threadpool_limits is None:
+        _oracle_sample("tiny", 1)
+    else:
+        with threadpool_limits(limits=cores):
+            _oracle_sample("tiny", 1)
 
 
 def cpu_baseline(cfg_name):
-    """the CPU oracle (`kind: "port"`: oracle/oracle_np.py, numpy + the plain-C kernels of oracle/s2d_oracle.c) timed on a
-    bounded sample of the same workload, rank 0, N = 1 only, at two thread counts as SURVEY.md 8d asks: all host cores (BLAS
-    threads; the python loops around them are single-threaded) on one 2-frame clip, and ONE thread on one 1-frame clip.
-    Both are extrapolated, and say so: the KD step also runs the teacher forward and the KD criterion (x2 per frame)."""
+    """the CPU oracle (`kind: "port"`: oracle/oracle_np.py, numpy + the C kernels of oracle/s2d_oracle.c) timed on a bounded sample of
+    the same workload, rank 0, N = 1 only, at two thread counts as SURVEY.md 8d asks: ALL USABLE host cores (BLAS threads for the
+    contractions, OpenMP threads for the oracle's C loops: MSDeformAttn gather, point sampling, bilinear resize -- sized by the
+    process's affinity / cgroup share, not os.cpu_count()) on one 2-frame clip, and ONE thread on one 1-frame clip, each with its
+    per-stage seconds.  Both are extrapolated, and say so: the KD step also runs the teacher forward and the KD criterion (x2)."""
+    from oracle import oracle_np as O
     B, T, H0, W0, Q, P, N = CONFIGS[cfg_name]
-    threads = 1
+    cores = _usable_cores()
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
+
+    def run(nthreads, Ts):
+        omp = O.lib().orc_set_threads(nthreads)
+        if threadpool_limits is None:
+            return _oracle_sample(cfg_name, Ts), omp
+        with threadpool_limits(limits=nthreads):
+            return _oracle_sample(cfg_name, Ts), omp
+
+    _warm_oracle(cores, threadpool_limits)      # thread-pool start-up and library loads are not part of any stage
     Ts = 2
-    dt = _oracle_sample(cfg_name, Ts)
-    out = {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": threads, "kind": "port",
-           "sample": f"oracle port, extrapolated x2: one {Ts}-frame clip {H0}x{W0} (Q={Q}, P={P}, N={N}): student fwd + 10-layer GT criterion took "
-                     f"{dt:.1f}s on {threads} BLAS thread(s) of {os.cpu_count()} host cores (numpy; python loops single-threaded); KD step = 2x "
-                     f"(teacher fwd + KD criterion) -> frames/s = {Ts}/(2*{dt:.1f})"}
-    if threadpool_limits is not None and threads > 1:
-        with threadpool_limits(limits=1):
-            dt1 = _oracle_sample(cfg_name, 1)
+    st, omp = run(cores, Ts)
+    dt = sum(st.values())
+    out = {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": cores, "kind": "port",
+           "sample": f"oracle port, extrapolated x2: one {Ts}-frame clip {H0}x{W0} (Q={Q}, P={P}, N={N}): student fwd + 10-layer GT criterion + KD "
+                     f"target prep took {dt:.1f}s on {cores} threads (BLAS and OpenMP {omp}; usable cores of {os.cpu_count()} host threads; python "
+                     f"loops between the kernels single-threaded); KD step = 2x (teacher fwd + KD criterion) -> frames/s = {Ts}/(2*{dt:.1f})",
+           "stage_seconds": {k: round(v, 3) for k, v in st.items()}}
+    if cores > 1:
+        st1, _ = run(1, 1)
+        dt1 = sum(st1.values())
         out["single_thread"] = {"value": round(1 / (2.0 * dt1), 5), "unit": "clip-frames/s", "cores": 1,
-                                "sample": f"oracle port, extrapolated x2: one 1-frame clip {H0}x{W0}, same stages, {dt1:.1f}s on 1 thread -> 1/(2*{dt1:.1f})"}
+                                "sample": f"oracle port, extrapolated x2: one 1-frame clip {H0}x{W0}, same stages, {dt1:.1f}s on 1 thread -> 1/(2*{dt1:.1f})",
+                                "stage_seconds": {k: round(v, 3) for k, v in st1.items()}}
+        O.lib().orc_set_threads(cores)
     return out
 
 
@@ -488,9 +544,10 @@ def main():
         events_note = "HIP events around every dense launch inside the timed region"
     model.overlap_teacher = model.overlap_criteria = two
 
-    # Extra report, never `value`: the same step with AMP COMPUTE on -- the arithmetic the reference itself trains in (every shipped
-    # yaml sets SOLVER.AMP.ENABLED, engine/train_loop.py:709 `with autocast():`): single-pass fp16 MFMA with f32 accumulation for
-    # the modules autocast runs in fp16 (R50 trunk, video decoder linears, mask-logit einsum); pixel decoder, matcher, losses as above.
+    # Extra report, never `value`: the same step with AMP COMPUTE on -- fp16-operand / f32-accumulate contractions with f32 outputs
+    # (autocast-LIKE: every shipped yaml sets SOLVER.AMP.ENABLED, engine/train_loop.py:709 `with autocast():`, but real autocast also
+    # rounds each output to fp16): single-pass fp16 MFMA for the modules autocast runs in fp16 (R50 trunk, video decoder linears,
+    # mask-logit einsum); pixel decoder, matcher, losses as above.
     amp_res = None
     if not args.no_amp and args.dense == "f16x3":
         from s2d_amd.modeling import set_amp_compute
@@ -499,9 +556,9 @@ def main():
             n_amp = max(args.steps // 2, 2)
             dt_amp, tot_amp, _ = timed(False, two, n_amp, 1)
             dt_amp = _max_over_ranks(dt_amp, world, cdev or dev)
-            amp_res = {"what": "same workload and schedule, AMP compute on (s2d_amd.modeling.set_amp_compute): fp16 operands / f32 accumulate, one MFMA pass, in "
-                               "the R50 trunk, the video decoder's linear layers and the mask-logit einsum -- the modules torch.autocast runs in fp16 in the "
-                               "reference; pixel decoder, matcher and losses unchanged (fp32-class)",
+            amp_res = {"what": "same workload and schedule, AMP compute on (s2d_amd.modeling.set_amp_compute): fp16 operands / f32 accumulate / f32 outputs (autocast-like, not autocast's exact "
+                               "arithmetic), one MFMA pass, in the R50 trunk, the video decoder's linear layers and the mask-logit einsum -- the modules "
+                               "torch.autocast runs in fp16 in the reference; pixel decoder, matcher and losses unchanged (fp32-class)",
                        "value": round(world * B * T * n_amp / dt_amp, 3), "unit": "clip-frames/s", "ms_per_step": round(1000 * dt_amp / n_amp, 3),
                        "steps": n_amp, "loss_total_finite": bool(torch.isfinite(tot_amp)),
                        "hbm_roofline_frac": round(world * B * T * n_amp / dt_amp / world * 19.0 / 8000.0, 4) if args.config == "c4" else None}

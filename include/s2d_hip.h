@@ -90,6 +90,22 @@ int s2d_gemm_nt_presplit_f32(const void *A_split, const float *B, float *C, int 
 long s2d_split_weights_words(int N, int K);
 int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hipStream_t stream);
 
+/* The encoder layer's feed-forward block in one launch (split-fp16 x3 arithmetic, dense mode 2's):
+ *     xn = ln1_gamma ? LayerNorm(x; ln1_gamma, ln1_beta, eps) : x
+ *     y  = LN2?( xn + dropout_p( W2 . dropout_p( relu( W1 . xn + b1 ) ) + b2 ) )      LN2 applied when ln2_gamma != NULL
+ * i.e. `src = norm2(src + dropout3(linear2(dropout2(relu(linear1(src))))))` of MSDeformAttnTransformerEncoderLayer
+ * (mask2former/modeling/pixel_decoder/msdeformattn.py:116-131), optionally with the layer's norm1 (:125) folded into the input side.
+ * The F-wide hidden activation stays in registers.  x, y [M, C] fp32 (C = 256; F a multiple of 32, <= 2048); pack = the image
+ * s2d_ffn_pack_f16 wrote from W1 [F, C] and W2 [C, F] (s2d_ffn_pack_words(C, F) 32-bit words; -1 = unsupported sizes).
+ * Dropout: p = 0 -> none; otherwise the counter-based masks of s2d_gemm_nt_dropout_f32 for (seed, site_hidden) on the [M, F] hidden
+ * activation and (seed, site_out) on the [M, C] output, mask row of row 0 = row0 -- the same bits the two-launch form applies.
+ * xn (optional, requires ln1_gamma): receives the normalised input. */
+long s2d_ffn_pack_words(int C, int F);
+int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, void *out, hipStream_t stream);
+int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, const float *b1, const float *b2, const float *ln1_gamma,
+                      const float *ln1_beta, const float *ln2_gamma, const float *ln2_beta, float eps, float p, uint64_t seed,
+                      unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, hipStream_t stream);
+
 /* NHWC convolution as implicit GEMM: x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
  * y [N,Ho,Wo,Cout] = act(conv(x,w) * scale[Cout] + bias[Cout] + res).  Replaces detectron2 Conv2d+FrozenBN+ReLU
  * of the R50 trunk (build_resnet_backbone, call site kd_video_maskformer_model.py:132,135) and the FPN
@@ -98,9 +114,9 @@ int s2d_conv2d_nhwc_f32(const float *x, const float *w, float *y, int N, int H, 
                         int KW, int stride, int pad, const float *scale, const float *bias, const float *res,
                         int relu, const void *w_split, hipStream_t stream);
 
-/* The two contractions in the arithmetic torch.autocast gives the reference (engine/train_loop.py:709 `with autocast():`,
- * SOLVER.AMP.ENABLED True in every shipped yaml): operands rounded to fp16 (nearest-even), f32 accumulation by ONE fp16 MFMA per
- * product, f32 out.  Opt-in, for the modules autocast runs in fp16 (the R50 trunk, the video decoder's linear layers, the
+/* The two contractions with fp16 operands / f32 accumulate / f32 output -- autocast-LIKE (engine/train_loop.py:709 `with autocast():`,
+ * SOLVER.AMP.ENABLED True in every shipped yaml; real autocast additionally rounds every output to fp16): operands rounded to fp16
+ * (nearest-even), f32 accumulation by ONE fp16 MFMA per product, f32 out.  Opt-in, for the modules autocast runs in fp16 (the R50 trunk, the video decoder's linear layers, the
  * mask-logit einsum); the pixel decoder and the matcher force fp32 in the reference (msdeformattn.py:314, matcher.py:266-268) and
  * never take these.  Same arguments as s2d_gemm_nt_f32 / s2d_conv2d_nhwc_f32 without the pre-split image. */
 int s2d_gemm_nt_amp_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc, int batch,
@@ -142,7 +158,8 @@ int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host,
  * spatial_shapes.data<int64_t>() / level_start_index.data<int64_t>() straight to the kernels; the module builds both tensors
  * fresh on every forward, msdeformattn.py:82-83).  No host copy, no cache, no synchronisation: a one-thread kernel turns the two
  * tensors into the geometry record at the head of `workspace` and every kernel of the call reads it from there.
- * Shapes that fail the host form's argument checks (H, W <= 0; a level past S) cannot be reported through the return code
+ * Shapes that fail the host form's argument checks (H, W <= 0; a level past S), or whose levels overlap (sum of H*W > S: the
+ * reference would read the shared rows twice; the sorted backward's workspace is sized for disjoint levels), cannot be reported through the return code
  * without a sync: the call then produces zeros and sets the record's error flag, which s2d_msda_dev_status reads back.
  * workspace: s2d_msda_dev_forward_workspace_bytes() / s2d_msda_dev_backward_workspace_bytes(...) bytes of device memory, 16-B
  * aligned, private to the call until it has finished.  The backward is the atomic-free sorted form. */
@@ -155,6 +172,12 @@ int s2d_msda_backward_dev_f32(const float *value, const int64_t *shapes_dev, con
                               const float *attn_w, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                               float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace, long workspace_bytes,
                               hipStream_t stream);
+/* Failing loudly without a sync: `word` is an int in memory that both the GPU and the host can address (pinned host memory, e.g.
+ * hipHostMalloc / torch's pin_memory; NULL: none), registered once for the process.  A *_dev call whose shapes are rejected stores 1
+ * into it (system scope, never cleared by the library): the caller tests the word with a plain host read before / after its calls and
+ * raises -- at the latest one call after the offending one has executed -- instead of training on zeros.  The drop-in module
+ * (s2d_amd/compat/MultiScaleDeformableAttention.py) does exactly that. */
+int s2d_msda_dev_error_word(int *word);
 /* *err_host = the error flag of the *_dev call that used `workspace` (0 = shapes accepted).  Synchronises `stream`. */
 int s2d_msda_dev_status(const void *workspace, int *err_host, hipStream_t stream);
 
@@ -500,7 +523,9 @@ int s2d_visibility_curve_f32(const uint8_t *visibility, int T, int Np, float *cu
 /* K1 (co-tracker is not in the reference tree; self-defined restatement, parity unpinned): local 4-D correlation
  * corr[t][n][i][j] = <bilinear(fmap[t], coords[t][n] + offset_i), support[n][j]> over C channels, offsets on the
  * (2r+1)^2 integer grid, zero padding.  fmap NHWC [T][H][W][C], coords [T][Np][2] in pixels of this level,
- * support [Np][(2r+1)^2][C], corr [T][Np][(2r+1)^2][(2r+1)^2]. */
+ * support [Np][(2r+1)^2][C], corr [T][Np][(2r+1)^2][(2r+1)^2].
+ * Contract: C a multiple of 4 (16-B channel vectors), 0 <= r <= 3 (co-tracker's correlation radius is 3; a thread grid of
+ * ceil(S/4)^2 <= 256 threads covers the S x S outputs), (S + 1)(C + 4) * 8 bytes of LDS <= 96 KB; anything else returns S2D_ERR_ARG. */
 int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float *support, int T, int Np, int H, int W, int C,
                        int r, float *corr, hipStream_t stream);
 
@@ -529,6 +554,13 @@ int s2d_aug_warp_frames_u8(const uint8_t *frames, int T, int H0, int W0, void *a
  * pixel (apply_segmentation). */
 int s2d_aug_warp_masks_u8(const uint8_t *masks, int N, int T, int H0, int W0, const void *aug_frames_dev, int H1, int W1, uint8_t *out,
                           hipStream_t stream);
+
+/* Sparse-mask densification of the trainer (`propagate_sparse_masks`, mask2former_video/engine/train_loop.py:30-156): all output
+ * planes of a clip in one launch.  plan_dev: n_planes records {uint64 address of a source plane (bool / u8 [H, W], device memory),
+ * int32 dx, int32 dy} (16 bytes each); out [n_planes][H][W] u8: out[j][y][x] = src_j[y + dy][x + dx] != 0 inside the frame, else 0 --
+ * the reference's `_translate` (:58-68) for the instances an id's last sighting fills in, dx = dy = 0 for the instances a frame keeps.
+ * Which planes, and the (dx, dy) draws in the reference's `random.randint` order, are the host's plan (s2d_amd/data/copy_paste.py). */
+int s2d_shift_planes_u8(const void *plan_dev, int n_planes, int H, int W, uint8_t *out, hipStream_t stream);
 
 /* One target frame of the trainer's video copy-paste loop exactly as written (engine/train_loop.py:445-570): the K copied masks
  * cur_masks [K][Hc][Wc] -- the source masks at the first frame, the PREVIOUS frame's canvas afterwards (the reference reassigns

@@ -1,8 +1,12 @@
 /*
  * oracle/s2d_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * Plain-C, single-threaded CPU restatement of the loops of the S2D hot path that
- * are too slow in numpy.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * Plain-C CPU restatement of the loops of the S2D hot path that are too slow in
+ * numpy.  The loops whose outputs are independent (MSDeformAttn forward, point
+ * sampling, bilinear resize) carry OpenMP pragmas so that bench.py's all-core
+ * CPU baseline really uses the host's cores (orc_set_threads; results do not
+ * depend on the thread count: every output element is computed by one thread
+ * in the same order of operations).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; s2d_amd never does.
  *
  * Every function cites the reference lines it restates (paths relative to
@@ -13,6 +17,21 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads of the parallel loops below (<= 0: the OpenMP default); returns the count now in force */
+int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------- *
  * MSDeformAttn core, forward.
@@ -25,6 +44,7 @@
     void NAME(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *w, \
               int N, int S, int M, int D, int L, int Lq, int P, T *out)                            \
     {                                                                                              \
+        _Pragma("omp parallel for collapse(2) schedule(static)")                                   \
         for (int n = 0; n < N; ++n)                                                                \
             for (int q = 0; q < Lq; ++q)                                                           \
                 for (int m = 0; m < M; ++m) {                                                      \
@@ -120,6 +140,7 @@ void orc_msda_backward_f32(const float *value, const int64_t *shapes, const int6
  * ------------------------------------------------------------------------- */
 void orc_point_sample_f32(const float *in, const float *coords, int R, int C, int H, int W, int P, float *out)
 {
+#pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < R; ++r)
         for (int p = 0; p < P; ++p) {
             const float u = coords[((size_t)r * P + p) * 2], v = coords[((size_t)r * P + p) * 2 + 1];
@@ -144,6 +165,7 @@ void orc_point_sample_f32(const float *in, const float *coords, int R, int C, in
 /* same, input uint8 {0,1} masks (targets are stored as bytes by the product path) */
 void orc_point_sample_u8(const uint8_t *in, const float *coords, int R, int C, int H, int W, int P, float *out)
 {
+#pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < R; ++r)
         for (int p = 0; p < P; ++p) {
             const float u = coords[((size_t)r * P + p) * 2], v = coords[((size_t)r * P + p) * 2 + 1];
@@ -174,6 +196,7 @@ void orc_point_sample_u8(const uint8_t *in, const float *coords, int R, int C, i
 void orc_resize_bilinear_f32(const float *in, int R, int H, int W, int OH, int OW, float *out)
 {
     const float sh = (float)H / OH, sw = (float)W / OW;
+#pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < R; ++r)
         for (int oy = 0; oy < OH; ++oy) {
             float sy = sh * (oy + 0.5f) - 0.5f; if (sy < 0) sy = 0;

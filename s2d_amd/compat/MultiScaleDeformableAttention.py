@@ -22,6 +22,35 @@ lib()          # fail at import, loudly, when libs2d_hip.so is absent (ms_deform
 
 _DEBUG = bool(int(os.environ.get("S2D_MSDA_CHECK", "0")))    # 1: read the device-side shape check back after every call (syncs)
 
+# Rejected shapes fail loudly WITHOUT a sync: the device-side check of every call also sets this pinned host word (system-scope store,
+# s2d_msda_dev_error_word); the host looks at it with a plain memory read on entry to every call and in check(), so a mis-shaped call
+# raises at the next call that follows its execution (or at check(), which synchronises) instead of training on zeros.
+_WORD = None
+_MSG = ("MultiScaleDeformableAttention: a previous call's spatial_shapes / level_start_index did not describe `value` "
+        "(H, W > 0, every level inside S, levels not overlapping); that call produced zeros")
+
+
+def _word():
+    global _WORD
+    if _WORD is None:
+        _WORD = torch.zeros(1, dtype=torch.int32).pin_memory()
+        lib().call("s2d_msda_dev_error_word", _WORD)
+    return _WORD
+
+
+def _raise_if_flagged():
+    w = _word()
+    if int(w[0]) != 0:
+        w[0] = 0
+        raise RuntimeError(_MSG)
+
+
+def check():
+    """synchronise the current stream and raise if any call so far was given shapes that do not describe its `value`"""
+    _word()
+    torch.cuda.current_stream().synchronize()
+    _raise_if_flagged()
+
 
 def _check(name, t, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -35,6 +64,7 @@ def _check(name, t, dtype=torch.float32):
 def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     _check("value", value); _check("sampling_loc", sampling_loc); _check("attn_weight", attn_weight)
     _check("spatial_shapes", spatial_shapes, torch.int64); _check("level_start_index", level_start_index, torch.int64)
+    _raise_if_flagged()
     batch = value.shape[0]
     step = min(batch, int(im2col_step))
     if step <= 0 or batch % step != 0:
@@ -43,6 +73,7 @@ def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
 
 def _status(ws):
     if _DEBUG and ops.msda_dev_status(ws):
+        _word()[0] = 0
         raise RuntimeError("spatial_shapes / level_start_index do not describe `value` (H, W > 0 and every level inside S)")
 
 

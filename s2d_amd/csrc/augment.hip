@@ -257,6 +257,34 @@ __global__ __launch_bounds__(256) void copy_paste_frame_kernel(const uint8_t *__
     }
 }
 
+// ---- sparse-mask densification (engine/train_loop.py:30-156): every output plane of a clip in ONE launch ------------------------------
+// plan row j = {address of the source plane (bool / u8 [H, W]), dx, dy}: out[j][y][x] = src[y + dy][x + dx] inside the frame, else 0.
+// Kept instances are rows with dx = dy = 0 (the reference concatenates them in front of the synthesised ones), filled instances read
+// the plane of the frame the id was last seen in.  16 output bytes per thread; a shifted row is read with unaligned byte loads only on
+// the planes that are shifted (dx != 0).
+struct ShiftPlan { unsigned long long src; int dx, dy; };
+
+__global__ __launch_bounds__(256) void shift_planes_kernel(const ShiftPlan *__restrict__ plan, int H, int W, uint8_t *__restrict__ out)
+{
+    const ShiftPlan pl = plan[blockIdx.y];
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(pl.src);
+    uint8_t *dst = out + (size_t)blockIdx.y * H * W;
+    const long npix = (long)H * W;
+    for (long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16; i0 < npix; i0 += (long)gridDim.x * 256 * 16) {
+        const bool fast = pl.dx == 0 && pl.dy == 0 && i0 + 16 <= npix && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+        if (fast) {
+            *reinterpret_cast<uint4 *>(dst + i0) = *reinterpret_cast<const uint4 *>(src + i0);
+            continue;
+        }
+        int y = (int)(i0 / W), x = (int)(i0 - (long)y * W);
+        for (int e = 0; e < 16 && i0 + e < npix; ++e) {
+            const int sy = y + pl.dy, sx = x + pl.dx;
+            dst[i0 + e] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? (src[(long)sy * W + sx] != 0) : 0;
+            if (++x == W) { x = 0; ++y; }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,6 +346,18 @@ int s2d_copy_paste_u8(const uint8_t *tgt_frames, const uint8_t *tgt_masks, int N
     if (N < 0 || K <= 0 || T <= 0 || H <= 0 || W <= 0 || H > 65535) return S2D_ERR_ARG;
     hipLaunchKernelGGL(copy_paste_kernel, dim3(cdiv(W, 256), H, T), dim3(256), 0, stream, tgt_frames, tgt_masks, N, T, H, W, src_frame, src_masks, K,
                        Hs, Ws, reinterpret_cast<const PasteFrame *>(paste_frames_dev), keep_dev, out_frames, out_masks);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_shift_planes_u8(const void *plan_dev, int n_planes, int H, int W, uint8_t *out, hipStream_t stream)
+{
+    if (n_planes < 0 || H < 0 || W < 0 || (n_planes && (!plan_dev || !out)) || n_planes > 65535) return S2D_ERR_ARG;
+    if (n_planes == 0 || (long)H * W == 0) return S2D_OK;
+    const long npix = (long)H * W;
+    int gx = cdiv(npix, 256 * 16);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(shift_planes_kernel, dim3(gx, n_planes), dim3(256), 0, stream, reinterpret_cast<const ShiftPlan *>(plan_dev), H, W, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -16,6 +16,25 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: a process that drives several GPUs must set it on each, so the
+// launchers' "already set" state is a bit per device of the calling thread's current device (atomic: host threads may race to set it)
+#include <atomic>
+struct S2dDevOnce {
+    std::atomic<unsigned long long> bits[4];
+    bool done() const
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return false;     // unknown device: set the attribute again (cheap)
+        return (bits[d >> 6].load(std::memory_order_relaxed) >> (d & 63)) & 1ull;
+    }
+    void mark()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return;
+        bits[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_relaxed);
+    }
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Zero `bytes` bytes with a kernel on `stream`.  Used instead of hipMemsetAsync: the

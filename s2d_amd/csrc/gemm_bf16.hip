@@ -1799,12 +1799,12 @@ template <bool CONV, bool PIPE, bool BSPLIT, bool DROP = false>
 int launch_f16_v(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel<CONV, PIPE, BSPLIT, DROP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
     hipLaunchKernelGGL((gemm_f16x3_kernel<CONV, PIPE, BSPLIT, DROP>), dim3(nwg, batch), dim3(256), lds, st, p);
@@ -1840,9 +1840,9 @@ template <bool CONV, bool BSPLIT, bool DROP, bool RES, bool ASPLIT = false>
 int launch_f16_ws_v(const GemmParams &p, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned int) * 2 * (128 + BN) * ROWW + sizeof(float) * 4 * 64 * 68;
-    static bool attr_set = false;
+    static S2dDevOnce attr_set;
     static int cus = 0;
-    if (!attr_set) {
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_ws_kernel<CONV, BSPLIT, DROP, RES, ASPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
@@ -1850,7 +1850,7 @@ int launch_f16_ws_v(const GemmParams &p, hipStream_t st)
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return S2D_ERR_LAUNCH;
         cus = prop.multiProcessorCount;
-        attr_set = true;
+        attr_set.mark();
     }
     const int nwg = cdiv(p.M, 128) * cdiv(p.N, BN);
     GemmParams q = p;
@@ -1877,11 +1877,11 @@ int launch_conv7x7s2_stem(const GemmParams &p, hipStream_t st)
     static int ph = -1;
     if (ph < 0) { const char *e = getenv("S2D_CONV_STEM_PH"); ph = e ? atoi(e) : 8; }
     const size_t lds16 = sizeof(float) * 4 * 64 * 68, lds8 = sizeof(float) * 4 * 32 * 68;       // epilogue staging >= halo planes + two weight buffers
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv7x7s2_c4_halo_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     const int imgs = p.M / (p.Hout * p.Wout);
     if (ph == 16) hipLaunchKernelGGL(conv7x7s2_c4_halo_kernel<16>, dim3(imgs * cdiv(p.Hout, 16) * cdiv(p.Wout, ST_P)), dim3(256), lds16, st, p);
@@ -1893,12 +1893,12 @@ int launch_conv7x7s2_stem(const GemmParams &p, hipStream_t st)
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t st)
 {
     const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 / 65.1 KB)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     const int imgs = p.M / (p.Hin * p.Win);
     if (p.N <= 64) {
@@ -1916,12 +1916,12 @@ template <bool CONV, bool BSPLIT>
 int launch_w128_v(const GemmParams &p, int batch, hipStream_t st)
 {
     const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= operand buffer (55.3 KB)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_w128_kernel<CONV, BSPLIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     const int nwg = cdiv(p.M, 256) * cdiv(p.N, BN);
     hipLaunchKernelGGL((gemm_bf16x3_w128_kernel<CONV, BSPLIT>), dim3(nwg, batch), dim3(256), lds, st, p);
@@ -1940,12 +1940,12 @@ int launch_t(const GemmParams &p, int batch, hipStream_t st)
 {
     constexpr int BM = 64 * WM;
     const size_t lds = sizeof(unsigned int) * 2 * (BM + BN) * ROWW;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_kernel<WM, CONV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
     hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, CONV>), dim3(nwg, batch), dim3(128 * WM), lds, st, p);

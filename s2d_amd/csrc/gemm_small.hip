@@ -127,11 +127,11 @@ template <int NW>
 int launch_small(const GemmParams &p, hipStream_t st)
 {
     const size_t lds = (size_t)NW * TM * RS * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
+    static S2dDevOnce attr;
+    if (!attr.done() && lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_small_m_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr = true;
+        attr.mark();
     }
     const int nwg = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
     hipLaunchKernelGGL((gemm_small_m_kernel<NW>), dim3(nwg), dim3(NW * 64), lds, st, p, p.K / NW);

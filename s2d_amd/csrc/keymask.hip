@@ -378,25 +378,17 @@ int s2d_local_corr_f32(const float *fmap_nhwc, const float *coords, const float 
     if (lds > 96 * 1024 || TB > 16) return S2D_ERR_ARG;
 #define S2D_LC(tb)                                                                                                              \
     case tb: {                                                                                                                  \
-        static bool set = false;                                                                                                \
-        if (!set && lds > 48 * 1024) {                                                                                          \
+        static S2dDevOnce set;                                                                                                \
+        if (!set.done() && lds > 48 * 1024) {                                                                                          \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_kernel<tb>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) \
                 return S2D_ERR_LAUNCH;                                                                                          \
-            set = true;                                                                                                         \
+            set.mark();                                                                                                         \
         }                                                                                                                       \
         hipLaunchKernelGGL(local_corr_kernel<tb>, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr); \
     } break;
     switch (TB) {
         S2D_LC(1) S2D_LC(3) S2D_LC(7) S2D_LC(13)                              // r = 0, 1, 2, 3
-    default: {
-        static bool set16 = false;
-        if (!set16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-                return S2D_ERR_LAUNCH;
-            set16 = true;
-        }
-        hipLaunchKernelGGL(local_corr_kernel<16>, dim3(Np, T), dim3(256), lds, stream, fmap_nhwc, coords, support, T, Np, H, W, C, r, corr);
-    }
+    default: return S2D_ERR_ARG;                                           // S = (2r+1)^2 <= 64 gives TB in {1, 3, 7, 13} only
     }
 #undef S2D_LC
     S2D_CHECK_LAUNCH();

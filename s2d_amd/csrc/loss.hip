@@ -941,7 +941,14 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     // fits ((rpp + 3) wm ints <= PART_BYTES by part_geom).  The up-to-three rows two consecutive tiles share are carried over as
     // integers, so a pixel's sum is still one integer sum over all its taps.
     int *gh = reinterpret_cast<int *>(tbits);
-    constexpr float FX_CAP = 1024.f;
+    // FX_CAP = the number of unit tap weights a pixel may collect without its int32 sum wrapping.  A point adds at most weight 1 to a
+    // pixel, so n_unc + n_rand is a PROVABLE cap; 1024 is the density argument above and holds only for generator-drawn (i.i.d. uniform)
+    // points on maps much larger than the point density: with injected coordinates (any clustering / duplicates) and on small maps
+    // (expected taps per pixel x 64 > 1024) the provable cap is used instead -- ~3.6 bits coarser at 12 544 points, still <= 2^-17 of
+    // the bound per contribution.
+    const float n_pts = (float)(p.n_unc + p.n_rand);
+    const bool injected = p.coords_over != nullptr || p.coords_rand != nullptr;
+    const float FX_CAP = injected ? fmaxf(n_pts, 1.f) : fminf(fmaxf(n_pts, 1.f), fmaxf(1024.f, 256.f * n_pts / (float)(p.hm * p.wm)));
     __shared__ unsigned int tie_before;                      // ties with a smaller point index than the current part's (earlier parts)
     for (int li = blockIdx.x; li < nrows; li += gridDim.x) {
         const long rowid = p.list[li];
@@ -1425,8 +1432,8 @@ static int loss_setup(LossParams &p, long &rows, const float *mask_logits, const
 
 static int loss_attrs()
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         const int cap = PART_BYTES + 8192 + 4096;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
@@ -1435,7 +1442,7 @@ static int loss_attrs()
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     return S2D_OK;
 }

@@ -806,14 +806,14 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     const int npairs = nprob * T;
     const int grid = ((npairs + 7) / 8) * 8 * CHM;
     const size_t lds_rows = sizeof(float) * 2 * ROWS * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static S2dDevOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_rows) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_q16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_rows) != hipSuccess)
             return S2D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     // opt-in (read per call): measured slower, profiles/r3_experiments/not_adopted.txt -- four point groups per wave read four staged
     // logit rows at once and every row starts at bank 0

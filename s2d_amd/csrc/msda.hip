@@ -1108,7 +1108,7 @@ static int launch_backward_sorted(const G &geo, long ncell_cap, const float *val
 // Device-shape form: one thread turns the reference op's two int64 DEVICE tensors into the Geom the kernels read (the checks of
 // fill_levels, on the device: a geometry that fails them becomes "every level empty" + err = 1, so no kernel indexes by it).
 __global__ void msda_geom_kernel(const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, int L, long S, int N, int M,
-                                 Geom *__restrict__ g)
+                                 Geom *__restrict__ g, int *sticky)
 {
     if (threadIdx.x | blockIdx.x) return;
     bool ok = true;
@@ -1123,6 +1123,10 @@ __global__ void msda_geom_kernel(const int64_t *__restrict__ shapes, const int64
         g->cl.base[l] = (int)cells;
         if (l < L) { tot += H * W; cells += (H + 1) * (W + 1); }
     }
+    // overlapping levels (sum of H*W > S, e.g. every level_start_index 0) pass the per-level test above but make more bilinear cells
+    // than the workspace and the sort-key width were sized for (dev_ncell_cap = N*M*(2S + 2L) assumes sum(H*W) <= S; every H, W >= 1
+    // gives (H+1)(W+1) <= 2HW + 2): such geometry takes the rejected path (zeros + flag)
+    ok = ok && tot <= S && cells <= 2 * S + 2 * (long)L;
     ok = ok && (long)N * M * cells < (1L << 32) - 1;
     if (!ok) {
         cells = 0;
@@ -1135,6 +1139,9 @@ __global__ void msda_geom_kernel(const int64_t *__restrict__ shapes, const int64
     g->cl.tot = (int)cells;
     g->kmax = (unsigned int)((long)N * M * cells);
     g->err = ok ? 0 : 1;
+    // the process's error word (s2d_msda_dev_error_word; pinned host memory in the drop-in module): set, never cleared, by a rejected
+    // call, so that the host learns of it without synchronising -- by its next look at the word
+    if (!ok && sticky) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static long dev_ncell_cap(int N, int S, int M, int L)
@@ -1143,10 +1150,13 @@ static long dev_ncell_cap(int N, int S, int M, int L)
     return (long)N * M * (2L * S + 2L * L);
 }
 
+static std::atomic<int *> g_error_word{nullptr};     // s2d_msda_dev_error_word
+
 static int launch_geom(const int64_t *shapes_dev, const int64_t *lsi_dev, int L, long S, int N, int M, void *workspace, hipStream_t stream)
 {
     if (L < 1 || L > MAX_L || !shapes_dev || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return S2D_ERR_ARG;
-    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(64), 0, stream, shapes_dev, lsi_dev, L, S, N, M, reinterpret_cast<Geom *>(workspace));
+    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(64), 0, stream, shapes_dev, lsi_dev, L, S, N, M, reinterpret_cast<Geom *>(workspace),
+                       g_error_word.load(std::memory_order_relaxed));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1230,6 +1240,12 @@ int s2d_msda_backward_dev_f32(const float *value, const int64_t *shapes_dev, con
     GeomPtr gp{reinterpret_cast<const Geom *>(workspace)};
     return launch_backward_sorted(gp, dev_ncell_cap(N, S, M, L), value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc,
                                   grad_attn_w, reinterpret_cast<char *>(workspace) + GEOM_BYTES, workspace_bytes - GEOM_BYTES, stream);
+}
+
+int s2d_msda_dev_error_word(int *word)
+{
+    g_error_word.store(word, std::memory_order_relaxed);
+    return S2D_OK;
 }
 
 int s2d_msda_dev_status(const void *workspace, int *err_host, hipStream_t stream)
@@ -1328,11 +1344,11 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
             win_ok = R >= 1;
         }
         if (win_ok) {
-            static bool attr = false;
-            if (!attr) {
+            static S2dDevOnce attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_win_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 640 * 128) != hipSuccess)
                     return S2D_ERR_LAUNCH;
-                attr = true;
+                attr.mark();
             }
             const int npatch = ((lv.W[lq] + 7) / 8) * ((lv.H[lq] + 7) / 8);
             hipLaunchKernelGGL((msda_fused_win_kernel<3, 4>), dim3(npatch, N), dim3(512), (size_t)(wg.basey + ((wg.ny + 7) & ~7)) * 128, stream, value, ldv, lv, wg, offs_logits,

@@ -13,14 +13,12 @@ import torch
 
 
 def clip_id_slots(video_annos, selected_idx):
-    """:297-303: {annotation id: slot}"""
-    _ids = set()
-    for frame_idx in selected_idx:
-        _ids.update([anno["id"] for anno in video_annos[frame_idx]])
-    ids = dict()
-    for i, _id in enumerate(_ids):
-        ids[_id] = i
-    return ids
+    """{annotation id: slot}: slots number the clip's distinct annotation ids in the ITERATION order of the Python set they were
+    collected into frame by frame (dataset_mapper.py:297-303) -- that order, not sorted order, is the contract the goldens pin"""
+    distinct = set()
+    for f in selected_idx:
+        distinct.update(a["id"] for a in video_annos[f])
+    return {aid: slot for slot, aid in enumerate(distinct)}
 
 
 def assemble_clip_instances(video_annos, selected_idx, image_shape, num_classes, device="cuda", box_threshold=1e-5):

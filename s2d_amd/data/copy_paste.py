@@ -1,6 +1,8 @@
-"""Video copy-paste and sparse-mask densification of the trainer, for clips that live on the GPU: a statement-by-statement mirror of
+"""Video copy-paste and sparse-mask densification of the trainer, for clips that live on the GPU: the behaviour of
 model_training/mask2former_video/engine/train_loop.py:30-156 (`propagate_sparse_masks`) and :377-590
 (`CustomSimpleTrainer.copy_and_paste`), pinned by tests/golden/copy_paste.npz (written by the reference's own two functions).
+`propagate_sparse_masks` is a plan-then-launch design (host: id tables -> fill plan with the reference's RNG draw order; device: all
+planes of the clip in one launch); `copy_and_paste` replays the reference loop's decisions on integer tables after one launch per frame.
 
 What is mirrored, including what looks accidental in the reference but is what it ships:
   * the order and number of draws from `random` and `numpy.random` -- also on a rate miss or with no source instance, where the
@@ -48,51 +50,85 @@ def _masks(fr, device=None):
 
 
 # ------------------------------------------------------------------------------------------------ propagate_sparse_masks (:30-156)
-def _translate(mask_hw, dx, dy):
-    """:58-68"""
-    H, W = mask_hw.shape[-2], mask_hw.shape[-1]
-    outm = torch.zeros_like(mask_hw)
-    xs, xt = slice(max(0, dx), min(W, W + dx)), slice(max(0, -dx), min(W, W - dx))
-    ys, yt = slice(max(0, dy), min(H, H + dy)), slice(max(0, -dy), min(H, H - dy))
-    if (xt.stop - xt.start) > 0 and (yt.stop - yt.start) > 0:
-        outm[yt, xt] = mask_hw[ys, xs]
-    return outm
+def _host_ids_classes(frames):
+    """every frame's ids and classes as host int64 arrays; device-resident ones come over in ONE copy for the clip"""
+    vals, on_dev = [], []
+    for fr in frames:
+        for key in ("gt_ids", "gt_classes"):
+            v = fr[key]
+            vals.append(v)
+            on_dev.append(isinstance(v, torch.Tensor) and v.is_cuda)
+    if any(on_dev):
+        flat = torch.cat([v.reshape(-1).to(torch.int64) for v, d in zip(vals, on_dev) if d]).cpu().numpy()
+        pos = 0
+    out = []
+    for v, d in zip(vals, on_dev):
+        if d:
+            out.append(flat[pos:pos + v.numel()].copy()); pos += v.numel()
+        else:
+            out.append(np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, np.int64).reshape(-1))
+    return out[0::2], out[1::2]
+
+
+def _fill_plan(ids, classes, has_pixels, max_shift):
+    """Which instance planes each frame gains, from the id tables alone.  An id missing from a frame is filled from its LATEST earlier
+    sighting (original planes only: synthesised ones are never sources), ids are visited in order of FIRST sighting, and each fill
+    draws its jitter as two `random.randint(-max_shift, max_shift)` calls, x then y -- the consumption order of the reference loop.
+    -> per frame a list of (source frame, source slot, dx, dy, id, class or None)."""
+    first_seen, latest = [], {}
+    fills = []
+    for t, (ids_t, cls_t) in enumerate(zip(ids, classes)):
+        if has_pixels[t]:
+            for slot, tid in enumerate(ids_t.tolist()):
+                if tid not in latest:
+                    first_seen.append(tid)
+                latest[tid] = (t, slot, int(cls_t[slot]) if slot < len(cls_t) else None)
+        here = set(ids_t.tolist())
+        row = []
+        for tid in first_seen:
+            if tid in here:
+                continue
+            dx = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
+            dy = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
+            ft, fs, fc = latest[tid]
+            row.append((ft, fs, dx, dy, tid, fc))
+        fills.append(row)
+    return fills
 
 
 def propagate_sparse_masks(instances_per_frame, max_shift=2):
-    """fill a frame where an already-seen instance id is missing with that id's most recent mask, jittered by up to max_shift pixels
-    (two `random.randint` draws per filled instance, x then y).  Returns new per-frame dicts; the inputs are not modified."""
+    """Densify a sparsely annotated clip (engine/train_loop.py:30-156): a frame that lacks an instance id seen earlier receives that
+    id's most recent mask, shifted by a random jitter of up to max_shift pixels (out[y][x] = mask[y + dy][x + dx], zero outside).
+    The host only reads the id tables and writes a plan (_fill_plan); every plane of every frame that changes -- kept ones first,
+    filled ones behind them, as the reference concatenates -- is then produced by one launch (s2d_shift_planes_u8) into one
+    buffer the returned frames are views of.  Returns new per-frame dicts; the inputs are not modified."""
     if not instances_per_frame:
         return instances_per_frame
-    out = [_frame(_masks(fr), _ids(fr), _ids(fr, "gt_classes")) for fr in instances_per_frame]
-    last_seen = {}                                                # tid -> (mask [H,W], class): insertion-ordered, as the reference's dict
-    for t, fr in enumerate(out):
-        masks_t, ids_t, cls_t = fr["gt_masks"], fr["gt_ids"], fr["gt_classes"]
-        n = len(ids_t)
-        for i in range(n):
-            if masks_t.numel() > 0:
-                last_seen[int(ids_t[i])] = (masks_t[i], int(cls_t[i]) if i < len(cls_t) else None)
-        present = set(int(x) for x in ids_t.tolist()) if n else set()
-        to_fill = [tid for tid in last_seen if tid not in present]
-        if not to_fill:
-            continue
-        mask_list = [masks_t] if masks_t.numel() > 0 else []
-        new_classes, new_ids = [], []
-        for tid in to_fill:
-            pm, pc = last_seen[tid]
-            dx = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
-            dy = random.randint(-max_shift, max_shift) if max_shift > 0 else 0
-            mask_list.append(_translate(pm, dx, dy)[None])
-            new_ids.append(tid)
-            if pc is not None:
-                new_classes.append(pc)
-        all_masks = torch.cat(mask_list, 0)
-        if n:
-            classes = np.concatenate([cls_t, np.asarray(new_classes, np.int64)]) if new_classes else cls_t
-            ids = np.concatenate([ids_t, np.asarray(new_ids, np.int64)])
-        else:
-            classes, ids = np.asarray(new_classes, np.int64), np.asarray(new_ids, np.int64)
-        out[t] = _frame(all_masks, ids, classes)
+    planes = [_masks(fr).contiguous() for fr in instances_per_frame]
+    ids, classes = _host_ids_classes(instances_per_frame)
+    fills = _fill_plan(ids, classes, [m.numel() > 0 for m in planes], max_shift)
+    out = [_frame(m, i, c) for m, i, c in zip(planes, ids, classes)]
+    changed = [t for t, row in enumerate(fills) if row]
+    if not changed:
+        return out
+    H, W = planes[0].shape[-2:]
+    dev = planes[0].device
+    rows, spans = [], []
+    for t in changed:
+        keep = planes[t].shape[0] if planes[t].numel() > 0 else 0
+        start = len(rows)
+        rows += [(planes[t].data_ptr() + k * H * W, 0, 0) for k in range(keep)]
+        rows += [(planes[ft].data_ptr() + fs * H * W, dx, dy) for ft, fs, dx, dy, _, _ in fills[t]]
+        spans.append((start, len(rows)))
+    table = np.zeros((len(rows),), dtype=[("src", np.uint64), ("dx", np.int32), ("dy", np.int32)])
+    table["src"], table["dx"], table["dy"] = zip(*rows)
+    plan = torch.from_numpy(table.view(np.int64).reshape(-1, 2)).to(dev)
+    buf = torch.empty((len(rows), H, W), dtype=torch.bool, device=dev)
+    lib().call("s2d_shift_planes_u8", plan, len(rows), int(H), int(W), buf, _stream())
+    for t, (a, b) in zip(changed, spans):
+        new_ids = np.asarray([f[4] for f in fills[t]], np.int64)
+        new_cls = np.asarray([f[5] for f in fills[t] if f[5] is not None], np.int64)
+        out[t] = _frame(buf[a:b], np.concatenate([ids[t], new_ids]), np.concatenate([classes[t], new_cls]))
     return out
 
 

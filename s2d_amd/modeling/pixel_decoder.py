@@ -138,6 +138,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout
 
+    fuse_ffn = True      # False: the two-launch FFN + separate LayerNorms also on the forward-only path (A/B measurements, tests)
+
     def forward(self, src, pos, shapes, tape=None):
         """msdeformattn.py:116-131 (post-norm).  src [N,S,C], pos [S,C].
         src = norm1(src + dropout1(attn));  src = norm2(src + dropout3(linear2(dropout2(relu(linear1(src))))))  (:101-125).
@@ -149,6 +151,12 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         d1, d2, d3 = ((p, seed, 0), (p, seed, 1), (p, seed, 2)) if p > 0.0 else (None, None, None)
         sub = [] if tape is not None else None
         x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1)
+        if tape is None and self.fuse_ffn and ops.ffn_fusable(self.linear1.weight, self.linear2.weight):
+            # forward / loss path (nothing kept for a backward): norm1, the whole FFN with both masks, the residual and norm2 in ONE
+            # launch (csrc/ffn.hip) -- the 1024-wide hidden activation never reaches memory.  Same masks as the taped path below.
+            return ops.ffn_fused(x1.view(-1, C), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                 ln1=(self.norm1.weight, self.norm1.bias), ln2=(self.norm2.weight, self.norm2.bias),
+                                 dropout=(p, seed, 1, 2) if p > 0.0 else None, eps=self.norm1.eps).view(N, S, C)
         s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
         h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True, dropout=d2)
         x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C), dropout=d3).view(N, S, C)

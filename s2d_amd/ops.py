@@ -77,6 +77,7 @@ def mark_static(t):
 
 def clear_weight_cache():
     _SPLIT.clear()
+    _FFN_PACK.clear()
 
 
 _SWEEP = [256]
@@ -126,8 +127,8 @@ _AMP = [0]
 
 
 class amp_fp16:
-    """`with ops.amp_fp16(enabled):` -- the dense launches inside take torch.autocast's arithmetic (operands rounded to fp16, f32
-    accumulate, one MFMA pass: s2d_gemm_nt_amp_f32 / s2d_conv2d_nhwc_amp_f32) instead of the fp32-class split.  The modules the
+    """`with ops.amp_fp16(enabled):` -- the dense launches inside take fp16-operand / f32-accumulate / f32-output arithmetic
+    (autocast-like; one MFMA pass: s2d_gemm_nt_amp_f32 / s2d_conv2d_nhwc_amp_f32) instead of the fp32-class split.  The modules the
     reference runs under autocast wrap their forward in it when the model's `amp_compute` is set (engine/train_loop.py:709); the
     pixel decoder and the criterion never do (msdeformattn.py:314, matcher.py:266-268 force fp32).  Forward / loss only: the
     gradient kernels stay fp32-class."""
@@ -244,6 +245,57 @@ def gemm_nt_presplit(A_split, M, K, B, bias=None, res=None, relu=False, out=None
         lib().call("s2d_gemm_nt_presplit_f32", A_split, B, out, M, N, K, K, out.shape[-1], bias, res, res.shape[-1] if res is not None else N,
                    res_rows, res_cols, int(relu), Bs, _stream())
     return out
+
+
+_FFN_PACK = {}    # (W1 ptr, W2 ptr, F) -> (image, (version W1, version W2), weakrefs of the two parameters)
+
+
+def _ffn_pack(W1, W2):
+    """cached MFMA-fragment image of an FFN's two weight matrices (s2d_ffn_pack_f16), rebuilt when either parameter changes"""
+    F, C = W1.shape
+    key = (W1.data_ptr(), W2.data_ptr(), F)
+    b1, b2 = (W1._base if W1._base is not None else W1), (W2._base if W2._base is not None else W2)
+    ver = (b1._version + getattr(b1, "_s2d_version", 0), b2._version + getattr(b2, "_s2d_version", 0))
+    ent = _FFN_PACK.get(key)
+    if ent is None or ent[1] != ver or ent[2]() is not b1 or ent[3]() is not b2:
+        same = ent is not None and ent[2]() is b1 and ent[3]() is b2
+        img = ent[0] if same else torch.empty((lib().call("s2d_ffn_pack_words", C, F),), device=W1.device, dtype=torch.int32)
+        lib().call("s2d_ffn_pack_f16", W1, W2, C, F, img, _stream())
+        if not same and len(_FFN_PACK) >= 64:
+            for k in [k for k, e in _FFN_PACK.items() if e[2]() is None or e[3]() is None]:
+                del _FFN_PACK[k]
+        _FFN_PACK[key] = ent = (img, ver, weakref.ref(b1), weakref.ref(b2))
+    return ent[0]
+
+
+def ffn_fusable(W1, W2):
+    """the one-launch FFN exists for the split-fp16 arithmetic, model width 256 and hidden widths that are multiples of 32 (<= 2048)"""
+    return (_MODE == "f16x3" and not amp_active() and W1.dim() == 2 and W1.shape[1] == 256 and tuple(W2.shape) == (256, W1.shape[0])
+            and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0])) > 0)
+
+
+def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False):
+    """y = LN2?( xn + drop( W2 . drop( relu( W1 . xn + b1 ) ) + b2 ) ),  xn = LN1?(x)   in one launch (csrc/ffn.hip).
+    x [M, 256]; ln1 / ln2 = (gamma, beta) or None; dropout = (p, seed, site_hidden, site_out[, row0]) or None.
+    -> y, or (y, xn) with want_xn (requires ln1)."""
+    for t in (x, W1, b1, W2, b2) + tuple(ln1 or ()) + tuple(ln2 or ()):
+        _chk(t)
+    M, C = x.shape
+    F = W1.shape[0]
+    assert ffn_fusable(W1, W2) and C == 256 and (not want_xn or ln1 is not None)
+    y = torch.empty_like(x)
+    xn = torch.empty_like(x) if want_xn else None
+    p, seed, site_h, site_o, row0 = 0.0, 0, 0, 0, 0
+    if dropout is not None and dropout[0] > 0.0:
+        p, seed, site_h, site_o = dropout[:4]
+        row0 = dropout[4] if len(dropout) > 4 else 0
+    g1, be1 = ln1 if ln1 is not None else (None, None)
+    g2, be2 = ln2 if ln2 is not None else (None, None)
+    # counted as its two contractions; bytes: input, output, weights once
+    with _Timed(4.0 * M * F * C, ("ffn", 1, M, F, C, 4.0 * (2 * M * C + 2 * F * C))):
+        lib().call("s2d_ffn_fused_f32", x, M, C, F, _ffn_pack(W1, W2), b1, b2, g1, be1, g2, be2, float(eps), float(p),
+                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site_h), int(site_o), int(row0), xn, y, _stream())
+    return (y, xn) if want_xn else y
 
 
 def dropout_apply(x, p, seed, site, row0=0, out=None):

@@ -1,0 +1,54 @@
+"""Encoder FFN at the metric shape (309 120 rows x 256 -> 1024 -> 256): the one-launch form (csrc/ffn.hip) against the two GEMM
+launches + LayerNorm it replaces.  python scripts/mb_ffn.py [rows]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from s2d_amd import ops
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 309120
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn((M, 256), device=dev, generator=g)
+W1 = torch.nn.Parameter(torch.randn((1024, 256), device=dev, generator=g) * 0.06)
+W2 = torch.nn.Parameter(torch.randn((256, 1024), device=dev, generator=g) * 0.03)
+b1 = torch.randn((1024,), device=dev, generator=g) * 0.1
+b2 = torch.randn((256,), device=dev, generator=g) * 0.1
+g1, be1, g2, be2 = (torch.randn((256,), device=dev, generator=g) * 0.1 + (1 if i % 2 == 0 else 0) for i in range(4))
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def two_launch(p):
+    d2, d3 = ((p, 7, 1), (p, 7, 2)) if p > 0 else (None, None)
+    s1 = ops.layernorm(x, g1, be1)
+    h = ops.gemm_nt(s1, W1, bias=b1, relu=True, dropout=d2)
+    return ops.layernorm(ops.gemm_nt(h, W2, bias=b2, res=s1, dropout=d3), g2, be2)
+
+
+flops = 4.0 * M * 1024 * 256
+for p in (0.3, 0.0):
+    drop = (p, 7, 1, 2) if p > 0 else None
+    ref = two_launch(p)
+    out = ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop)
+    err = float((out - ref).abs().max() / ref.abs().max())
+    t2 = timeit(lambda: two_launch(p))
+    tf = timeit(lambda: ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop))
+    s1 = ops.layernorm(x, g1, be1)
+    tf2 = timeit(lambda: ops.ffn_fused(s1, W1, b1, W2, b2, ln2=(g2, be2), dropout=drop))
+    tf0 = timeit(lambda: ops.ffn_fused(s1, W1, b1, W2, b2, dropout=drop))
+    print(f"p={p}: two launches + 2 LN {t2:.3f} ms | fused LN1+FFN+LN2 {tf:.3f} ms ({flops / tf / 1e9:.0f} TFLOP/s alg.) | "
+          f"fused FFN+LN2 {tf2:.3f} | fused FFN {tf0:.3f} | max rel diff {err:.2e}", flush=True)

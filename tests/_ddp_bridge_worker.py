@@ -60,8 +60,10 @@ def main():
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert torch.equal(lo, hi), "ranks disagree on the reduced gradients"
-    # 2e-4: the point-loss scatter's float atomics reorder between the two evaluations of the same gradient
-    assert worst < 2e-4, worst
+    # every gradient kernel is bitwise reproducible (the point-loss scatter accumulates in int32 fixed point, the MSDeformAttn backward
+    # is the sorted atomic-free form), so the two evaluations hand DDP the same bits; what is left is DDP's own order of operations
+    # (divide by the world size, then sum) against sum-then-divide here: a rounding of the last bit, exact for world = 2
+    assert worst < 1e-6, worst
     n_nonzero = sum(int(g.abs().max() > 0) for g in g_ddp)
     dist.barrier()
     if rank == 0:

@@ -202,10 +202,54 @@ def test_msda_dev_shapes_rejected_on_device():
         gv, gl, gw, ws = ops.msda_backward_dev(value, shp, lsi, loc, w, go, want_ws=True)
         assert ops.msda_dev_status(ws) == 1
         assert torch.count_nonzero(gv) == 0 and torch.count_nonzero(gl) == 0 and torch.count_nonzero(gw) == 0
+    # overlapping levels: each level alone fits `value`, together they describe more pixels (and more bilinear cells than the
+    # backward's workspace and sort keys are sized for) than it has -> the rejected path, not an out-of-range sort
+    S2 = 6 * 8
+    value2 = torch.randn((N, S2, M, D), device=dev)
+    for shp, st in (([[6, 8], [6, 8]], [0, 0]), ([[6, 8], [4, 8]], [0, 16])):
+        shp, st = torch.tensor(shp, dtype=torch.long, device=dev), torch.tensor(st, dtype=torch.long, device=dev)
+        out, ws = ops.msda_forward_dev(value2, shp, st, loc, w, want_ws=True)
+        assert ops.msda_dev_status(ws) == 1 and torch.count_nonzero(out) == 0
+        gv, gl, gw, ws = ops.msda_backward_dev(value2, shp, st, loc, w, go, want_ws=True)
+        assert ops.msda_dev_status(ws) == 1
+        assert torch.count_nonzero(gv) == 0 and torch.count_nonzero(gl) == 0 and torch.count_nonzero(gw) == 0
     with pytest.raises(RuntimeError):
         ops.msda_forward_dev(value, good.cpu(), lsi, loc, w)                  # index tensors must be on the device
     with pytest.raises(RuntimeError):
         ops.msda_forward_dev(value, good.int(), lsi, loc, w)                  # and int64, as the extension reads them
+
+
+def test_msda_compat_module_fails_loudly_on_bad_shapes():
+    """the drop-in module must not train on zeros.  A call with shapes that do not describe `value` executes (zeros),
+    sets the pinned error word, and the module raises at the next call / at check() -- without a per-call sync"""
+    import s2d_amd.compat as compat
+    compat.install()
+    import MultiScaleDeformableAttention as MSDA
+    dev = torch.device(DEV)
+    N, M, D, P, Lq, L = 1, 8, 32, 4, 20, 2
+    S = 6 * 8 + 3 * 4
+    value = torch.randn((N, S, M, D), device=dev)
+    loc = torch.rand((N, Lq, M, L, P, 2), device=dev)
+    w = torch.softmax(torch.randn((N, Lq, M, L * P), device=dev), -1).view(N, Lq, M, L, P)
+    good = torch.tensor([[6, 8], [3, 4]], dtype=torch.long, device=dev)
+    bad = torch.tensor([[6, 8], [30, 40]], dtype=torch.long, device=dev)
+    lsi = torch.tensor([0, 48], dtype=torch.long, device=dev)
+    MSDA.check()                                                    # clean so far
+    out = MSDA.ms_deform_attn_forward(value, good, lsi, loc, w, 64)
+    MSDA.check()
+    assert out.abs().sum() > 0
+    MSDA.ms_deform_attn_forward(value, bad, lsi, loc, w, 64)        # enqueued; nothing can be known on the host yet
+    with pytest.raises(RuntimeError):
+        MSDA.check()
+    MSDA.check()                                                    # the flag was consumed by the raise
+    MSDA.ms_deform_attn_forward(value, bad, lsi, loc, w, 64)
+    torch.cuda.synchronize()                                        # (the trainer's own sync, e.g. _write_metrics)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(value, good, lsi, loc, w, 64)   # the next call raises on entry, before it launches anything
+    go = torch.randn((N, Lq, M * D), device=dev)
+    MSDA.ms_deform_attn_backward(value, bad, lsi, loc, w, go, 64)
+    with pytest.raises(RuntimeError):
+        MSDA.check()
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])

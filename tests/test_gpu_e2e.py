@@ -139,14 +139,50 @@ def test_amp_compute_mode_vs_oracle_with_fp16_operands(oracle):
     few 1e-2 of the logit scale (scripts/diag_amp_err.py prints the per-layer statistics: medians 1e-4 .. 5e-4, isolated layers
     with 1e-2 maxima, the layers after them back at 5e-4).  So the bounds are per layer: median 1e-3 of the scale -- the agreement
     of the arithmetic -- and maximum 5e-2 -- a flipped bit, not a wrong layer; losses 2e-2."""
+    import torch
+    from s2d_amd import ops
     from tests.parity import run_case
     hip, ref = run_case(oracle, seed=3, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), amp=True)
+    # "A flipped bit, not a wrong layer", checked instead of asserted in prose: the attention-mask bits the DEVICE formed from its own
+    # mask logits (the kernel the decoder ran, s2d_attn_mask_bits) against the bits the oracle formed from its logits, per head.
+    # flipped[L][b, q]: query q of clip b meets a different mask in decoder layer L.  A clip is "clean up to head L" when no query of
+    # it met a different mask in any layer < L (a flipped row reaches the clip's other queries through self-attention, so the unit
+    # of the argument is the clip): every logit of a clean clip must agree to 1e-3 -- the agreement of the arithmetic -- and every
+    # element outside 1e-3 must sit in a clip that a flip reached.
+    st = hip["model"].last["student"]
+    Q, T, hm, wm = st.dims
+    NLh, B = st.mask_logits.shape[:2]
+    Hp, Wp = hm * 4, wm * 4
+    sizes = [(Hp // 32, Wp // 32), (Hp // 16, Wp // 16), (Hp // 8, Wp // 8)]
+    flipped = []
+    for L in range(NLh - 1):
+        hl, wl = sizes[L % 3]
+        bits, _ = ops.attn_mask_bits(st.mask_logits[L].contiguous(), B, Q, T, hm, wm, hl, wl)
+        bits = bits.cpu().numpy().astype(np.uint32)                                               # [B, K, 4]
+        dev_bits = np.stack([(bits[:, :, q // 32] >> np.uint32(q % 32)) & np.uint32(1) for q in range(Q)], 1).astype(bool)   # [B, Q, K]
+        ref_bits = (oracle.resize_bilinear(ref["s_masks"][L], hl, wl) < 0).reshape(B, Q, T * hl * wl)
+        flipped.append((dev_bits != ref_bits).any(-1))
+    reached = np.zeros((NLh, B), bool)                           # reached[L, b]: some layer < L of clip b ran with a different mask
+    for L in range(1, NLh):
+        reached[L] = reached[L - 1] | flipped[L - 1].any(-1)
+    n_out = n_out_in_flipped_rows = 0
     for k in ("s_logits", "s_masks"):
         a, b = hip[k].astype(np.float64), ref[k].astype(np.float64)
         sc = np.abs(b).max()
         for layer in range(a.shape[0]):
             d = np.abs(a[layer] - b[layer]) / sc
             assert np.median(d) < 1e-3 and d.max() < 5e-2, (k, layer, float(np.median(d)), float(d.max()))
+            for clip in range(B):
+                if not reached[layer, clip]:
+                    assert d[clip].max() < 1e-3, (k, layer, clip, float(d[clip].max()), "no attention-mask bit differs up to here")
+                else:
+                    rows = np.zeros(Q, bool)
+                    for L in range(layer):
+                        rows |= flipped[L][clip]
+                    big = d[clip].reshape(Q, -1) > 1e-3 if k == "s_masks" else d[clip] > 1e-3
+                    n_out += int(big.sum()); n_out_in_flipped_rows += int(big[rows].sum())
+    print(f"AMP: heads with a flipped attention-mask row per clip: {[int(f.any(-1).sum()) for f in flipped]}; elements outside 1e-3: {n_out}, "
+          f"of which in a query row whose own mask flipped: {n_out_in_flipped_rows}")
     assert hip["kd_counts"] == ref["kd_counts"]
     for k, v in ref["losses"].items():
         np.testing.assert_allclose(hip["losses"][k], float(v), rtol=2e-2, atol=1e-6, err_msg=k)

@@ -1,0 +1,95 @@
+"""The encoder layer's feed-forward block in one launch (csrc/ffn.hip) against the CPU oracle and against the two-launch form.
+Reference: mask2former/modeling/pixel_decoder/msdeformattn.py:116-131 (forward_ffn, norm1 / norm2 around it)."""
+import numpy as np
+import pytest
+import torch
+
+from s2d_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _params(F, seed):
+    W1 = synth.randn(seed, 1, (F, 256)) * 0.06
+    b1 = synth.randn(seed, 2, (F,)) * 0.1
+    W2 = synth.randn(seed, 3, (256, F)) * 0.03
+    b2 = synth.randn(seed, 4, (256,)) * 0.1
+    g1, be1 = synth.randn(seed, 5, (256,)) * 0.2 + 1, synth.randn(seed, 6, (256,)) * 0.1
+    g2, be2 = synth.randn(seed, 7, (256,)) * 0.2 + 1, synth.randn(seed, 8, (256,)) * 0.1
+    return W1, b1, W2, b2, g1, be1, g2, be2
+
+
+def _oracle_ffn(oracle, x, W1, b1, W2, b2, ln1, ln2, drop):
+    x = x.astype(np.float64)
+    xn = oracle.layer_norm(x, ln1[0].astype(np.float64), ln1[1].astype(np.float64)) if ln1 else x
+    hid = np.maximum(xn @ W1.astype(np.float64).T + b1, 0)
+    out = None
+    if drop:
+        p, seed, sh, so = drop
+        hid = hid * oracle.dropout_multipliers(x.shape[0], W1.shape[0], p, seed, sh)
+    out = hid @ W2.astype(np.float64).T + b2
+    if drop:
+        out = out * oracle.dropout_multipliers(x.shape[0], 256, p, seed, so)
+    y = xn + out
+    if ln2:
+        y = oracle.layer_norm(y, ln2[0].astype(np.float64), ln2[1].astype(np.float64))
+    return y, xn
+
+
+@pytest.mark.parametrize("M,F", [(128, 1024), (200, 1024), (1, 64), (129, 32), (1000, 2048), (5000, 1024)])
+@pytest.mark.parametrize("ln", ["none", "ln2", "ln1ln2"])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_ffn_fused_vs_oracle(oracle, M, F, ln, p):
+    """float64 oracle; tolerance 2e-5 of the output scale (split-fp16 x3 through two contractions + LayerNorm), masks exact"""
+    from s2d_amd import ops
+    W1, b1, W2, b2, g1, be1, g2, be2 = _params(F, 11)
+    x = synth.randn(12, 1, (M, 256)) * 1.5
+    ln1 = (g1, be1) if ln == "ln1ln2" else None
+    ln2 = (g2, be2) if ln != "none" else None
+    drop = (p, 0x1234567887654321, 1, 2) if p > 0 else None
+    ref, refn = _oracle_ffn(oracle, x, W1, b1, W2, b2, ln1, ln2, drop)
+    W1d, W2d = torch.nn.Parameter(_dev(W1)), torch.nn.Parameter(_dev(W2))
+    out = ops.ffn_fused(_dev(x), W1d, _dev(b1), W2d, _dev(b2), ln1=tuple(map(_dev, ln1)) if ln1 else None,
+                        ln2=tuple(map(_dev, ln2)) if ln2 else None, dropout=drop, want_xn=ln1 is not None)
+    if ln1 is not None:
+        out, xn = out
+        np.testing.assert_allclose(xn.cpu().numpy(), refn, rtol=0, atol=3e-6 * np.abs(refn).max())
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M", [309, 4096])
+def test_ffn_fused_vs_two_launch_form(M):
+    """same masks, same arithmetic class: the fused launch against gemm_nt(dropout) x 2 + layernorm (the taped training path)"""
+    from s2d_amd import ops
+    W1, b1, W2, b2, g1, be1, g2, be2 = (_dev(a) for a in _params(1024, 21))
+    W1, W2 = torch.nn.Parameter(W1), torch.nn.Parameter(W2)
+    x = _dev(synth.randn(22, 1, (M, 256)))
+    p, seed = 0.3, 987654321
+    s1 = ops.layernorm(x, g1, be1)
+    h = ops.gemm_nt(s1, W1, bias=b1, relu=True, dropout=(p, seed, 1))
+    ref = ops.layernorm(ops.gemm_nt(h, W2, bias=b2, res=s1, dropout=(p, seed, 2)), g2, be2)
+    out, xn = ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, seed, 1, 2), want_xn=True)
+    assert torch.allclose(xn, s1, rtol=0, atol=2e-6 * float(s1.abs().max()))
+    assert torch.allclose(out, ref, rtol=0, atol=1e-5 * float(ref.abs().max()))
+    # a changed weight is re-packed (parameter version)
+    with torch.no_grad():
+        W1.mul_(2.0)
+    out2 = ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, seed, 1, 2))
+    h2 = ops.gemm_nt(s1, W1, bias=b1, relu=True, dropout=(p, seed, 1))
+    ref2 = ops.layernorm(ops.gemm_nt(h2, W2, bias=b2, res=s1, dropout=(p, seed, 2)), g2, be2)
+    assert torch.allclose(out2, ref2, rtol=0, atol=1e-5 * float(ref2.abs().max()))
+    # run to run: same bits
+    assert torch.equal(out2, ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, seed, 1, 2)))
+
+
+def test_ffn_fused_rejects_unsupported_sizes():
+    from s2d_amd._lib import lib
+    assert lib().call("s2d_ffn_pack_words", 128, 1024) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1000) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 4096) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024) == 32 * 16384
