@@ -596,7 +596,7 @@ def main():
                              "timed_steps_compared_bitwise": None if same is None else ncmp,
                              "fell_back_to_one_stream": fallback}}
         prof_all = prof or []
-        prof = [r for r in prof_all if r[3][0] in ("gemm", "conv")]         # the dense family; the other tagged launches feed per_kernel
+        prof = [r for r in prof_all if r[3][0] in ("gemm", "conv", "ffn")]  # the dense family (ffn: the one-launch encoder FFN, counted as its two contractions); the other tagged launches feed per_kernel
         if prof:
             ms = sum(s.elapsed_time(e) for s, e, *_ in prof)
             fl = sum(f for _, _, f, *_ in prof)

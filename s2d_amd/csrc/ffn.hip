@@ -19,15 +19,21 @@
 // 16 CONSECUTIVE units / columns (two whole 8-column Philox blocks, 64 contiguous bytes): MFMA row 8g + 4h + i <-> 16h + 4g + i.
 //
 // Weights: s2d_ffn_pack_f16 writes both matrices once as an image of MFMA A-fragments in the order the kernel consumes them
-// (per chunk: 16 k-steps x (hi, lo) of W1 | 8 tiles x 2 k-steps x (hi, lo) of W2; 1 KB = 64 lanes x 16 B per fragment), so a chunk
-// goes global -> LDS by `buffer_load_dwordx4 ... lds` as 64 linear 1-KB pieces and every fragment read is one conflict-free
-// ds_read_b128.  LDS: two 32-KB W1 buffers + two 32-KB W2 buffers + b1 (4 KB).
+// (per chunk: 16 k-steps x (hi, lo) of W1 | k-step 0: 8 tiles x (hi, lo) of W2 | k-step 1: the same; 1 KB = 64 lanes x 16 B per
+// fragment), so a chunk goes global -> LDS by `buffer_load_dwordx4 ... lds` as 64 linear 1-KB pieces and every fragment read is one
+// conflict-free ds_read_b128.  LDS: two 32-KB W1 buffers + two 16-KB buffers for each k-step of W2 + b1 (4 KB).
 //
-// Schedule of phase p (one barrier per phase): DMA of W1(p+1) and W2(p) is issued; GEMM 1 of chunk p (48 MFMAs, the Philox rounds of
-// the chunk's mask in their shadow); GEMM 2 of chunk p-1 (48 MFMAs, with the ReLU / mask / split of chunk p in their shadow).
+// Schedule of chunk p (one barrier per chunk, weights double-buffered): DMA of the next pieces; GEMM 1 of chunk p (48 MFMAs, the Philox
+// rounds of its mask in their shadow); GEMM 2 k-step 1 of chunk p-1 (24 MFMAs, ReLU / mask / split of chunk p's k-step 0 in their
+// shadow); GEMM 2 k-step 0 of chunk p (24 MFMAs, the same for its k-step 1).
 #include "common.h"
 #include "dropout.h"
+#include <stdlib.h>
 #include <type_traits>
+
+#ifndef S2D_FFN_DBG
+#define S2D_FFN_DBG 0
+#endif
 
 namespace {
 
@@ -40,7 +46,7 @@ constexpr int FC = 256;                     // model width (the register layout 
 constexpr int FRAG = 1024;                  // bytes of one MFMA operand fragment (64 lanes x 16 B)
 constexpr int PART = 32 * FRAG;             // 32 KB: 16 k-steps x (hi, lo)  |  8 tiles x 2 k-steps x (hi, lo)
 constexpr int CHUNKB = 2 * PART;            // image bytes per chunk of 32 hidden units
-constexpr int LDS_B1 = 4 * PART;            // byte offset of the bias copy
+constexpr int LDS_B1 = 2 * CHUNKB;          // byte offset of the bias copy (behind the two chunk buffers)
 constexpr int FMAX = 2048;                  // hidden width limit of the bias copy
 
 // MFMA row rho of a 32-row tile <-> unit / column 16 h + 4 g + i   (rho = 8 g + 4 h + i): a lane half's 16 accumulator registers
@@ -54,6 +60,33 @@ __device__ __forceinline__ unsigned int pk_lo(float a, float b, unsigned int hi)
     return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz((a - f[0]) * 2048.f, (b - f[1]) * 2048.f));
 }
 
+// Register classes.  The 256 output accumulators must live in the accumulator half of the register file and everything else in the
+// vector half (X fragments 128, chunk accumulators 32, activation / weight fragments 48, Philox state ...).  With every MFMA a builtin
+// the allocator gives the chunk accumulators AGPRs and shuttles an output tile between the halves around every chunk (~100
+// v_accvgpr moves per 96 MFMAs) or spills the X fragments.  What works: GEMM 1 (the chunk accumulators) as asm statements with a "+v"
+// accumulator -- that pins am / ax to VGPRs -- and GEMM 2 on the builtin, whose accumulators then take exactly the 256 AGPRs.
+// GEMM 2 must NOT be asm: an asm form with "+a" accumulators gave wrong low-order bits (~1e-4 of the output) in some output tiles for
+// one of two orders of the same three products, deterministic per build, tiles changing with unrelated code motion; with the builtin
+// (hipcc sees an MFMA and keeps its hazards) both orders are exact.  The cause inside the asm form was not isolated; the rules the asm
+// form of GEMM 1 is written to, beyond what the compiler does for any asm operand (s_waitcnt for the LDS reads that feed it):
+//   * an MFMA reading the accumulator the preceding MFMA wrote needs no wait states (same-size back-to-back accumulation);
+//   * WAR on A / B: every MFMA lists the previous MFMA's operands as unused inputs, so their registers stay allocated until the next
+//     MFMA has issued (the allocator otherwise hands a dead fragment's registers to the very next VALU instruction);
+//   * the VALU readers of am / ax (the activation quarters) sit >= 4 MFMAs behind GEMM 1's last MFMA.
+// tests/test_gpu_ffn.py checks every variant against a float64 oracle at 2e-5 of the output scale (a lost low-order product is 1e-4).
+struct MfmaPrev { f16x8 a, b; };
+__device__ __forceinline__ void mfma_a(f32x16 &c, const f16x8 a, const f16x8 b) { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void mfma_v(f32x16 &c, const f16x8 a, const f16x8 b, MfmaPrev &pv)
+{
+    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "v"(pv.a), "v"(pv.b));
+    pv.a = a; pv.b = b;
+}
+__device__ __forceinline__ void mfma_v0(f32x16 &c, const f16x8 a, const f16x8 b, MfmaPrev &pv)       // the accumulator's first product: C = 0
+{
+    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b), "v"(pv.a), "v"(pv.b));
+    pv.a = a; pv.b = b;
+}
+
 // one thread = one lane's 16 bytes of one fragment
 __global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int F, u32x4 *__restrict__ out)
 {
@@ -65,8 +98,8 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__
     const float *src;
     if (frag < 32) src = W1 + (32 * c + perm_row(r)) * FC + 16 * (frag >> 1) + 8 * h;                      // k-step frag >> 1 of GEMM 1
     else {
-        const int f2 = frag - 32, s = (f2 >> 1) & 1, t = f2 >> 2;
-        src = W2 + (long)(32 * t + perm_row(r)) * F + 32 * c + 16 * h + 8 * s;                               // tile t, k-step s of GEMM 2
+        const int f2 = frag - 32, s = f2 >> 4, t = (f2 >> 1) & 7;
+        src = W2 + (long)(32 * t + perm_row(r)) * F + 32 * c + 16 * h + 8 * s;                               // k-step s, tile t of GEMM 2
     }
     u32x4 w;
 #pragma unroll
@@ -104,18 +137,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned int mrow = p.row0 + (unsigned int)row;                    // mask row
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB, 0x00020000);
-    // a wave copies pieces wave*8 .. wave*8+7 of a 32-piece part
-    auto dma_part = [&](int src_byte, int dst_byte) {
+    // a wave copies pieces wave * n .. wave * n + n - 1 of a part of 4 n pieces (n = 8: 32 KB; n = 4: one k-step of W2, 16 KB)
+    auto dma_part = [&](int src_byte, int dst_byte, auto n_) {
+        constexpr int n = decltype(n_)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int piece = wave * 8 + i;
+        for (int i = 0; i < n; ++i) {
+            const int piece = wave * n + i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte + piece * FRAG), 16,
                                                      lane * 16, src_byte + piece * FRAG, 0, 0);
         }
     };
     // phase 0's weights first (they are the longest wait of the prologue), then the bias copy and the input tile
-    dma_part(0, 0);
+    dma_part(0, 0, std::integral_constant<int, 8>{});                       // W1 of chunk 0
+    dma_part(PART, 2 * PART, std::integral_constant<int, 4>{});              // W2 k-step 0 of chunk 0
+    dma_part((p.nchunks > 1 ? 1 : 0) * CHUNKB, PART, std::integral_constant<int, 8>{});    // W1 of chunk 1
     for (int i = tid; i < p.nchunks * 32; i += 256) reinterpret_cast<float *>(lds + LDS_B1)[i] = p.b1[i];
+    for (int i = tid; i < PART / 2 / 16; i += 256)            // W2 k-step 1 buffer 1: what chunk 0's (empty) pass A multiplies by zero
+        reinterpret_cast<u32x4 *>(lds + 3 * PART + PART / 2)[i] = u32x4{0u, 0u, 0u, 0u};
 
     // ---- input tile -> fp16 hi / lo B fragments of GEMM 1: fragment ks holds X[row][16 ks + 8 h + j], j = 0..7 ----
     f16x8 xh[16], xl[16];
@@ -175,110 +213,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     f32x16 am, ax;                      // GEMM 1 accumulators of the current chunk
-    f16x8 hh[2], hlo[2];                // fp16 hi / lo B fragments (k-steps 0, 1) of the previous chunk's activation
-    uint32_t rb[2][4];                  // Philox state / result of the current chunk's two 8-unit mask blocks
+    u32x4 hw[2], lw[2];                 // fp16 hi / lo B fragments (k-steps 0, 1) of the chunk's activation, as packed words
+    uint32_t rb[2][4], rt[2];           // Philox state / result of the chunk's two 8-unit mask blocks; rt: the c0 a half-done round holds back
+    f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
+                                        // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
+    float hv0 = 0.f, hv1 = 0.f;         // the activation word being formed
+    MfmaPrev pv;                        // the previous asm MFMA's operands (see mfma_v)
+    pv.a = xh[0]; pv.b = xh[0];
+    unsigned int hhi = 0u;
     const unsigned char *lane_lds = lds + lane * 16;
+    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any bit set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads
 
-    // One Philox round of both blocks (10 per chunk) -- placed in the shadow of GEMM 1's MFMAs
-    auto philox_round = [&](int r) {
-        const uint32_t k0 = p.k0 + 0x9E3779B9u * (uint32_t)r, k1 = p.k1 + 0xBB67AE85u * (uint32_t)r;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t hi0 = __umulhi(0xD2511F53u, rb[e][0]), lo0 = 0xD2511F53u * rb[e][0];
-            const uint32_t hi1 = __umulhi(0xCD9E8D57u, rb[e][2]), lo1 = 0xCD9E8D57u * rb[e][2];
-            rb[e][0] = hi1 ^ rb[e][1] ^ k0; rb[e][1] = lo1; rb[e][2] = hi0 ^ rb[e][3] ^ k1; rb[e][3] = lo0;
+    // ---- filler work, cut into units of at most ~6 vector instructions: one unit per MFMA gap (a lone wave hides ~5 beside an MFMA) ----
+    // Philox4x32-10 of mask block e, round r, in two halves (idx = 4 r + 2 e + half):
+    //   half 0: M1 * c2 -> rt = hi ^ c1 ^ k0, c1 = lo;   half 1: M0 * c0 -> c2 = hi ^ c3 ^ k1, c3 = lo, c0 = rt
+    auto philox_half = [&](int idx) {
+        const int r = idx >> 2, e = (idx >> 1) & 1;
+        if (!(idx & 1)) {
+            const uint64_t pr = (uint64_t)0xCD9E8D57u * rb[e][2];
+            rt[e] = (uint32_t)(pr >> 32) ^ rb[e][1] ^ (p.k0 + 0x9E3779B9u * (uint32_t)r);
+            rb[e][1] = (uint32_t)pr;
+        } else {
+            const uint64_t pr = (uint64_t)0xD2511F53u * rb[e][0];
+            rb[e][2] = (uint32_t)(pr >> 32) ^ rb[e][3] ^ (p.k1 + 0xBB67AE85u * (uint32_t)r);
+            rb[e][3] = (uint32_t)pr;
+            rb[e][0] = rt[e];
         }
     };
-
-    auto phase = [&](auto do1_, auto do2_, int pc) {
-        constexpr bool DO1 = decltype(do1_)::value, DO2 = decltype(do2_)::value;
-        const unsigned char *w1 = lane_lds + (pc & 1) * PART;                   // chunk pc, GEMM 1 fragments
-        const unsigned char *w2 = lane_lds + 2 * PART + ((pc + 1) & 1) * PART;  // chunk pc - 1, GEMM 2 fragments
-        __syncthreads();            // every wave is past the previous phase's fragment reads, and its DMA pieces have landed (vmcnt(0) below)
-        if (DO1 && pc + 1 < p.nchunks) dma_part((pc + 1) * CHUNKB, ((pc + 1) & 1) * PART);
-        if (DO1) dma_part(pc * CHUNKB + PART, 2 * PART + (pc & 1) * PART);
-        if constexpr (DO1) {
-            // ---- GEMM 1 of chunk pc: am / ax [unit 16 h + reg][row] ----
-            {
-                const float *bp = reinterpret_cast<const float *>(lds + LDS_B1) + 32 * pc + 16 * h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(bp + 4 * q);
-                    am[4 * q] = b[0]; am[4 * q + 1] = b[1]; am[4 * q + 2] = b[2]; am[4 * q + 3] = b[3];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-            }
-            if (DROP) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) { rb[e][0] = mrow; rb[e][1] = (uint32_t)(4 * pc + 2 * h + e); rb[e][2] = p.site_h; rb[e][3] = 0u; }
-            }
-            f16x8 fa[3][2];
-            fa[0][0] = *reinterpret_cast<const f16x8 *>(w1); fa[0][1] = *reinterpret_cast<const f16x8 *>(w1 + FRAG);
-            fa[1][0] = *reinterpret_cast<const f16x8 *>(w1 + 2 * FRAG); fa[1][1] = *reinterpret_cast<const f16x8 *>(w1 + 3 * FRAG);
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int sl = ks % 3, sn = (ks + 2) % 3;
-                ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][1], xh[ks], ax, 0, 0, 0);
-                if (ks + 2 < 16) {
-                    fa[sn][0] = *reinterpret_cast<const f16x8 *>(w1 + (2 * ks + 4) * FRAG);
-                    fa[sn][1] = *reinterpret_cast<const f16x8 *>(w1 + (2 * ks + 5) * FRAG);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][0], xl[ks], ax, 0, 0, 0);
-                if (DROP && ks < 10) philox_round(ks);
-                __builtin_amdgcn_sched_barrier(0);
-                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][0], xh[ks], am, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        f16x8 nh[2], nl[2];             // the current chunk's activation fragments, built during GEMM 2 of the previous chunk
-        auto hproc = [&](int s, int q) {    // word q of k-step s: units 16 h + 8 s + 2 q, + 1
-            float v0 = am[8 * s + 2 * q] + ax[8 * s + 2 * q] * (1.0f / 2048.0f), v1 = am[8 * s + 2 * q + 1] + ax[8 * s + 2 * q + 1] * (1.0f / 2048.0f);
-            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f);
+    // activation word q = idx >> 2 of k-step s (units 16 h + 8 s + 2 q, + 1) in four quarters: combine + ReLU, mask, fp16 hi, scaled fp16 lo
+    auto hquarter = [&](int s, int idx) {
+        const int q = idx >> 2, part = idx & 3, r0 = 8 * s + 2 * q;
+        if (part == 0) {
+            hv0 = fmaxf(am[r0] + ax[r0] * (1.0f / 2048.0f), 0.f);
+            hv1 = fmaxf(am[r0 + 1] + ax[r0 + 1] * (1.0f / 2048.0f), 0.f);
+        } else if (part == 1) {
             if (DROP) {
                 const uint32_t w = rb[s][q];
-                v0 = (w & 0xFFFFu) >= p.thresh ? v0 * p.dscale : 0.f;
-                v1 = (w >> 16) >= p.thresh ? v1 * p.dscale : 0.f;
+                hv0 *= (w & 0xFFFFu) >= p.thresh ? p.dscale : 0.f;      // a multiplier (select of two constants), not a select of the products:
+                hv1 *= (w >> 16) >= p.thresh ? p.dscale : 0.f;          // the latter compiles to exec-masked blocks that cut the schedule
             }
-            const unsigned int hi = pk_hi(v0, v1), lo = pk_lo(v0, v1, hi);
-            u32x4 th = __builtin_bit_cast(u32x4, nh[s]), tl = __builtin_bit_cast(u32x4, nl[s]);
-            th[q] = hi; tl[q] = lo;
-            nh[s] = __builtin_bit_cast(f16x8, th); nl[s] = __builtin_bit_cast(f16x8, tl);
-        };
-        if constexpr (DO2) {
-            // ---- GEMM 2 of chunk pc - 1: ym / yx [column 32 t + 16 h + reg][row] += W2c . H^T ----
-            f16x8 fb[3][2];
-            fb[0][0] = *reinterpret_cast<const f16x8 *>(w2); fb[0][1] = *reinterpret_cast<const f16x8 *>(w2 + FRAG);
-            fb[1][0] = *reinterpret_cast<const f16x8 *>(w2 + 2 * FRAG); fb[1][1] = *reinterpret_cast<const f16x8 *>(w2 + 3 * FRAG);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int t = i >> 1, s = i & 1, sl = i % 3, sn = (i + 2) % 3;
-                yx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[sl][1], hh[s], yx[t], 0, 0, 0);
-                if (i + 2 < 16) {
-                    fb[sn][0] = *reinterpret_cast<const f16x8 *>(w2 + (2 * i + 4) * FRAG);
-                    fb[sn][1] = *reinterpret_cast<const f16x8 *>(w2 + (2 * i + 5) * FRAG);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                yx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[sl][0], hlo[s], yx[t], 0, 0, 0);
-                if (DO1 && i < 8) hproc(i >> 2, i & 3);
-                __builtin_amdgcn_sched_barrier(0);
-                ym[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[sl][0], hh[s], ym[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if constexpr (DO1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) hproc(i >> 2, i & 3);
+        } else if (part == 2) {
+            hhi = pk_hi(hv0, hv1);
+            hw[s][q] = hhi;
+        } else {
+            lw[s][q] = pk_lo(hv0, hv1, hhi);
         }
-        if constexpr (DO1) { hh[0] = nh[0]; hh[1] = nh[1]; hlo[0] = nl[0]; hlo[1] = nl[1]; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA pieces of the next phase have landed
+    };
+    auto dma_piece = [&](int src_byte, int dst_byte) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
+    };
+    // the 16 pieces a wave copies per chunk, all behind the chunk's barrier (which frees their destinations):
+    //   k 0..7  W1 of chunk pc + 2 -> W1 buffer pc & 1 (GEMM 1 of chunk pc has read it);  k 8..11  W2 k-step 0 of chunk pc + 1 -> S0 buffer
+    //   (pc + 1) & 1;  k 12..15  W2 k-step 1 of chunk pc -> S1 buffer pc & 1 (read by the next chunk's pass A).  Past the last chunk the
+    //   source is clamped (a copy nobody reads) so that the instruction stream has no branches.
+    auto dma_k = [&](int k, int pc) {
+        const int cur = pc & 1, last = p.nchunks - 1;
+        if (dbg & 1) return;
+        if (k < 8) dma_piece(min(pc + 2, last) * CHUNKB + (wave * 8 + k) * FRAG, cur * PART + (wave * 8 + k) * FRAG);
+        else if (k < 12) dma_piece(min(pc + 1, last) * CHUNKB + PART + (wave * 4 + k - 8) * FRAG, 2 * PART + (cur ^ 1) * (PART / 2) + (wave * 4 + k - 8) * FRAG);
+        else dma_piece(pc * CHUNKB + PART + PART / 2 + (wave * 4 + k - 12) * FRAG, 3 * PART + cur * (PART / 2) + (wave * 4 + k - 12) * FRAG);
+    };
+    auto frag_read = [&](int slot, const unsigned char *at) {
+        if (dbg & 8) return;
+        fr[slot][0] = *reinterpret_cast<const f16x8 *>(at);
+        fr[slot][1] = *reinterpret_cast<const f16x8 *>(at + FRAG);
+    };
+    auto bias_read = [&](int pc) {      // am := b1 of chunk pc's units 16 h + 0..15 (the accumulator's initial value)
+        const float *bp = reinterpret_cast<const float *>(lds + LDS_B1) + 32 * pc + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bp + 4 * q);
+            am[4 * q] = b[0]; am[4 * q + 1] = b[1]; am[4 * q + 2] = b[2]; am[4 * q + 3] = b[3];
+        }
+    };
+    // post-barrier gap j (0..53: GEMM 1's last two k-steps, pass A, pass B): DMA piece k at j = 3 k + 1
+    auto post_gap = [&](int j, int pc) {
+        if (j % 3 == 1 && j / 3 < 16) dma_k(j / 3, pc);
+    };
+    // GEMM 2, k-step S of a chunk over the 8 output tiles (fragment (tile t, hi / lo) at wf + (t * 2 + hi/lo) * FRAG; tile 0's pair is
+    // already in ring slot 0), with the activation quarters of the OTHER k-step of the current chunk as filler: pass A (S = 1, previous
+    // chunk) forms hw[0] / lw[0], pass B (S = 0, current chunk) reads them and forms hw[1] / lw[1], which the next chunk's pass A
+    // reads.  `next`: where ring slot 0 is refilled from behind tile 7 (the next MFMA group's first fragment pair).
+    auto gemm2_pass = [&](auto s_, const unsigned char *wf, const unsigned char *next, int j0, int pc, int first_q, int bias_pc) {
+        constexpr int S = decltype(s_)::value;
+        const f16x8 bh = __builtin_bit_cast(f16x8, hw[S]), bl = __builtin_bit_cast(f16x8, lw[S]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int sl = t & 3, sn = (t + 2) & 3;                                 // both passes start at a group index that is a multiple of 4
+            frag_read(sn, t + 2 < 8 ? wf + (2 * t + 4) * FRAG : next + (2 * (t + 2 - 8)) * FRAG);
+            mfma_a(ym[t], fr[sl][0], bh);
+            post_gap(j0 + 3 * t, pc);
+            if (3 * t >= first_q && 3 * t < first_q + 16 && !(dbg & 4)) hquarter(S ^ 1, 3 * t - first_q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_a(yx[t], fr[sl][0], bl);
+            post_gap(j0 + 3 * t + 1, pc);
+            if (3 * t + 1 >= first_q && 3 * t + 1 < first_q + 16 && !(dbg & 4)) hquarter(S ^ 1, 3 * t + 1 - first_q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_a(yx[t], fr[sl][1], bh);
+            post_gap(j0 + 3 * t + 2, pc);
+            if (3 * t + 2 >= first_q && 3 * t + 2 < first_q + 16 && !(dbg & 4)) hquarter(S ^ 1, 3 * t + 2 - first_q);
+            if (S == 0 && t == 6) bias_read(bias_pc);          // am is dead behind the last activation quarter (gap 17): the next chunk's initial value
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    phase(std::true_type{}, std::false_type{}, 0);
-    for (int pc = 1; pc < p.nchunks; ++pc) phase(std::true_type{}, std::true_type{}, pc);
-    phase(std::false_type{}, std::true_type{}, p.nchunks);
+    // Chunk pc:  GEMM 1 k-steps 0..13 (42 MFMAs; the 40 Philox half-rounds of its mask in their gaps)  ->  vmcnt(0), BARRIER (the pieces
+    // issued a chunk ago are visible, the buffers of chunk pc - 1 and W1 of chunk pc are free)  ->  GEMM 1 k-steps 14, 15 (their fragments were
+    // read before the barrier: 6 MFMAs that cover the latency of pass A's first fragment reads)  ->  pass A: GEMM 2 k-step 1 of chunk pc - 1 (24
+    // MFMAs; chunk pc's first activation fragment formed in their gaps)  ->  pass B: GEMM 2 k-step 0 of chunk pc (24 MFMAs; its second
+    // activation fragment).  The 16 DMA pieces of the chunk go out one per three MFMAs behind the barrier.  Deferring a chunk's second
+    // k-step by one chunk is what hides the activation work: every MFMA of GEMM 2 needs the activation.
+    // Live beside the 256 output accumulators: X fragments 128, am / ax 32, activation fragments 16, weight fragments 32.
+    hw[1] = u32x4{0u, 0u, 0u, 0u}; lw[1] = hw[1];                // chunk 0's pass A: zero activation against the zeroed S1 buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the prologue's DMA pieces (and the input tile's loads)
+    __syncthreads();
+    frag_read(0, lane_lds);
+    frag_read(1, lane_lds + 2 * FRAG);
+    bias_read(0);
+    for (int pc = 0; pc < p.nchunks; ++pc) {
+        const int cur = pc & 1;
+        const unsigned char *w1 = lane_lds + cur * PART;                          // W1 of chunk pc
+        const unsigned char *w2a = lane_lds + 3 * PART + (cur ^ 1) * (PART / 2);   // W2 k-step 1 of chunk pc - 1
+        const unsigned char *w2b = lane_lds + 2 * PART + cur * (PART / 2);         // W2 k-step 0 of chunk pc
+        if (DROP) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { rb[e][0] = mrow; rb[e][1] = (uint32_t)(4 * pc + 2 * h + e); rb[e][2] = p.site_h; rb[e][3] = 0u; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int sl = ks & 3, sn = (ks + 2) & 3;
+            if (ks == 14) {
+                // pass A's fragments (requested from here on) sit in a buffer this wave's pieces of a chunk ago went to: they must have
+                // landed, in every wave.  GEMM 1's last two k-steps already have their fragments: 6 MFMAs to cover the first read's latency.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            frag_read(sn, ks < 14 ? w1 + (2 * ks + 4) * FRAG : w2a + (2 * (ks - 14)) * FRAG);
+            mfma_v(am, fr[sl][0], xh[ks], pv);
+            if (ks >= 14) post_gap(3 * (ks - 14), pc);
+            if (DROP && 3 * ks < 40) philox_half(3 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) mfma_v0(ax, fr[sl][0], xl[ks], pv); else mfma_v(ax, fr[sl][0], xl[ks], pv);
+            if (ks >= 14) post_gap(3 * (ks - 14) + 1, pc);
+            if (DROP && 3 * ks + 1 < 40) philox_half(3 * ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_v(ax, fr[sl][1], xh[ks], pv);
+            if (ks >= 14) post_gap(3 * (ks - 14) + 2, pc);
+            if (DROP && 3 * ks + 2 < 40) philox_half(3 * ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ring slots 0, 1 hold pass A's first two fragment pairs (requested behind the barrier)
+        gemm2_pass(std::integral_constant<int, 1>{}, w2a, w2b, 6, pc, 6, -1);
+        gemm2_pass(std::integral_constant<int, 0>{}, w2b, lane_lds + (cur ^ 1) * PART, 30, pc, 2, pc + 1 < p.nchunks ? pc + 1 : pc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                            // the last chunk's W2 k-step 1 pieces, copied by all four waves
+    frag_read(0, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2));
+    frag_read(1, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2) + 2 * FRAG);
+    gemm2_pass(std::integral_constant<int, 1>{}, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2), lane_lds, 1000, 0, 1000, -1);   // no fillers
 
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are read by the VALU below (see mfma_a)
     // ---- epilogue: y = [LN2]( x + dropout3(acc) ),  this lane: columns 32 t + 16 h + 0..15 of its row ----
     // (tile by tile, pinned: the 32 residual loads of a lane must not all be in flight beside the 256 accumulators)
     const float *xr = p.X + rowc * FC + 16 * h;

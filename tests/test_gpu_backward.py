@@ -502,7 +502,9 @@ def test_point_loss_backward_walks_map_parts():
         gb = ops.point_loss_backward(cb, wm_, wd_)
         np.testing.assert_allclose(La.cpu().numpy(), Lb.cpu().numpy(), rtol=2e-6)
         assert float(ga.abs().max()) > 0
-        assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
+        # the two modes scale their int32 fixed-point sums differently (the generator's points may use the density cap, injected
+        # points must use the provable one, loss.hip FX_CAP): same gradient to the coarser of the two quantisation steps
+        assert float((ga - gb).abs().max()) <= 4e-6 * float(gb.abs().max())
         assert torch.equal(ga, ops.point_loss_backward(ca, wm_, wd_))            # integer sums: the same bits every time
 
 
