@@ -328,11 +328,11 @@ def per_kernel_report(prof, steps, dims, args):
     """north_star's per-kernel numbers: achieved HBM GB/s of the MSDeformAttn gather against its algorithmic bytes (and, from the
     committed PMC pass, against the bytes it really moved), MFMA rate / busy fraction of the mask-logit einsum and of the masked
     cross-attention.  Durations: HIP events around each launch inside this run's one-stream steps; the PMC figures come from
-    profiles/r3_pmc_northstar.json (rocprofv3 --pmc passes of scripts/mb_northstar_kernels.py, stamped with their commit)."""
+    profiles/r4_pmc_northstar.json (rocprofv3 --pmc passes of scripts/mb_northstar_kernels.py, stamped with their commit)."""
     B, T, Q = dims
     pmc = {}
-    pp = os.path.join(ROOT, "profiles", "r3_pmc_northstar.json")
-    if os.path.exists(pp) and args.config == "c4" and args.dense == "f16x3":
+    pp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r4_pmc_northstar.json", "r3_pmc_northstar.json")) if os.path.exists(q)), "")
+    if pp and args.config == "c4" and args.dense == "f16x3":
         j = json.load(open(pp))
         pmc = {k: dict(v, pmc_commit=j.get("commit")) for k, v in j.get("kernels", {}).items()}
 
@@ -606,7 +606,7 @@ def main():
             # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (scripts/pmc_traffic.py; fetch corrected x2 as MI355X_MICROARCH.md prescribes), stamped with the commit it was taken at
             traffic, traffic_src = None, None
-            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
                 if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
                     j = json.load(open(tp))

@@ -99,12 +99,19 @@ int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hip
  * s2d_ffn_pack_f16 wrote from W1 [F, C] and W2 [C, F] (s2d_ffn_pack_words(C, F) 32-bit words; -1 = unsupported sizes).
  * Dropout: p = 0 -> none; otherwise the counter-based masks of s2d_gemm_nt_dropout_f32 for (seed, site_hidden) on the [M, F] hidden
  * activation and (seed, site_out) on the [M, C] output, mask row of row 0 = row0 -- the same bits the two-launch form applies.
- * xn (optional, requires ln1_gamma): receives the normalised input. */
-long s2d_ffn_pack_words(int C, int F);
-int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, void *out, hipStream_t stream);
+ * xn (optional, requires ln1_gamma): receives the normalised input.
+ * Npost > 0 (a multiple of 32; requires both LayerNorms): the same launch also applies the NEXT encoder layer's merged projection to
+ * every output row while it is still in registers -- post_out[row][n] = y[row] . Wpost[n]^T + post_bias[n] (+ post_pos[row % post_S][n]
+ * for n < post_npos, a multiple of 32: the row-periodic `pos . W^T + b` term of the sampling offsets / attention logits; post_ldpos
+ * its row stride) for n < Npost, row stride post_ld -- i.e. [sampling_offsets | attention_weights | value_proj] of
+ * ops/modules/ms_deform_attn.py:98-104 applied to the layer output, which is the next layer's `src`.  Wpost [Npost, C] is packed behind
+ * the FFN weights by s2d_ffn_pack_f16. */
+long s2d_ffn_pack_words(int C, int F, int Npost);
+int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, void *out, hipStream_t stream);
 int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, const float *b1, const float *b2, const float *ln1_gamma,
                       const float *ln1_beta, const float *ln2_gamma, const float *ln2_beta, float eps, float p, uint64_t seed,
-                      unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, hipStream_t stream);
+                      unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, int Npost, const float *post_bias,
+                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld, hipStream_t stream);
 
 /* NHWC convolution as implicit GEMM: x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
  * y [N,Ho,Wo,Cout] = act(conv(x,w) * scale[Cout] + bias[Cout] + res).  Replaces detectron2 Conv2d+FrozenBN+ReLU
@@ -301,8 +308,10 @@ int s2d_kd_targets_u8(const float *t_class_logits, const float *t_mask_logits, f
 int s2d_target_nonempty(const uint8_t *tgt, const int *count, int B, int Nmax, int T, int H, int W, int *nonempty,
                         hipStream_t stream);
 
+/* H, W: the padded frame size of the targets (frames beyond 1.15 M pixels keep a bit-packed target plane per workgroup behind the
+ * sample buffer: their plane does not fit LDS) */
 long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm, int num_points,
-                                    float oversample_ratio, float importance_ratio);
+                                    float oversample_ratio, float importance_ratio, int H, int W);
 
 /* loss_masks for NL layers at once (criterion.py:292-356, point_features.py:63-116): losses[layer][0] = loss_mask,
  * [1] = loss_dice, both already divided by num_masks = max(sum_b tgt_count[b] / world_size, 1) (:404-409).

@@ -45,6 +45,14 @@ def _raise_if_flagged():
         raise RuntimeError(_MSG)
 
 
+def reset():
+    """forget rejected shapes seen so far (other users of the library in this process -- e.g. calls of ops.msda_forward_dev with
+    deliberately bad shapes -- set the same process-wide word)"""
+    _word()
+    torch.cuda.current_stream().synchronize()
+    _WORD[0] = 0
+
+
 def check():
     """synchronise the current stream and raise if any call so far was given shapes that do not describe its `value`"""
     _word()

@@ -87,19 +87,38 @@ __device__ __forceinline__ void mfma_v0(f32x16 &c, const f16x8 a, const f16x8 b,
     pv.a = a; pv.b = b;
 }
 
-// one thread = one lane's 16 bytes of one fragment
-__global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int F, u32x4 *__restrict__ out)
+// The 256 input columns of a "part" (16 k-steps x (hi, lo) A-fragments of 32 weight rows) are taken in the order the B operand holds
+// them when it comes out of an accumulator tile set: k-step ks = 2 t + s, lane half h, element j  <->  column 32 t + 16 h + 8 s + j
+// (a lane's accumulator registers are columns 32 t + 16 h + 0..15; the input tile is loaded from memory in that layout too).
+__host__ __device__ __forceinline__ int kcol(int ks, int h) { return 32 * (ks >> 1) + 16 * h + 8 * (ks & 1); }
+
+// one thread = one lane's 16 bytes of one fragment.  Image: [F / 32 chunks x 64 fragments: W1 part | W2 k-step 0 | W2 k-step 1]
+// [npost / 32 parts x 32 fragments: the rows 32 j + perm_row(r) of Wpost, as a W1 part]
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int F,
+                                                       const float *__restrict__ Wpost, int npost, u32x4 *__restrict__ out)
 {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int lane = (int)(gid & 63), frag = (int)((gid >> 6) & 63);
-    const long c = gid >> 12;
-    if (c >= F / 32) return;
-    const int r = lane & 31, h = lane >> 5, lo = frag & 1;
+    const long nfrag = (long)(F / 32) * 64 + (long)(npost / 32) * 32;
+    if (gid >= nfrag * 64) return;
+    const int lane = (int)(gid & 63);
+    const long fidx = gid >> 6;
+    const int r = lane & 31, h = lane >> 5;
     const float *src;
-    if (frag < 32) src = W1 + (32 * c + perm_row(r)) * FC + 16 * (frag >> 1) + 8 * h;                      // k-step frag >> 1 of GEMM 1
-    else {
-        const int f2 = frag - 32, s = f2 >> 4, t = (f2 >> 1) & 7;
-        src = W2 + (long)(32 * t + perm_row(r)) * F + 32 * c + 16 * h + 8 * s;                               // k-step s, tile t of GEMM 2
+    int lo;
+    if (fidx < (long)(F / 32) * 64) {
+        const int frag = (int)(fidx & 63);
+        const long c = fidx >> 6;
+        lo = frag & 1;
+        if (frag < 32) src = W1 + (32 * c + perm_row(r)) * FC + kcol(frag >> 1, h);                            // k-step frag >> 1 of GEMM 1
+        else {
+            const int f2 = frag - 32, s = f2 >> 4, t = (f2 >> 1) & 7;
+            src = W2 + (long)(32 * t + perm_row(r)) * F + 32 * c + 16 * h + 8 * s;                               // k-step s, tile t of GEMM 2
+        }
+    } else {
+        const long f2 = fidx - (long)(F / 32) * 64;
+        const int frag = (int)(f2 & 31);
+        lo = frag & 1;
+        src = Wpost + (32 * (f2 >> 5) + perm_row(r)) * FC + kcol(frag >> 1, h);
     }
     u32x4 w;
 #pragma unroll
@@ -123,9 +142,14 @@ struct FfnParams {
     unsigned int thresh;        // dropout: element kept iff its 16 bits >= thresh; 0 = no dropout
     float dscale;
     unsigned int k0, k1, site_h, site_o, row0;
+    // POST: the next encoder layer's merged projection of the output row, out_post[row][n] = y . Wpost[n]^T + post_bias[n]
+    // (+ post_pos[row % post_S][n] for n < post_npos: the row-periodic (pos . W^T + b) term of the sampling offsets / attention logits)
+    const float *post_bias, *post_pos;
+    float *post_out;
+    int post_parts, post_S, post_npos, post_ld, post_ldpos;
 };
 
-template <bool DROP, bool LN1, bool LN2>
+template <bool DROP, bool LN1, bool LN2, bool POST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_f16x3_kernel(FfnParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [W1 buf 0 | W1 buf 1 | W2 buf 0 | W2 buf 1 | b1]
@@ -134,9 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long row = (long)blockIdx.x * 128 + wave * 32 + tok;
     const bool rowok = row < p.M;
     const long rowc = rowok ? row : p.M - 1;
-    const unsigned int mrow = p.row0 + (unsigned int)row;                    // mask row
+    const unsigned int mrow = p.row0 + (unsigned int)rowc;                   // mask row (lanes past M replicate row M - 1 exactly: their stores of
+                                                                             // the projection phase are unconditional and must carry its values)
 
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB + p.post_parts * PART, 0x00020000);
     // a wave copies pieces wave * n .. wave * n + n - 1 of a part of 4 n pieces (n = 8: 32 KB; n = 4: one k-step of W2, 16 KB)
     auto dma_part = [&](int src_byte, int dst_byte, auto n_) {
         constexpr int n = decltype(n_)::value;
@@ -155,52 +180,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = tid; i < PART / 2 / 16; i += 256)            // W2 k-step 1 buffer 1: what chunk 0's (empty) pass A multiplies by zero
         reinterpret_cast<u32x4 *>(lds + 3 * PART + PART / 2)[i] = u32x4{0u, 0u, 0u, 0u};
 
-    // ---- input tile -> fp16 hi / lo B fragments of GEMM 1: fragment ks holds X[row][16 ks + 8 h + j], j = 0..7 ----
+    // ---- input tile -> fp16 hi / lo B fragments of GEMM 1.  The row is loaded in the accumulator layout (this lane: columns
+    // 32 t + 16 h + 0..15 for t = 0..7, lane ^ 32 the other halves) and parked in the output accumulators, which are idle until the
+    // chunk loop: LayerNorm1 needs the whole row before any fragment can be formed, and 128 parked values + 128 fragment registers do
+    // not fit the vector half.  Fragment (k-step 2 t + s) = columns 32 t + 16 h + 8 s + 0..7: kcol(), the order the weight image uses.
+    f32x16 ym[8], yx[8];
     f16x8 xh[16], xl[16];
     float mean1 = 0.f, rstd1 = 1.f;
+    auto tile_to_frags = [&]() {        // ym (fp32, accumulator layout) -> xh / xl
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 hi, lo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = ym[t][8 * s2 + 2 * q], b = ym[t][8 * s2 + 2 * q + 1];
+                    hi[q] = pk_hi(a, b);
+                    lo[q] = pk_lo(a, b, hi[q]);
+                }
+                xh[2 * t + s2] = __builtin_bit_cast(f16x8, hi);
+                xl[2 * t + s2] = __builtin_bit_cast(f16x8, lo);
+            }
+    };
     {
-        const float *xr = p.X + rowc * FC + 8 * h;
+        const float *xr = p.X + rowc * FC + 16 * h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
+                ym[t][4 * q] = a[0]; ym[t][4 * q + 1] = a[1]; ym[t][4 * q + 2] = a[2]; ym[t][4 * q + 3] = a[3];
+            }
         if (LN1) {
-            // LayerNorm1 statistics of the row: this lane holds 128 of its 256 values, lane ^ 32 the others
             float s = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 16 * ks), b = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
-                s += (a[0] + a[1] + a[2] + a[3]) + (b[0] + b[1] + b[2] + b[3]);
-            }
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += ym[t][r];
             s += __shfl_xor(s, 32, 64);
             mean1 = s / (float)FC;
             float ss = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 16 * ks) - mean1, b = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4) - mean1;
-                ss += (a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
-            }
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = ym[t][r] - mean1; ss += d * d; }
             ss += __shfl_xor(ss, 32, 64);
             rstd1 = 1.f / sqrtf(ss / (float)FC + p.eps);
-        }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 16 * ks), b = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
-            if (LN1) {
-                const float *gp = p.g1 + 16 * ks + 8 * h, *bp = p.be1 + 16 * ks + 8 * h;
-                a = (a - mean1) * rstd1 * *reinterpret_cast<const f32x4 *>(gp) + *reinterpret_cast<const f32x4 *>(bp);
-                b = (b - mean1) * rstd1 * *reinterpret_cast<const f32x4 *>(gp + 4) + *reinterpret_cast<const f32x4 *>(bp + 4);
-                if (p.Xn && rowok) {
-                    *reinterpret_cast<f32x4 *>(p.Xn + row * FC + 8 * h + 16 * ks) = a;
-                    *reinterpret_cast<f32x4 *>(p.Xn + row * FC + 8 * h + 16 * ks + 4) = b;
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.g1 + 32 * t + 16 * h + 4 * q), be = *reinterpret_cast<const f32x4 *>(p.be1 + 32 * t + 16 * h + 4 * q);
+                    f32x4 v = {ym[t][4 * q], ym[t][4 * q + 1], ym[t][4 * q + 2], ym[t][4 * q + 3]};
+                    v = (v - mean1) * rstd1 * ga + be;
+                    ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3];
+                    if (p.Xn && rowok) *reinterpret_cast<f32x4 *>(p.Xn + row * FC + 32 * t + 16 * h + 4 * q) = v;
                 }
-            }
-            u32x4 hi, lo;
-            hi[0] = pk_hi(a[0], a[1]); hi[1] = pk_hi(a[2], a[3]); hi[2] = pk_hi(b[0], b[1]); hi[3] = pk_hi(b[2], b[3]);
-            lo[0] = pk_lo(a[0], a[1], hi[0]); lo[1] = pk_lo(a[2], a[3], hi[1]); lo[2] = pk_lo(b[0], b[1], hi[2]); lo[3] = pk_lo(b[2], b[3], hi[3]);
-            xh[ks] = __builtin_bit_cast(f16x8, hi);
-            xl[ks] = __builtin_bit_cast(f16x8, lo);
         }
+        tile_to_frags();
     }
 
     // ---- output accumulators: tile t, register reg <-> column 32 t + 16 h + reg of the wave's rows; bias b2 as the initial value ----
-    f32x16 ym[8], yx[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -369,6 +410,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                            // the last chunk's W2 k-step 1 pieces, copied by all four waves
+    const int post_base = p.nchunks * CHUNKB;
+    if (POST) {
+        // both W1 buffers are free: the projection's part 0 and the first quarter of part 1 go out now and land behind the last pass
+        // and the epilogue (the remaining pieces follow the per-part schedule of the projection loop)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_piece(post_base + (wave * 8 + k) * FRAG, (wave * 8 + k) * FRAG);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) dma_piece(post_base + (p.post_parts > 1 ? PART : 0) + (wave * 8 + k) * FRAG, PART + (wave * 8 + k) * FRAG);
+    }
     frag_read(0, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2));
     frag_read(1, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2) + 2 * FRAG);
     gemm2_pass(std::integral_constant<int, 1>{}, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2), lane_lds, 1000, 0, 1000, -1);   // no fillers
@@ -431,8 +481,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 v = (v - mean) * rstd * ga + be;
             }
             if (rowok) *reinterpret_cast<f32x4 *>(yr + 32 * t + 4 * q) = v;
+            if (POST) { ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3]; }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (POST) {
+        // ---- the next layer's merged projection of the row just written: out_post[row][32 j + 16 h + reg] for the post_parts tiles j,
+        // one weight part (32 KB, W1 buffers alternately) per tile, the row as the B fragments (same layout as the input tile's).
+        // Accumulators: builtin MFMAs on two (main, cross) pairs, so that tile j - 1's epilogue -- 16 values per lane: combine, the
+        // row-periodic pos term for the first post_npos columns, one 64-byte store -- runs in the gaps of tile j's MFMAs.
+        tile_to_frags();
+        const long prow = rowc % p.post_S;
+        const float *posr = p.post_pos + prow * p.post_ldpos + 16 * h;
+        float *outr = p.post_out + rowc * p.post_ld + 16 * h;
+        const float *pbr = p.post_bias + 16 * h;
+        f32x16 pm[2], px[2];
+        auto acc_init = [&](f32x16 &m, f32x16 &x, int j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(pbr + 32 * j + 4 * q);
+                m[4 * q] = b[0]; m[4 * q + 1] = b[1]; m[4 * q + 2] = b[2]; m[4 * q + 3] = b[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+        };
+        f32x4 pos4[4];
+        auto pos_load = [&](int j) {         // tile j's row-periodic term
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pos4[q] = *reinterpret_cast<const f32x4 *>(posr + 32 * j + 4 * q);
+        };
+        auto tile_out = [&](const f32x16 &m, const f32x16 &x, int j, int q, bool haspos) {
+            f32x4 v = {m[4 * q] + x[4 * q] * (1.0f / 2048.0f), m[4 * q + 1] + x[4 * q + 1] * (1.0f / 2048.0f),
+                       m[4 * q + 2] + x[4 * q + 2] * (1.0f / 2048.0f), m[4 * q + 3] + x[4 * q + 3] * (1.0f / 2048.0f)};
+            if (haspos) v += pos4[q];
+            *reinterpret_cast<f32x4 *>(outr + 32 * j + 4 * q) = v;        // unconditional (rows past M rewrite row M - 1 with its own values): the wait below counts it
+        };
+        // part j (accumulator pair CUR = j & 1; PREV: 0 = no previous tile, 1 = the previous tile takes the pos term, 2 = it does not):
+        // the 8 DMA pieces issued while it runs are the rest of part j + 1 (k-steps 0..5, behind barrier j - 1 that freed its buffer)
+        // and the first two of part j + 2 (behind this part's barrier, k-steps 14, 15)
+        auto post_part = [&](auto cur_, auto prev_, int j) {
+            constexpr int CUR = decltype(cur_)::value, PREV = decltype(prev_)::value;
+            const unsigned char *w = lane_lds + CUR * PART, *wn = lane_lds + (CUR ^ 1) * PART;
+            const int last = p.post_parts - 1;
+            const int src1 = post_base + min(j + 1, last) * PART, src2 = post_base + min(j + 2, last) * PART;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int sl = ks & 3, sn = (ks + 2) & 3;
+                if (ks == 14) {
+                    // the DMA pieces of the next part must have landed; the previous tile's four stores (k-steps 6, 8, 10, 12) and the four
+                    // bias loads of k-step 13 -- the youngest vector-memory operations -- need not: vmcnt retires in order
+                    if (PREV) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                frag_read(sn, ks < 14 ? w + (2 * ks + 4) * FRAG : wn + (2 * (ks - 14)) * FRAG);
+                mfma_a(pm[CUR], fr[sl][0], xh[ks]);
+                if (ks == 2 && PREV == 1) pos_load(j - 1);
+                if (ks == 13) acc_init(pm[CUR ^ 1], px[CUR ^ 1], min(j + 1, last));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_a(px[CUR], fr[sl][0], xl[ks]);
+                if (ks < 6) dma_piece(src1 + (wave * 8 + 2 + ks) * FRAG, (CUR ^ 1) * PART + (wave * 8 + 2 + ks) * FRAG);
+                if (ks >= 14) dma_piece(src2 + (wave * 8 + ks - 14) * FRAG, CUR * PART + (wave * 8 + ks - 14) * FRAG);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_a(px[CUR], fr[sl][1], xh[ks]);
+                if (PREV && ks >= 6 && ks < 14 && !(ks & 1)) tile_out(pm[CUR ^ 1], px[CUR ^ 1], j - 1, (ks - 6) >> 1, PREV == 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 2> I2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // part 0 (and the head of part 1) have landed ...
+        __syncthreads();                                        // ... in every wave
+        frag_read(0, lane_lds);
+        frag_read(1, lane_lds + 2 * FRAG);
+        acc_init(pm[0], px[0], 0);
+        const int npt = p.post_npos >> 5;                       // tiles 0 .. npt - 1 take the pos term
+        post_part(I0{}, I0{}, 0);
+        for (int j = 1; j < p.post_parts; ++j) {
+            const bool hp = j - 1 < npt;                        // wave-uniform: one branch per part, outside its schedule
+            if (j & 1) { if (hp) post_part(I1{}, I1{}, j); else post_part(I1{}, I2{}, j); }
+            else { if (hp) post_part(I0{}, I1{}, j); else post_part(I0{}, I2{}, j); }
+        }
+        {
+            const int j = p.post_parts - 1;
+            const bool hp = j < npt;
+            if (hp) pos_load(j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { if (j & 1) tile_out(pm[1], px[1], j, q, hp); else tile_out(pm[0], px[0], j, q, hp); }
+        }
     }
 }
 
@@ -440,29 +578,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" {
 
-long s2d_ffn_pack_words(int C, int F)
+long s2d_ffn_pack_words(int C, int F, int Npost)
 {
-    if (C != FC || F <= 0 || F % 32 || F > FMAX) return -1;
-    return (long)(F / 32) * (CHUNKB / 4);
+    if (C != FC || F <= 0 || F % 32 || F > FMAX || Npost < 0 || Npost % 32 || Npost > 4096) return -1;
+    return (long)(F / 32) * (CHUNKB / 4) + (long)(Npost / 32) * (PART / 4);
 }
 
-int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, void *out, hipStream_t stream)
+int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, void *out, hipStream_t stream)
 {
-    if (s2d_ffn_pack_words(C, F) < 0 || !W1 || !W2 || !out) return S2D_ERR_ARG;
-    const long n = (long)(F / 32) * 64 * 64;
-    hipLaunchKernelGGL(ffn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, W1, W2, F, reinterpret_cast<u32x4 *>(out));
+    if (s2d_ffn_pack_words(C, F, Npost) < 0 || !W1 || !W2 || !out || (Npost > 0 && !Wpost)) return S2D_ERR_ARG;
+    const long n = ((long)(F / 32) * 64 + (long)(Npost / 32) * 32) * 64;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, W1, W2, F, Wpost, Npost, reinterpret_cast<u32x4 *>(out));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
 
 int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, const float *b1, const float *b2, const float *ln1_gamma,
                       const float *ln1_beta, const float *ln2_gamma, const float *ln2_beta, float eps, float p, uint64_t seed,
-                      unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, hipStream_t stream)
+                      unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, int Npost, const float *post_bias,
+                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld, hipStream_t stream)
 {
-    if (s2d_ffn_pack_words(C, F) < 0 || !x || !pack || !b1 || !b2 || !y || M <= 0 || M > 0x7FFFFF00L) return S2D_ERR_ARG;
+    if (s2d_ffn_pack_words(C, F, Npost) < 0 || !x || !pack || !b1 || !b2 || !y || M <= 0 || M > 0x7FFFFF00L) return S2D_ERR_ARG;
     if ((ln1_gamma == nullptr) != (ln1_beta == nullptr) || (ln2_gamma == nullptr) != (ln2_beta == nullptr)) return S2D_ERR_ARG;
     if (xn && !ln1_gamma) return S2D_ERR_ARG;
     if (!(p >= 0.f && p < 1.f)) return S2D_ERR_ARG;
+    if (Npost > 0 && (!post_bias || !post_out || post_ld < Npost || (post_ld & 3) || post_npos < 0 || post_npos > Npost || (post_npos & 31) ||
+                      (post_npos > 0 && (!post_pos || post_S <= 0 || post_ldpos < post_npos || (post_ldpos & 3))) || M * post_ld > 0x7FFFFFFFL * 4))
+        return S2D_ERR_ARG;
     FfnParams q;
     q.X = x; q.Y = y; q.Xn = xn; q.M = (int)M; q.nchunks = F / 32;
     q.pack = reinterpret_cast<const unsigned int *>(pack);
@@ -470,17 +612,20 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     q.thresh = (unsigned int)lrintf(p * 65536.f);
     q.dscale = 1.f / (1.f - p);
     q.k0 = (unsigned int)seed; q.k1 = (unsigned int)(seed >> 32); q.site_h = site_hidden; q.site_o = site_out; q.row0 = row0;
+    q.post_bias = post_bias; q.post_pos = post_npos > 0 ? post_pos : post_bias; q.post_out = post_out; q.post_parts = Npost / 32;
+    q.post_S = post_npos > 0 ? post_S : 1; q.post_npos = post_npos; q.post_ld = (int)post_ld; q.post_ldpos = (int)post_ldpos;
     const int smem = LDS_B1 + FMAX * 4;
     const dim3 grid(cdiv(M, 128)), block(256);
-    static S2dDevOnce attr[12];
-    const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr;
+    static S2dDevOnce attr[16];
+    const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr, post = Npost > 0;
     const void *fn = nullptr;
-#define S2D_FFN_CASE(D, A, B) if (drop == D && ln1 == A && ln2 == B) fn = (const void *)ffn_f16x3_kernel<D, A, B>;
-    S2D_FFN_CASE(false, false, false) S2D_FFN_CASE(false, false, true) S2D_FFN_CASE(false, true, true)
-    S2D_FFN_CASE(true, false, false) S2D_FFN_CASE(true, false, true) S2D_FFN_CASE(true, true, true)
+#define S2D_FFN_CASE(D, A, B, P) if (drop == D && ln1 == A && ln2 == B && post == P) fn = (const void *)ffn_f16x3_kernel<D, A, B, P>;
+    S2D_FFN_CASE(false, false, false, false) S2D_FFN_CASE(false, false, true, false) S2D_FFN_CASE(false, true, true, false)
+    S2D_FFN_CASE(true, false, false, false) S2D_FFN_CASE(true, false, true, false) S2D_FFN_CASE(true, true, true, false)
+    S2D_FFN_CASE(false, true, true, true) S2D_FFN_CASE(true, true, true, true)
 #undef S2D_FFN_CASE
-    if (!fn) return S2D_ERR_ARG;          // LayerNorm on the input only: not instantiated (no caller)
-    const int slot = (drop ? 6 : 0) + (ln1 ? 2 : 0) + (ln2 ? 1 : 0);
+    if (!fn) return S2D_ERR_ARG;          // combinations without a caller are not instantiated
+    const int slot = (post ? 8 : 0) + (drop ? 4 : 0) + (ln1 ? 2 : 0) + (ln2 ? 1 : 0);
     if (!attr[slot].done()) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return S2D_ERR_LAUNCH;
         attr[slot].mark();

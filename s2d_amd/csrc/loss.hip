@@ -246,6 +246,7 @@ struct LossParams {
     float *part;              // [rows][chunks][4]
     int chunks;
     float *xbuf;              // [xcap][n_over + n_rand]: sampled logits of the first xcap active rows (sampled ONCE)
+    unsigned int *bits_global; // [ACC_BLOCKS][H*W/32] or null: the accumulate pass's bit-packed target plane when it does not fit LDS
     int xcap;
     int *pbound;              // [rows][PB_STRIDE]: RNG mode, first oversampled-point index of every map part of the row (strata)
 };
@@ -905,7 +906,9 @@ struct LossBwdArgs {
     float w_mask, w_dice;     // loss weights (weight_dict) of loss_mask / loss_dice
     unsigned int *bit_scratch; // [gridDim.x][H*W/32]: the row's bit-packed target plane (LDS holds the gradient tile instead)
 };
-template <bool BWD>
+// GBITS: the row's bit-packed target plane lives in global scratch (backward: LDS holds the gradient tile; forward: frames beyond
+// 1.15 M pixels), read back coherently, instead of in the dynamic LDS
+template <bool BWD, bool GBITS = BWD>
 __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p, LossBwdArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int tbits[];
@@ -926,7 +929,8 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     __shared__ int s_pb[PB_STRIDE];
     const PartGeom sg_ = part_geom(p.hm, p.wm);
     if ((int)threadIdx.x < sg_.nparts) { const VRange vr = part_vrange(threadIdx.x, sg_.nparts, sg_.rows_per_part, p.hm); s_v0[threadIdx.x] = vr.v0; s_dv[threadIdx.x] = vr.dv; }
-    unsigned int *tb = BWD ? ba.bit_scratch + (long)blockIdx.x * (HW / 32) : tbits;
+    static_assert(GBITS || !BWD, "the backward keeps its gradient tile in the dynamic LDS");
+    unsigned int *tb = GBITS ? (BWD ? ba.bit_scratch : p.bits_global) + (long)blockIdx.x * (HW / 32) : tbits;
     // BWD: the dynamic LDS is the gradient tile [hh][wm], accumulated in FIXED POINT (int32, LDS integer atomics): integer sums
     // do not depend on the order the points arrive in, so the gradient is bitwise reproducible -- float atomics made it the last
     // gradient of the training step that was not.  Scale per row: a power of two such that FX_CAP tap weights of the largest
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
             }
             tb[wd] = out;
         }
-        if constexpr (BWD) __threadfence();
+        if constexpr (GBITS) __threadfence();
         if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
         __syncthreads();
         const unsigned int thr = p.prefix[rowid];
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                point(xv, sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
+                point(xv, sample_bits<GBITS>(tb, p.H, p.W, u, v), u, v);
             };
             // Only ~1 in 4 oversampled points passes the threshold, scattered over the lanes: evaluating them in place
             // would run the heavy path at 25 % lane utilisation.  Each wave instead compacts its selected points (ballot
@@ -1184,7 +1188,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
                 if (BWD && !ranged_ties) { const int y0 = y0_of(v); if (y0 < own_lo || y0 >= own_hi) return; }
-                point(xb[i], sample_bits<BWD>(tb, p.H, p.W, u, v), u, v);
+                point(xb[i], sample_bits<GBITS>(tb, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
                 for (unsigned int j = threadIdx.x; j < nties; j += LTHREADS) {
@@ -1379,16 +1383,21 @@ static void point_counts(int num_points, float oversample_ratio, float importanc
     n_rand = num_points - n_unc;                                   // :100
 }
 
+// frames whose bit-packed target plane (H * W / 8 bytes) does not fit LDS keep it in a per-workgroup scratch behind the workspace
+static inline bool plane_in_lds(long HW) { return HW / 8 <= 140 * 1024; }
+constexpr int ACC_BLOCKS = 512;          // workgroups of the accumulate pass (persistent over the rows)
+
 long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int hm, int wm, int num_points,
-                                    float oversample_ratio, float importance_ratio)
+                                    float oversample_ratio, float importance_ratio, int H, int W)
 {
     const long maxm = Q < Nmax ? Q : Nmax;
     const long rows = (long)NL * B * maxm * T;
     int n_over, n_unc, n_rand;
     point_counts(num_points, oversample_ratio, importance_ratio, n_over, n_unc, n_rand);
     const long xrows = rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS;
+    const long HW = (long)H * W;
     return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16 + PB_STRIDE * 4) + 4L * (NL + 1) + 1024 +
-           xrows * (long)(n_over + n_rand + 8) * 4;
+           xrows * (long)(n_over + n_rand + 8) * 4 + (plane_in_lds(HW) ? 0 : 256 + (long)ACC_BLOCKS * (HW / 32) * 4);
 }
 
 // parameter block + workspace carve-up shared by the forward and the backward entry points (same arguments, same layout)
@@ -1421,9 +1430,15 @@ static int loss_setup(LossParams &p, long &rows, const float *mask_logits, const
     p.mq = (float *)w; w += rows * (long)hm * wm * 4;
     w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     p.xbuf = (float *)w;
-    // samples are kept only when the target plane fits LDS as bits and vector loads line up
-    const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0) && ((long)H * W / 8 <= 140 * 1024);   // + ~13 KB of static LDS (queues, tie lists) under the 160 KB of a CU
+    // samples are kept when vector loads line up; the row's target plane is sampled as bits from LDS when it fits (H * W / 8 <= 140 KB
+    // beside ~13 KB of static LDS: up to 1.15 M pixels) and from a per-workgroup scratch behind the sample buffer otherwise
+    const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0);
     p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
+    p.bits_global = nullptr;
+    if (can_stream && !plane_in_lds((long)H * W)) {
+        char *e = (char *)p.xbuf + (long)p.xcap * (p.n_over + p.n_rand + 8) * 4;
+        p.bits_global = (unsigned int *)(((uintptr_t)e + 255) & ~(uintptr_t)255);
+    }
     const PartGeom pg = part_geom(hm, wm);
     if ((wm & 3) || pg.rows_per_part < 1 || pg.nparts > LOSS_CHUNKS) return S2D_ERR_ARG;
     p.chunks = pg.nparts;
@@ -1440,6 +1455,7 @@ static int loss_attrs()
             hipFuncSetAttribute(reinterpret_cast<const void *>(hist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return S2D_ERR_LAUNCH;
         attr_set.mark();
@@ -1479,7 +1495,10 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<2>, dim3(2048), dim3(256), 0, stream, p);
     if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
-    if (p.xcap > 0) hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(512), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f, nullptr});
+    if (p.xcap > 0 && !p.bits_global)
+        hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(ACC_BLOCKS), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f, nullptr});
+    else if (p.xcap > 0)
+        hipLaunchKernelGGL((accumulate_stream_kernel<false, true>), dim3(ACC_BLOCKS), dim3(LTHREADS), 16, stream, p, LossBwdArgs{nullptr, 0.f, 0.f, nullptr});
     if (rows > p.xcap) hipLaunchKernelGGL(accumulate_kernel, g, dim3(LTHREADS), lds_map, stream, p);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(NL), dim3(64), 0, stream, p, losses);
     S2D_CHECK_LAUNCH();
@@ -1511,7 +1530,7 @@ int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, co
     if (lds > 140 * 1024 || 3L * wm > 4L * LTHREADS || pg.nparts + 1 > PB_STRIDE) return S2D_ERR_ARG;
     // the bit-packed target planes of the rows in flight: the tail of the workspace's sample buffer is not used by the
     // backward walk beyond xcap rows; a dedicated scratch keeps it simple
-    hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(512), dim3(LTHREADS), lds, stream, p,
+    hipLaunchKernelGGL(accumulate_stream_kernel<true>, dim3(ACC_BLOCKS), dim3(LTHREADS), lds, stream, p,
                        LossBwdArgs{grad_rows, w_mask, w_dice, bit_scratch});
     S2D_CHECK_LAUNCH();
     return S2D_OK;

@@ -60,7 +60,14 @@ class MSDeformAttn(nn.Module):
             self._packed = (key, ops.mark_static(w_all), b_all, ops.mark_static(w_oa), b_oa)
         return self._packed[1:]
 
-    def forward_fused(self, src, pos, shapes, res, tape=None, dropout=None):
+    def projection(self, pos):
+        """what the previous layer's fused FFN launch needs to apply this layer's merged projection to its output rows (ops.ffn_fused
+        `post`): (w_all [288 + C, C], b_all, pos . W_oa^T + b_oa [S, 288])"""
+        S, C = pos.shape[-2:]
+        w_all, b_all, w_oa, b_oa = self.packed()
+        return w_all, b_all, ops.gemm_nt(pos.view(S, C), w_oa, bias=b_oa)
+
+    def forward_fused(self, src, pos, shapes, res, tape=None, dropout=None, both=None):
         """self-attention over the flattened pyramid with query = src + pos (query positions == value positions;
         pos [S, C] is shared by all N frames).  Returns dropout(output_proj(msda(...))) + res (dropout = (p, seed, site) or
         None: the encoder layer's dropout1, msdeformattn.py:125, fused into the projection's epilogue).
@@ -69,8 +76,10 @@ class MSDeformAttn(nn.Module):
         N, S, C = src.shape
         w_all, b_all, w_oa, b_oa = self.packed()
         n_oa = w_oa.shape[0]
-        pos_oa = ops.gemm_nt(pos.view(S, C), w_oa, bias=b_oa)
-        both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa).view(N, S, n_oa + C)
+        if both is None:
+            pos_oa = ops.gemm_nt(pos.view(S, C), w_oa, bias=b_oa)
+            both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa)
+        both = both.view(N, S, n_oa + C)          # (given: the previous layer's FFN launch already projected its output rows)
         samp = ops.msda_fused_forward(both[..., n_oa:], shapes, both[..., :n_oa], self.n_heads, self.n_points)
         out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C), dropout=dropout)
         if tape is not None:
@@ -139,8 +148,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.dropout_p = dropout
 
     fuse_ffn = True      # False: the two-launch FFN + separate LayerNorms also on the forward-only path (A/B measurements, tests)
+    fuse_next = True     # False: the next layer's merged projection stays its own launch
 
-    def forward(self, src, pos, shapes, tape=None):
+    def forward(self, src, pos, shapes, tape=None, both=None, nxt=None):
         """msdeformattn.py:116-131 (post-norm).  src [N,S,C], pos [S,C].
         src = norm1(src + dropout1(attn));  src = norm2(src + dropout3(linear2(dropout2(relu(linear1(src))))))  (:101-125).
         In training mode with p > 0 the three masks are counter-based (csrc/dropout.h: one Philox key per call, sites 0..2)
@@ -150,13 +160,17 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         seed = ops.next_dropout_seed() if p > 0.0 else 0
         d1, d2, d3 = ((p, seed, 0), (p, seed, 1), (p, seed, 2)) if p > 0.0 else (None, None, None)
         sub = [] if tape is not None else None
-        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1)
+        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1, both=both)
         if tape is None and self.fuse_ffn and ops.ffn_fusable(self.linear1.weight, self.linear2.weight):
             # forward / loss path (nothing kept for a backward): norm1, the whole FFN with both masks, the residual and norm2 in ONE
             # launch (csrc/ffn.hip) -- the 1024-wide hidden activation never reaches memory.  Same masks as the taped path below.
-            return ops.ffn_fused(x1.view(-1, C), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                                 ln1=(self.norm1.weight, self.norm1.bias), ln2=(self.norm2.weight, self.norm2.bias),
-                                 dropout=(p, seed, 1, 2) if p > 0.0 else None, eps=self.norm1.eps).view(N, S, C)
+            # nxt (the next layer's attention module): its merged projection of this layer's output rows rides in the same launch;
+            # returns (output, that projection) then.
+            out = ops.ffn_fused(x1.view(-1, C), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                ln1=(self.norm1.weight, self.norm1.bias), ln2=(self.norm2.weight, self.norm2.bias),
+                                dropout=(p, seed, 1, 2) if p > 0.0 else None, eps=self.norm1.eps,
+                                post=nxt.projection(pos) if nxt is not None else None)
+            return (out[0].view(N, S, C), out[1]) if nxt is not None else out.view(N, S, C)
         s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
         h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True, dropout=d2)
         x2 = ops.gemm_nt(h, self.linear2.weight, bias=self.linear2.bias, res=s1.view(-1, C), dropout=d3).view(N, S, C)
@@ -280,8 +294,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
         pos = self._pos(shapes, src.device)
         shp = torch.tensor(shapes, dtype=torch.int64)
         enc = [] if tape is not None else None
-        for layer in self.transformer.encoder.layers:
-            src = layer(src, pos, shp, enc)
+        layers = list(self.transformer.encoder.layers)
+        both = None
+        for i, layer in enumerate(layers):
+            # forward-only path: layer i's FFN launch also applies layer i + 1's merged projection to its output rows
+            nxt = layers[i + 1].self_attn if (enc is None and i + 1 < len(layers) and layer.fuse_ffn and layer.fuse_next
+                                              and ops.ffn_fusable(layer.linear1.weight, layer.linear2.weight)) else None
+            out = layer(src, pos, shp, enc, both=both, nxt=nxt)
+            src, both = out if nxt is not None else (out, None)
         N = src.shape[0]
         outs, o = [], 0
         for (h, w) in shapes:

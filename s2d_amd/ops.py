@@ -247,37 +247,46 @@ def gemm_nt_presplit(A_split, M, K, B, bias=None, res=None, relu=False, out=None
     return out
 
 
-_FFN_PACK = {}    # (W1 ptr, W2 ptr, F) -> (image, (version W1, version W2), weakrefs of the two parameters)
+_FFN_PACK = {}    # (W1 ptr, W2 ptr, Wpost ptr, F, Npost) -> (image, versions, weakrefs of the owners)
 
 
-def _ffn_pack(W1, W2):
-    """cached MFMA-fragment image of an FFN's two weight matrices (s2d_ffn_pack_f16), rebuilt when either parameter changes"""
+def _owner(t):
+    return t._base if t._base is not None else t
+
+
+def _ffn_pack(W1, W2, Wpost=None):
+    """cached MFMA-fragment image of an FFN's two weight matrices (+ the projection applied behind it), s2d_ffn_pack_f16; rebuilt when
+    an owner changes (parameter version; packed copies are replaced by their module, which changes the key)"""
     F, C = W1.shape
-    key = (W1.data_ptr(), W2.data_ptr(), F)
-    b1, b2 = (W1._base if W1._base is not None else W1), (W2._base if W2._base is not None else W2)
-    ver = (b1._version + getattr(b1, "_s2d_version", 0), b2._version + getattr(b2, "_s2d_version", 0))
+    Np = 0 if Wpost is None else Wpost.shape[0]
+    ts = (W1, W2) + (() if Wpost is None else (Wpost,))
+    key = tuple(t.data_ptr() for t in ts) + (F, Np)
+    owners = [_owner(t) for t in ts]
+    ver = tuple(o._version + getattr(o, "_s2d_version", 0) for o in owners)
     ent = _FFN_PACK.get(key)
-    if ent is None or ent[1] != ver or ent[2]() is not b1 or ent[3]() is not b2:
-        same = ent is not None and ent[2]() is b1 and ent[3]() is b2
-        img = ent[0] if same else torch.empty((lib().call("s2d_ffn_pack_words", C, F),), device=W1.device, dtype=torch.int32)
-        lib().call("s2d_ffn_pack_f16", W1, W2, C, F, img, _stream())
+    if ent is None or ent[1] != ver or any(r() is not o for r, o in zip(ent[2], owners)):
+        same = ent is not None and all(r() is o for r, o in zip(ent[2], owners))
+        img = ent[0] if same else torch.empty((lib().call("s2d_ffn_pack_words", C, F, Np),), device=W1.device, dtype=torch.int32)
+        lib().call("s2d_ffn_pack_f16", W1, W2, C, F, Wpost, Np, img, _stream())
         if not same and len(_FFN_PACK) >= 64:
-            for k in [k for k, e in _FFN_PACK.items() if e[2]() is None or e[3]() is None]:
+            for k in [k for k, e in _FFN_PACK.items() if any(r() is None for r in e[2])]:
                 del _FFN_PACK[k]
-        _FFN_PACK[key] = ent = (img, ver, weakref.ref(b1), weakref.ref(b2))
+        _FFN_PACK[key] = ent = (img, ver, [weakref.ref(o) for o in owners])
     return ent[0]
 
 
 def ffn_fusable(W1, W2):
     """the one-launch FFN exists for the split-fp16 arithmetic, model width 256 and hidden widths that are multiples of 32 (<= 2048)"""
     return (_MODE == "f16x3" and not amp_active() and W1.dim() == 2 and W1.shape[1] == 256 and tuple(W2.shape) == (256, W1.shape[0])
-            and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0])) > 0)
+            and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0]), 0) > 0)
 
 
-def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False):
+def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False, post=None):
     """y = LN2?( xn + drop( W2 . drop( relu( W1 . xn + b1 ) ) + b2 ) ),  xn = LN1?(x)   in one launch (csrc/ffn.hip).
     x [M, 256]; ln1 / ln2 = (gamma, beta) or None; dropout = (p, seed, site_hidden, site_out[, row0]) or None.
-    -> y, or (y, xn) with want_xn (requires ln1)."""
+    post = (Wpost [Np, 256], bias [Np], pos [S, npos] or None): also out_post[M, Np] = y . Wpost^T + bias (+ pos[row % S] on the first
+    npos columns) -- the next encoder layer's merged projection, applied while the row is in registers (needs ln1 and ln2).
+    -> y, (y, xn) with want_xn (requires ln1), with post additionally out_post as the last element."""
     for t in (x, W1, b1, W2, b2) + tuple(ln1 or ()) + tuple(ln2 or ()):
         _chk(t)
     M, C = x.shape
@@ -291,11 +300,25 @@ def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, wan
         row0 = dropout[4] if len(dropout) > 4 else 0
     g1, be1 = ln1 if ln1 is not None else (None, None)
     g2, be2 = ln2 if ln2 is not None else (None, None)
-    # counted as its two contractions; bytes: input, output, weights once
-    with _Timed(4.0 * M * F * C, ("ffn", 1, M, F, C, 4.0 * (2 * M * C + 2 * F * C))):
-        lib().call("s2d_ffn_fused_f32", x, M, C, F, _ffn_pack(W1, W2), b1, b2, g1, be1, g2, be2, float(eps), float(p),
-                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site_h), int(site_o), int(row0), xn, y, _stream())
-    return (y, xn) if want_xn else y
+    Wp = pb = pp = out_post = None
+    Np = S = npos = ldpos = 0
+    if post is not None:
+        Wp, pb, pp = post
+        assert ln1 is not None and ln2 is not None
+        for t in (Wp, pb, pp):
+            _chk(t)
+        Np = Wp.shape[0]
+        assert Wp.shape[1] == C and pb.shape == (Np,)
+        if pp is not None:
+            S, npos = pp.shape
+            ldpos = pp.stride(0)
+        out_post = torch.empty((M, Np), device=x.device, dtype=torch.float32)
+    # counted as its contractions; bytes: input, output(s), weights once
+    with _Timed(4.0 * M * F * C + 2.0 * M * Np * C, ("ffn", 1, M, F + Np // 2, C, 4.0 * (2 * M * C + M * Np + 2 * F * C + Np * C))):
+        lib().call("s2d_ffn_fused_f32", x, M, C, F, _ffn_pack(W1, W2, Wp), b1, b2, g1, be1, g2, be2, float(eps), float(p),
+                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site_h), int(site_o), int(row0), xn, y, Np, pb, pp, S, npos, ldpos, out_post, Np, _stream())
+    res = (y,) + ((xn,) if want_xn else ()) + ((out_post,) if post is not None else ())
+    return res if len(res) > 1 else y
 
 
 def dropout_apply(x, p, seed, site, row0=0, out=None):
@@ -625,7 +648,7 @@ def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dim
     NL, B = mask_logits.shape[:2]
     Q, T, hm, wm = dims
     Nmax, H, W = tgt.shape[1], tgt.shape[3], tgt.shape[4]
-    nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm, int(P), float(oversample), float(importance))
+    nbytes = lib().call("s2d_point_loss_workspace_bytes", NL, B, Q, Nmax, T, hm, wm, int(P), float(oversample), float(importance), H, W)
     ws = torch.empty((nbytes,), device=tgt.device, dtype=torch.uint8)
     losses = torch.zeros((NL, 2), device=tgt.device, dtype=torch.float32)
     args = (mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, coords_over, coords_rand, int(seed), NL, B, Q,

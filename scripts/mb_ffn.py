@@ -40,6 +40,10 @@ def two_launch(p):
 
 
 flops = 4.0 * M * 1024 * 256
+S = M // 16 if M % 16 == 0 else M
+Wp = ops.mark_static(torch.randn((544, 256), device=dev, generator=g) * 0.05)
+bp = torch.randn((544,), device=dev, generator=g) * 0.1
+pos = torch.randn((S, 288), device=dev, generator=g) * 0.5
 for p in (0.3, 0.0):
     drop = (p, 7, 1, 2) if p > 0 else None
     ref = two_launch(p)
@@ -50,5 +54,11 @@ for p in (0.3, 0.0):
     s1 = ops.layernorm(x, g1, be1)
     tf2 = timeit(lambda: ops.ffn_fused(s1, W1, b1, W2, b2, ln2=(g2, be2), dropout=drop))
     tf0 = timeit(lambda: ops.ffn_fused(s1, W1, b1, W2, b2, dropout=drop))
+    tp = timeit(lambda: ops.gemm_nt(ref, Wp, bias=bp, res=pos, res_rows=S, res_cols=288))
+    tfp = timeit(lambda: ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, post=(Wp, bp, pos)))
+    yp, outp = ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, post=(Wp, bp, pos))
+    refp = ops.gemm_nt(yp, Wp, bias=bp, res=pos, res_rows=S, res_cols=288)
+    print(f"p={p}: next layer's projection as its own launch {tp:.3f} ms | fused LN1+FFN+LN2+projection {tfp:.3f} ms (vs {tf:.3f} + {tp:.3f} = "
+          f"{tf + tp:.3f}) | max rel diff of the projection {float((outp - refp).abs().max() / refp.abs().max()):.2e}", flush=True)
     print(f"p={p}: two launches + 2 LN {t2:.3f} ms | fused LN1+FFN+LN2 {tf:.3f} ms ({flops / tf / 1e9:.0f} TFLOP/s alg.) | "
           f"fused FFN+LN2 {tf2:.3f} | fused FFN {tf0:.3f} | max rel diff {err:.2e}", flush=True)

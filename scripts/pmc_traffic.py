@@ -15,7 +15,7 @@ COMMIT = sys.argv[5] if len(sys.argv) > 5 else "unrecorded"
 
 
 def family(name):
-    if "gemm" in name: return "gemm"
+    if "gemm" in name or "conv3x3" in name or "conv7x7" in name or "ffn_f16x3" in name: return "gemm"      # the dense family (bench.py's roofline)
     if "msda" in name: return "msda"
     if "matcher_cost" in name: return "matcher_cost"
     if any(k in name for k in ("hist_", "accumulate", "gather_rows", "select_kernel", "loss_finalize", "row_prep", "row_list")): return "loss"

@@ -234,7 +234,8 @@ def test_msda_compat_module_fails_loudly_on_bad_shapes():
     good = torch.tensor([[6, 8], [3, 4]], dtype=torch.long, device=dev)
     bad = torch.tensor([[6, 8], [30, 40]], dtype=torch.long, device=dev)
     lsi = torch.tensor([0, 48], dtype=torch.long, device=dev)
-    MSDA.check()                                                    # clean so far
+    MSDA.reset()                                                    # (earlier tests feed the *_dev entry points bad shapes on purpose)
+    MSDA.check()                                                    # clean
     out = MSDA.ms_deform_attn_forward(value, good, lsi, loc, w, 64)
     MSDA.check()
     assert out.abs().sum() > 0

@@ -87,9 +87,77 @@ def test_ffn_fused_vs_two_launch_form(M):
     assert torch.equal(out2, ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, seed, 1, 2)))
 
 
+@pytest.mark.parametrize("M,S,p", [(200, 50, 0.0), (1000, 333, 0.3), (4097, 4097, 0.3), (128, 7, 0.0)])
+def test_ffn_fused_with_next_layer_projection(oracle, M, S, p):
+    """the launch that also applies the next encoder layer's merged projection (544 columns: 288 offsets / logits with the
+    row-periodic pos term, 256 value columns with their bias) to its output rows: against the float64 oracle of
+    [sampling_offsets | attention_weights | value_proj](LN2(...)) (ms_deform_attn.py:98-104), and the output itself unchanged"""
+    from s2d_amd import ops
+    F = 1024
+    W1, b1, W2, b2, g1, be1, g2, be2 = _params(F, 31)
+    x = synth.randn(32, 1, (M, 256)) * 1.5
+    Wp = synth.randn(33, 1, (544, 256)) * 0.05
+    bp = np.concatenate([np.zeros(288, np.float32), synth.randn(33, 2, (256,)) * 0.1]).astype(np.float32)
+    pos = synth.randn(33, 3, (S, 288)) * 0.5
+    drop = (p, 0x0123456789ABCDEF, 1, 2) if p > 0 else None
+    ref, _ = _oracle_ffn(oracle, x, W1, b1, W2, b2, (g1, be1), (g2, be2), drop)
+    refp = ref @ Wp.astype(np.float64).T + bp
+    refp[:, :288] += pos[np.arange(M) % S]
+    W1d, W2d, Wpd = torch.nn.Parameter(_dev(W1)), torch.nn.Parameter(_dev(W2)), ops.mark_static(_dev(Wp))
+    args = (_dev(x), W1d, _dev(b1), W2d, _dev(b2))
+    kw = dict(ln1=(_dev(g1), _dev(be1)), ln2=(_dev(g2), _dev(be2)), dropout=drop)
+    y, out = ops.ffn_fused(*args, post=(Wpd, _dev(bp), _dev(pos)), **kw)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(out.cpu().numpy(), refp, rtol=0, atol=2e-5 * np.abs(refp).max())
+    assert torch.equal(y, ops.ffn_fused(*args, **kw))                      # the output does not depend on the extra phase
+    y2, out2 = ops.ffn_fused(*args, post=(Wpd, _dev(bp), _dev(pos)), **kw)
+    assert torch.equal(out, out2) and torch.equal(y, y2)                    # run to run: same bits
+    # against the launch it replaces (same arithmetic class)
+    two = ops.gemm_nt(y, Wpd, bias=_dev(bp), res=_dev(pos), res_rows=S, res_cols=288)
+    assert torch.allclose(out, two, rtol=0, atol=3e-6 * float(two.abs().max()))
+
+
+def test_encoder_forward_with_and_without_fused_projection():
+    """the pixel decoder's encoder stack, forward-only path: fused FFN launches that carry the next layer's projection against the
+    stack with every projection as its own launch and against the fully unfused stack (same dropout masks: same seeds)"""
+    from s2d_amd import ops
+    from s2d_amd.modeling.pixel_decoder import MSDeformAttnTransformerEncoderLayer
+    torch.manual_seed(3)
+    layers = [MSDeformAttnTransformerEncoderLayer(dropout=0.3).to(DEV).train() for _ in range(3)]
+    for l in layers:
+        for q in l.parameters():
+            if q.dim() > 1:
+                torch.nn.init.xavier_uniform_(q)
+        torch.nn.init.normal_(l.self_attn.sampling_offsets.weight, std=0.02)
+    shapes = [(6, 10), (12, 20), (24, 40)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(4)
+    src0 = torch.randn((2, S, 256), generator=g).to(DEV)
+    pos = torch.randn((S, 256), generator=g).to(DEV)
+    shp = torch.tensor(shapes, dtype=torch.int64)
+
+    def run(fuse_ffn, fuse_next):
+        ops._DROP_CALLS[0] = 1000                      # same Philox keys in every arrangement
+        src, both = src0, None
+        for i, l in enumerate(layers):
+            l.fuse_ffn, l.fuse_next = fuse_ffn, fuse_next
+            nxt = layers[i + 1].self_attn if (fuse_ffn and fuse_next and i + 1 < len(layers)) else None
+            out = l(src, pos, shp, None, both=both, nxt=nxt)
+            src, both = out if nxt is not None else (out, None)
+        return src
+
+    a, b, c = run(True, True), run(True, False), run(False, False)
+    sc = float(c.abs().max())
+    assert float((a - b).abs().max()) < 5e-6 * sc and float((a - c).abs().max()) < 2e-5 * sc
+    for l in layers:
+        l.fuse_ffn = l.fuse_next = True
+
+
 def test_ffn_fused_rejects_unsupported_sizes():
     from s2d_amd._lib import lib
-    assert lib().call("s2d_ffn_pack_words", 128, 1024) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 1000) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 4096) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 1024) == 32 * 16384
+    assert lib().call("s2d_ffn_pack_words", 128, 1024, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1000, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 4096, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 100) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 0) == 32 * 16384
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 544) == 32 * 16384 + 17 * 8192
