@@ -69,6 +69,8 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     groups = param_groups_like_reference(model.student, 1e-4, 0.05)
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
+    from s2d_amd.optim import OverlappedAllReduce, student_parts
+    exchange = OverlappedAllReduce(opt, student_parts(model))
     losses, times, t_ar = [], [], []
     WARM = 4                                            # the caching allocator settles over the first iterations (0 hipMalloc from the fifth on)
     st0 = torch.cuda.memory_stats()
@@ -80,9 +82,9 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
         images = ops.normalize_pad(frames, 32, mean, std)
         targets = TargetSet.from_list(masks, device=dev)
         opt.zero_grad()
-        out = model.forward_backward(images, targets)
+        out = model.forward_backward(images, targets, grad_ready=exchange.ready)     # buckets go out while the backward still runs
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        inv = opt.allreduce_grads()
+        inv = exchange.finish()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         opt.step(inv_scale=inv, ema_momentum=0.999)
         tot = float(sum(out.values()))
@@ -92,7 +94,8 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     ms = 1000 * _max_over_ranks(sum(times[WARM:]) / iters, world, cdev or dev)
     ar = 1000 * _max_over_ranks(sum(t_ar[WARM:]) / iters, world, cdev or dev)
     return {"what": "one full training iteration per rank on its batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
-                    "(HIP gradient kernels, no autograd graph) + gradient all-reduce + full-model clip + AdamW + EMA teacher update; fp32, one stream",
+                    "(HIP gradient kernels, no autograd graph) + gradient all-reduce (per part of the student, started while the backward of the remaining parts "
+                    "runs; allreduce_ms = what is left to wait for after the backward) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
             "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(world * frames.shape[0] / (ms / 1000), 2),
             "allreduce_ms": round(ar, 2), "allreduce_bytes": int(opt.grad_arena.numel() * 4), "n_gpus": world,
             "iterations": iters, "warmup_iterations": WARM, "loss_per_iteration_rank0": losses,

@@ -101,9 +101,10 @@ int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hip
  * activation and (seed, site_out) on the [M, C] output, mask row of row 0 = row0 -- the same bits the two-launch form applies.
  * xn (optional, requires ln1_gamma): receives the normalised input.
  * Npost > 0 (a multiple of 32; requires both LayerNorms): the same launch also applies the NEXT encoder layer's merged projection to
- * every output row while it is still in registers -- post_out[row][n] = y[row] . Wpost[n]^T + post_bias[n] (+ post_pos[row % post_S][n]
- * for n < post_npos, a multiple of 32: the row-periodic `pos . W^T + b` term of the sampling offsets / attention logits; post_ldpos
- * its row stride) for n < Npost, row stride post_ld -- i.e. [sampling_offsets | attention_weights | value_proj] of
+ * every output row while it is still in registers -- post_out[row][n] = y[row] . Wpost[n]^T + post_pos[row % post_S][n] for
+ * n < post_npos (a multiple of 32: the row-periodic `pos . W^T + b` term of the sampling offsets / attention logits, which carries
+ * their bias -- post_bias is NOT read for these columns; post_ldpos its row stride) and y[row] . Wpost[n]^T + post_bias[n] for
+ * post_npos <= n < Npost, row stride post_ld -- i.e. [sampling_offsets | attention_weights | value_proj] of
  * ops/modules/ms_deform_attn.py:98-104 applied to the layer output, which is the next layer's `src`.  Wpost [Npost, C] is packed behind
  * the FFN weights by s2d_ffn_pack_f16. */
 long s2d_ffn_pack_words(int C, int F, int Npost);

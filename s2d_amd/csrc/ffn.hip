@@ -56,8 +56,10 @@ __host__ __device__ __forceinline__ int perm_row(int rho) { return 16 * ((rho >>
 __device__ __forceinline__ unsigned int pk_hi(float a, float b) { return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 __device__ __forceinline__ unsigned int pk_lo(float a, float b, unsigned int hi)
 {
-    const f32x2 f = __builtin_convertvector(__builtin_bit_cast(h16x2, hi), f32x2);
-    return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz((a - f[0]) * 2048.f, (b - f[1]) * 2048.f));
+    // (a - h) * 2048 == fma(h, -2048, a * 2048) exactly (a - h is exact, the factor a power of two): one multiply and one
+    // v_fma_mix_f32 (the fp16 operand converted inside the fma) per value instead of convert, subtract, multiply
+    const h16x2 h = __builtin_bit_cast(h16x2, hi);
+    return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -2048.f, a * 2048.f), __builtin_fmaf((float)h[1], -2048.f, b * 2048.f)));
 }
 
 // Register classes.  The 256 output accumulators must live in the accumulator half of the register file and everything else in the
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto hquarter = [&](int s, int idx) {
         const int q = idx >> 2, part = idx & 3, r0 = 8 * s + 2 * q;
         if (part == 0) {
-            hv0 = fmaxf(am[r0] + ax[r0] * (1.0f / 2048.0f), 0.f);
-            hv1 = fmaxf(am[r0 + 1] + ax[r0 + 1] * (1.0f / 2048.0f), 0.f);
+            hv0 = fmaxf(__builtin_fmaf(ax[r0], 1.0f / 2048.0f, am[r0]), 0.f);
+            hv1 = fmaxf(__builtin_fmaf(ax[r0 + 1], 1.0f / 2048.0f, am[r0 + 1]), 0.f);
         } else if (part == 1) {
             if (DROP) {
                 const uint32_t w = rb[s][q];
@@ -303,6 +305,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto dma_piece = [&](int src_byte, int dst_byte) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
     };
+    // piece `sub` (0..3) of a run of four consecutive 1-KB pieces: the instruction's immediate offset advances the source and the LDS
+    // address alike, so the four share one M0 value and one scalar offset (two scalar instructions saved per piece)
+    auto dma_piece4 = [&](int src_byte, int dst_byte, auto sub_) {
+        constexpr int SUB = decltype(sub_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, SUB * FRAG, 0);
+    };
     // the 16 pieces a wave copies per chunk, all behind the chunk's barrier (which frees their destinations):
     //   k 0..7  W1 of chunk pc + 2 -> W1 buffer pc & 1 (GEMM 1 of chunk pc has read it);  k 8..11  W2 k-step 0 of chunk pc + 1 -> S0 buffer
     //   (pc + 1) & 1;  k 12..15  W2 k-step 1 of chunk pc -> S1 buffer pc & 1 (read by the next chunk's pass A).  Past the last chunk the
@@ -310,9 +318,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto dma_k = [&](int k, int pc) {
         const int cur = pc & 1, last = p.nchunks - 1;
         if (dbg & 1) return;
-        if (k < 8) dma_piece(min(pc + 2, last) * CHUNKB + (wave * 8 + k) * FRAG, cur * PART + (wave * 8 + k) * FRAG);
-        else if (k < 12) dma_piece(min(pc + 1, last) * CHUNKB + PART + (wave * 4 + k - 8) * FRAG, 2 * PART + (cur ^ 1) * (PART / 2) + (wave * 4 + k - 8) * FRAG);
-        else dma_piece(pc * CHUNKB + PART + PART / 2 + (wave * 4 + k - 12) * FRAG, 3 * PART + cur * (PART / 2) + (wave * 4 + k - 12) * FRAG);
+        auto go = [&](int src, int dst) {
+            switch (k & 3) {
+            case 0: dma_piece4(src, dst, std::integral_constant<int, 0>{}); break;
+            case 1: dma_piece4(src, dst, std::integral_constant<int, 1>{}); break;
+            case 2: dma_piece4(src, dst, std::integral_constant<int, 2>{}); break;
+            default: dma_piece4(src, dst, std::integral_constant<int, 3>{}); break;
+            }
+        };
+        if (k < 8) go(min(pc + 2, last) * CHUNKB + (wave * 8 + (k & 4)) * FRAG, cur * PART + (wave * 8 + (k & 4)) * FRAG);
+        else if (k < 12) go(min(pc + 1, last) * CHUNKB + PART + wave * 4 * FRAG, 2 * PART + (cur ^ 1) * (PART / 2) + wave * 4 * FRAG);
+        else go(pc * CHUNKB + PART + PART / 2 + wave * 4 * FRAG, 3 * PART + cur * (PART / 2) + wave * 4 * FRAG);
     };
     auto frag_read = [&](int slot, const unsigned char *at) {
         if (dbg & 8) return;
@@ -412,12 +428,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();                                            // the last chunk's W2 k-step 1 pieces, copied by all four waves
     const int post_base = p.nchunks * CHUNKB;
     if (POST) {
-        // both W1 buffers are free: the projection's part 0 and the first quarter of part 1 go out now and land behind the last pass
-        // and the epilogue (the remaining pieces follow the per-part schedule of the projection loop)
+        // both W1 buffers are free: the projection's parts 0 and 1 go out now and land behind the last pass and the epilogue
 #pragma unroll
         for (int k = 0; k < 8; ++k) dma_piece(post_base + (wave * 8 + k) * FRAG, (wave * 8 + k) * FRAG);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) dma_piece(post_base + (p.post_parts > 1 ? PART : 0) + (wave * 8 + k) * FRAG, PART + (wave * 8 + k) * FRAG);
+        for (int k = 0; k < 8; ++k) dma_piece(post_base + (p.post_parts > 1 ? PART : 0) + (wave * 8 + k) * FRAG, PART + (wave * 8 + k) * FRAG);
     }
     frag_read(0, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2));
     frag_read(1, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2) + 2 * FRAG);
@@ -495,57 +510,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float *posr = p.post_pos + prow * p.post_ldpos + 16 * h;
         float *outr = p.post_out + rowc * p.post_ld + 16 * h;
         const float *pbr = p.post_bias + 16 * h;
-        f32x16 pm[2], px[2];
-        auto acc_init = [&](f32x16 &m, f32x16 &x, int j) {
+        f32x16 pm[2], px[2], zero16;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(pbr + 32 * j + 4 * q);
-                m[4 * q] = b[0]; m[4 * q + 1] = b[1]; m[4 * q + 2] = b[2]; m[4 * q + 3] = b[3];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = 0.f;
-        };
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
         f32x4 pos4[4];
-        auto pos_load = [&](int j) {         // tile j's row-periodic term
+        // tile j's additive term: the row-periodic pos . W^T + b for the offsets / logits columns (their bias vector is zero), the bias
+        // for the value columns.  Loaded a quarter part ahead of its use: as the accumulators' initial value it stalled every part's
+        // first MFMA on an L2 round trip.
+        auto add_load = [&](int j, bool haspos) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pos4[q] = *reinterpret_cast<const f32x4 *>(posr + 32 * j + 4 * q);
+            for (int q = 0; q < 4; ++q) pos4[q] = *reinterpret_cast<const f32x4 *>((haspos ? posr : pbr) + 32 * j + 4 * q);
         };
-        auto tile_out = [&](const f32x16 &m, const f32x16 &x, int j, int q, bool haspos) {
+        auto tile_out = [&](const f32x16 &m, const f32x16 &x, int j, int q) {
             f32x4 v = {m[4 * q] + x[4 * q] * (1.0f / 2048.0f), m[4 * q + 1] + x[4 * q + 1] * (1.0f / 2048.0f),
                        m[4 * q + 2] + x[4 * q + 2] * (1.0f / 2048.0f), m[4 * q + 3] + x[4 * q + 3] * (1.0f / 2048.0f)};
-            if (haspos) v += pos4[q];
+            v += pos4[q];
             *reinterpret_cast<f32x4 *>(outr + 32 * j + 4 * q) = v;        // unconditional (rows past M rewrite row M - 1 with its own values): the wait below counts it
         };
-        // part j (accumulator pair CUR = j & 1; PREV: 0 = no previous tile, 1 = the previous tile takes the pos term, 2 = it does not):
-        // the 8 DMA pieces issued while it runs are the rest of part j + 1 (k-steps 0..5, behind barrier j - 1 that freed its buffer)
-        // and the first two of part j + 2 (behind this part's barrier, k-steps 14, 15)
+        // part j (accumulator pair CUR = j & 1; PREV: 0 = no previous tile, 1 = the previous tile takes the pos term, 2 = it does not) reads
+        // buffer j & 3 of a ring of FOUR 32-KB buffers (the whole weight area: the chunk loop is over).  While it runs, the 8 pieces of
+        // part j + 2 go to buffer (j + 2) & 3 -- free since barrier j - 1, behind which every wave is done with part j - 2 -- so a piece has
+        // more than a whole part to land before barrier j + 1 publishes it (with two buffers and one part of lead, every part waited for
+        // its successor's pieces: 4 400 cycles per part instead of 1 536)
         auto post_part = [&](auto cur_, auto prev_, int j) {
             constexpr int CUR = decltype(cur_)::value, PREV = decltype(prev_)::value;
-            const unsigned char *w = lane_lds + CUR * PART, *wn = lane_lds + (CUR ^ 1) * PART;
+            const unsigned char *w = lane_lds + (j & 3) * PART, *wn = lane_lds + ((j + 1) & 3) * PART;
             const int last = p.post_parts - 1;
-            const int src1 = post_base + min(j + 1, last) * PART, src2 = post_base + min(j + 2, last) * PART;
+            const int src2 = post_base + min(j + 2, last) * PART, dst2 = ((j + 2) & 3) * PART;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const int sl = ks & 3, sn = (ks + 2) & 3;
                 if (ks == 14) {
-                    // the DMA pieces of the next part must have landed; the previous tile's four stores (k-steps 6, 8, 10, 12) and the four
-                    // bias loads of k-step 13 -- the youngest vector-memory operations -- need not: vmcnt retires in order
-                    if (PREV) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    // part j + 1's pieces (issued during part j - 1) must have landed; what this part issued -- its 8 pieces, the previous
+                    // tile's four additive-term loads and four stores -- are the youngest vector-memory operations and need not: vmcnt
+                    // retires in order
+                    if (PREV) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 frag_read(sn, ks < 14 ? w + (2 * ks + 4) * FRAG : wn + (2 * (ks - 14)) * FRAG);
-                mfma_a(pm[CUR], fr[sl][0], xh[ks]);
-                if (ks == 2 && PREV == 1) pos_load(j - 1);
-                if (ks == 13) acc_init(pm[CUR ^ 1], px[CUR ^ 1], min(j + 1, last));
+                if (ks == 0) pm[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xh[ks], zero16, 0, 0, 0); else mfma_a(pm[CUR], fr[sl][0], xh[ks]);
+                if (ks == 0 && PREV) add_load(j - 1, PREV == 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_a(px[CUR], fr[sl][0], xl[ks]);
-                if (ks < 6) dma_piece(src1 + (wave * 8 + 2 + ks) * FRAG, (CUR ^ 1) * PART + (wave * 8 + 2 + ks) * FRAG);
-                if (ks >= 14) dma_piece(src2 + (wave * 8 + ks - 14) * FRAG, CUR * PART + (wave * 8 + ks - 14) * FRAG);
+                if (ks == 0) px[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xl[ks], zero16, 0, 0, 0); else mfma_a(px[CUR], fr[sl][0], xl[ks]);
+                if (ks < 8) {
+                    const int s4 = src2 + (wave * 8 + (ks & 4)) * FRAG, d4 = dst2 + (wave * 8 + (ks & 4)) * FRAG;
+                    switch (ks & 3) {
+                    case 0: dma_piece4(s4, d4, std::integral_constant<int, 0>{}); break;
+                    case 1: dma_piece4(s4, d4, std::integral_constant<int, 1>{}); break;
+                    case 2: dma_piece4(s4, d4, std::integral_constant<int, 2>{}); break;
+                    default: dma_piece4(s4, d4, std::integral_constant<int, 3>{}); break;
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_a(px[CUR], fr[sl][1], xh[ks]);
-                if (PREV && ks >= 6 && ks < 14 && !(ks & 1)) tile_out(pm[CUR ^ 1], px[CUR ^ 1], j - 1, (ks - 6) >> 1, PREV == 1);
+                if (PREV && ks >= 6 && ks < 14 && !(ks & 1)) tile_out(pm[CUR ^ 1], px[CUR ^ 1], j - 1, (ks - 6) >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -556,7 +576,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                        // ... in every wave
         frag_read(0, lane_lds);
         frag_read(1, lane_lds + 2 * FRAG);
-        acc_init(pm[0], px[0], 0);
         const int npt = p.post_npos >> 5;                       // tiles 0 .. npt - 1 take the pos term
         post_part(I0{}, I0{}, 0);
         for (int j = 1; j < p.post_parts; ++j) {
@@ -566,10 +585,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         {
             const int j = p.post_parts - 1;
-            const bool hp = j < npt;
-            if (hp) pos_load(j);
+            add_load(j, j < npt);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { if (j & 1) tile_out(pm[1], px[1], j, q, hp); else tile_out(pm[0], px[0], j, q, hp); }
+            for (int q = 0; q < 4; ++q) { if (j & 1) tile_out(pm[1], px[1], j, q); else tile_out(pm[0], px[0], j, q); }
         }
     }
 }

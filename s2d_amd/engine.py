@@ -20,7 +20,18 @@ def run_step(model, optimizer, data, iteration=0, ema_momentum=None):
     accum = max(int(getattr(model, "accum_iter", 1)), 1)
     if iteration % accum == 0:
         optimizer.zero_grad()
+    last = (iteration + 1) % accum == 0
+    if last and hasattr(model, "student"):
+        # the exchange starts part by part while the backward still runs (DDP's bucketed overlap, engine/defaults.py:76-85);
+        # under accumulation only the last micro-step exchanges, as DDP's no_sync() iterations do
+        from .optim import OverlappedAllReduce, student_parts
+        ex = getattr(optimizer, "_exchange", None)
+        if ex is None:
+            ex = optimizer._exchange = OverlappedAllReduce(optimizer, student_parts(model))
+        losses = model.forward_backward(images, targets, loss_scale=1.0 / accum, grad_ready=ex.ready)
+        optimizer.step(inv_scale=ex.finish(), ema_momentum=ema_momentum)
+        return losses
     losses = model.forward_backward(images, targets, loss_scale=1.0 / accum)
-    if (iteration + 1) % accum == 0:
+    if last:
         optimizer.step(inv_scale=optimizer.allreduce_grads(), ema_momentum=ema_momentum)
     return losses

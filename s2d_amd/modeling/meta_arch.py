@@ -294,13 +294,15 @@ class KDVideoMaskFormer(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_backward(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None, loss_scale=1.0):
+    def forward_backward(self, images, gt_targets: TargetSet, coords_gt=None, coords_kd=None, kd_nmax=None, loss_scale=1.0, grad_ready=None):
         """One training iteration's device work up to the optimizer (engine/train_loop.py:709-726: forward, sum of the
         weighted losses, backward): returns the weighted loss dict of forward_losses and leaves d(sum of losses)/d(parameter)
         in .grad of every student parameter (accumulating, like autograd).  Every gradient is computed by the HIP kernels of
         s2d_amd/backward.py through explicit tapes of the student's activations; the teacher and both matchers carry no
         gradient, attention masks and sampled points are constants, as in the reference.  loss_scale multiplies the
-        gradients only (1 / ACCUM_ITER under gradient accumulation, train_loop.py:737-741)."""
+        gradients only (1 / ACCUM_ITER under gradient accumulation, train_loop.py:737-741).  grad_ready(name): called when every
+        gradient of the student's "predictor", "pixel_decoder", "backbone" has been enqueued, in that order -- the hook the
+        overlapped gradient all-reduce hangs on (optim.OverlappedAllReduce; DDP's bucket hooks in the reference)."""
         wd = self.criterion.weight_dict
         Hp, Wp = images.shape[1:3]
         kd_nmax = kd_nmax or self.num_queries
@@ -349,8 +351,14 @@ class KDVideoMaskFormer(nn.Module):
                 d_cls[NL - 1] += ops.class_loss_backward(student.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),
                                                          ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce * loss_scale, self.criterion.eos_coef)
         d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
+        if grad_ready is not None:
+            grad_ready("predictor")
         grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
+        if grad_ready is not None:
+            grad_ready("pixel_decoder")
         backbone.backward(tb, grads)
+        if grad_ready is not None:
+            grad_ready("backbone")
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
         # the activation tapes are garbage once the gradients exist; keeping them alive into the next iteration's forward
         # costs 45 GiB of peak memory at c4 (keep_tapes = True for tests that inspect them)

@@ -9,6 +9,7 @@ the value projection, the fused MSDA kernel does softmax + location arithmetic +
 projection GEMM adds the residual in its epilogue, LayerNorm follows; FFN likewise.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -147,8 +148,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout
 
-    fuse_ffn = True      # False: the two-launch FFN + separate LayerNorms also on the forward-only path (A/B measurements, tests)
-    fuse_next = True     # False: the next layer's merged projection stays its own launch
+    fuse_ffn = os.environ.get("S2D_FUSE_FFN", "1") != "0"      # False: the two-launch FFN + separate LayerNorms also on the forward-only path (A/B measurements, tests)
+    fuse_next = os.environ.get("S2D_FUSE_NEXT", "1") != "0"     # False: the next layer's merged projection stays its own launch (A/B runs)
 
     def forward(self, src, pos, shapes, tape=None, both=None, nxt=None):
         """msdeformattn.py:116-131 (post-norm).  src [N,S,C], pos [S,C].

@@ -284,8 +284,9 @@ def ffn_fusable(W1, W2):
 def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False, post=None):
     """y = LN2?( xn + drop( W2 . drop( relu( W1 . xn + b1 ) ) + b2 ) ),  xn = LN1?(x)   in one launch (csrc/ffn.hip).
     x [M, 256]; ln1 / ln2 = (gamma, beta) or None; dropout = (p, seed, site_hidden, site_out[, row0]) or None.
-    post = (Wpost [Np, 256], bias [Np], pos [S, npos] or None): also out_post[M, Np] = y . Wpost^T + bias (+ pos[row % S] on the first
-    npos columns) -- the next encoder layer's merged projection, applied while the row is in registers (needs ln1 and ln2).
+    post = (Wpost [Np, 256], bias [Np], pos [S, npos] or None): also out_post[M, Np] = y . Wpost^T + (pos[row % S] on the first npos
+    columns -- it carries their bias, `bias` is not read there -- and bias on the others): the next encoder layer's merged
+    projection, applied while the row is in registers (needs ln1 and ln2).
     -> y, (y, xn) with want_xn (requires ln1), with post additionally out_post as the last element."""
     for t in (x, W1, b1, W2, b2) + tuple(ln1 or ()) + tuple(ln2 or ()):
         _chk(t)

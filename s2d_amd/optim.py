@@ -185,6 +185,75 @@ class FullModelGradientClippingAdamW:
         return allreduce_flat(self.grad_arena, bucket_bytes)
 
 
+class OverlappedAllReduce:
+    """The gradient exchange started bucket by bucket WHILE the backward still runs, as the reference's DistributedDataParallel does
+    (engine/defaults.py:76-85: bucketed all-reduce fired from autograd hooks inside `losses.backward()`, train_loop.py:719).
+
+    The explicit backward of `forward_backward` finishes the student's parts in a fixed order -- predictor, pixel decoder, trunk --
+    and reports each (`grad_ready=self.ready`).  A part's parameters are a contiguous range of the gradient arena (parameters are
+    laid out in `model.parameters()` order: trunk | pixel decoder | predictor), so each report becomes one asynchronous SUM
+    all-reduce of that range: RCCL runs it on its own stream behind the kernels already enqueued, beside the backward of the parts
+    still to come.  `finish()` makes the compute stream wait for all of them and returns 1 / world for `step(inv_scale=...)`.
+    Backends that cannot work on device memory asynchronously (the gloo rehearsal) reduce the whole arena in `finish()`: same
+    result, no overlap."""
+
+    def __init__(self, optimizer, parts):
+        """parts: {name: iterable of parameters}; every optimized parameter must belong to exactly one part"""
+        import torch.distributed as dist
+        self.opt = optimizer
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.async_ok = self.active and (dist.get_backend() != "gloo" or not optimizer.grad_arena.is_cuda)     # gloo: host tensors only
+        index = {id(q): i for i, q in enumerate(optimizer._params)}
+        self.ranges, seen = {}, 0
+        for name, ps in parts.items():
+            idx = sorted(index[id(q)] for q in ps if id(q) in index)
+            if not idx:
+                continue
+            if idx != list(range(idx[0], idx[-1] + 1)):
+                raise ValueError(f"the parameters of part {name!r} are not contiguous in the gradient arena")
+            lo = optimizer._offs[idx[0]]
+            hi = optimizer._offs[idx[-1] + 1] if idx[-1] + 1 < len(optimizer._offs) else optimizer._total
+            self.ranges[name] = (lo, hi)
+            seen += len(idx)
+        if seen != len(optimizer._params):
+            raise ValueError("the parts do not cover the optimized parameters exactly once")
+        self.works, self.done = [], set()
+
+    def ready(self, name):
+        """every gradient of part `name` has been written (enqueued on the current stream)"""
+        if name in self.done or name not in self.ranges:
+            return
+        self.done.add(name)
+        if self.async_ok:
+            import torch.distributed as dist
+            lo, hi = self.ranges[name]
+            self.works.append(dist.all_reduce(self.opt.grad_arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        import torch.distributed as dist
+        if not self.active:
+            return 1.0
+        if not self.async_ok:
+            self.done.clear()
+            return allreduce_flat(self.opt.grad_arena)
+        for name in self.ranges:            # parts nobody reported (a caller without the hook): reduce them now
+            self.ready(name)
+        for w in self.works:
+            w.wait()
+        self.works, self.done = [], set()
+        return 1.0 / dist.get_world_size()
+
+
+def student_parts(model):
+    """the three parts of a KD / plain meta-architecture's student in the order its explicit backward finishes them"""
+    student = model.student if hasattr(model, "student") else None
+    if student is None:
+        return {"predictor": list(model.sem_seg_head.predictor.parameters()), "pixel_decoder": list(model.sem_seg_head.pixel_decoder.parameters()),
+                "backbone": list(model.backbone.parameters())}
+    return {"predictor": list(student[1].predictor.parameters()), "pixel_decoder": list(student[1].pixel_decoder.parameters()),
+            "backbone": list(student[0].parameters())}
+
+
 def allreduce_flat(flat, bucket_bytes=256 << 20):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -43,6 +43,7 @@ flops = 4.0 * M * 1024 * 256
 S = M // 16 if M % 16 == 0 else M
 Wp = ops.mark_static(torch.randn((544, 256), device=dev, generator=g) * 0.05)
 bp = torch.randn((544,), device=dev, generator=g) * 0.1
+bp[:288] = 0          # (the pos term carries the bias of the offsets / logits columns)
 pos = torch.randn((S, 288), device=dev, generator=g) * 0.5
 for p in (0.3, 0.0):
     drop = (p, 7, 1, 2) if p > 0 else None

@@ -87,7 +87,7 @@ def test_ffn_fused_vs_two_launch_form(M):
     assert torch.equal(out2, ops.ffn_fused(x, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, seed, 1, 2)))
 
 
-@pytest.mark.parametrize("M,S,p", [(200, 50, 0.0), (1000, 333, 0.3), (4097, 4097, 0.3), (128, 7, 0.0)])
+@pytest.mark.parametrize("M,S,p", [(200, 50, 0.0), (1000, 333, 0.3), (4097, 4097, 0.3), (128, 7, 0.0), (40000, 2500, 0.3)])
 def test_ffn_fused_with_next_layer_projection(oracle, M, S, p):
     """the launch that also applies the next encoder layer's merged projection (544 columns: 288 offsets / logits with the
     row-periodic pos term, 256 value columns with their bias) to its output rows: against the float64 oracle of

@@ -84,6 +84,62 @@ def test_gradient_arena_allreduce_two_ranks_gloo():
         assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
 
 
+def _overlap_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import types
+    import torch
+    import torch.distributed as dist
+    from s2d_amd.optim import OverlappedAllReduce
+    dist.init_process_group("gloo")
+    # a stand-in with the optimizer's arena bookkeeping (the real one needs device memory): 7 parameters in 3 parts, 4-aligned offsets
+    sizes = [10, 3, 8, 5, 4, 9, 2]
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot); tot += (n + 3) // 4 * 4
+    opt = types.SimpleNamespace(_params=params, _offs=offs, _total=tot, grad_arena=torch.arange(tot, dtype=torch.float32) * (rank + 1))
+    parts = {"predictor": params[5:], "pixel_decoder": params[2:5], "backbone": params[:2]}
+    ex = OverlappedAllReduce(opt, parts)
+    assert ex.ranges == {"predictor": (offs[5], tot), "pixel_decoder": (offs[2], offs[5]), "backbone": (0, offs[2])}
+    out = []
+    for it in range(2):                                    # the exchange object is reused iteration after iteration
+        opt.grad_arena.copy_(torch.arange(tot, dtype=torch.float32) * (rank + 1 + it))
+        for name in ("predictor", "pixel_decoder", "backbone"):
+            ex.ready(name)
+        out.append((ex.finish(), opt.grad_arena.clone()))
+    bad = None
+    try:
+        OverlappedAllReduce(opt, {"a": [params[0], params[2]], "b": [params[1]] + params[3:]})
+    except ValueError as e:
+        bad = str(e)
+    q.put((rank, out, tot, bad))
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_per_part_two_ranks_gloo():
+    """the exchange DDP overlaps with the backward (engine/defaults.py:76-85): one asynchronous all-reduce per part of the student as
+    its gradients complete (predictor, pixel decoder, trunk), each a contiguous range of the arena; finish() waits and returns
+    1 / world.  Same reduced arena as the one-shot exchange."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, tot, bad in got:
+        for it, (f, arena) in enumerate(out):
+            assert f == 0.5
+            assert torch.equal(arena, torch.arange(tot, dtype=torch.float32) * (3 + 2 * it))
+        assert bad and "contiguous" in bad
+
+
 def test_param_groups_follow_reference_rules():
     """Trainer.build_optimizer (train_net_video.py:134-186): one group per trainable parameter, norm / embedding weight
     decay overrides, 'backbone' matched against the MODULE name"""
