@@ -96,7 +96,7 @@ int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hip
  * i.e. `src = norm2(src + dropout3(linear2(dropout2(relu(linear1(src))))))` of MSDeformAttnTransformerEncoderLayer
  * (mask2former/modeling/pixel_decoder/msdeformattn.py:116-131), optionally with the layer's norm1 (:125) folded into the input side.
  * The F-wide hidden activation stays in registers.  x, y [M, C] fp32 (C = 256; F a multiple of 32, <= 2048); pack = the image
- * s2d_ffn_pack_f16 wrote from W1 [F, C] and W2 [C, F] (s2d_ffn_pack_words(C, F) 32-bit words; -1 = unsupported sizes).
+ * s2d_ffn_pack_f16 wrote from W1 [F, C] and W2 [C, F] (s2d_ffn_pack_words(C, F, Npost, pre) 32-bit words; -1 = unsupported sizes).
  * Dropout: p = 0 -> none; otherwise the counter-based masks of s2d_gemm_nt_dropout_f32 for (seed, site_hidden) on the [M, F] hidden
  * activation and (seed, site_out) on the [M, C] output, mask row of row 0 = row0 -- the same bits the two-launch form applies.
  * xn (optional, requires ln1_gamma): receives the normalised input.
@@ -106,13 +106,20 @@ int s2d_split_weights_f16(const float *W, int N, int K, long ldw, void *out, hip
  * their bias -- post_bias is NOT read for these columns; post_ldpos its row stride) and y[row] . Wpost[n]^T + post_bias[n] for
  * post_npos <= n < Npost, row stride post_ld -- i.e. [sampling_offsets | attention_weights | value_proj] of
  * ops/modules/ms_deform_attn.py:98-104 applied to the layer output, which is the next layer's `src`.  Wpost [Npost, C] is packed behind
- * the FFN weights by s2d_ffn_pack_f16. */
-long s2d_ffn_pack_words(int C, int F, int Npost);
-int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, void *out, hipStream_t stream);
+ * the FFN weights by s2d_ffn_pack_f16.
+ * pre_bias != NULL (requires both LayerNorms and xn): the launch also takes over what precedes norm1 in the layer -- x is then the
+ * deformable attention's sampled values [M, C] and the FFN's input row becomes
+ *     x1 = pre_res + dropout_p( Wpre . x + pre_bias )        mask (seed, site_pre)
+ * i.e. `src = src + dropout1(output_proj(samp))` (ms_deform_attn.py:124, msdeformattn.py:124-125) with pre_res the layer input [M, C];
+ * Wpre [C, C] is packed behind Wpost (s2d_ffn_pack_f16's Wpre, s2d_ffn_pack_words' pre = 1).  xn receives norm1(x1) as before. */
+long s2d_ffn_pack_words(int C, int F, int Npost, int pre);
+int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, const float *Wpre, void *out,
+                     hipStream_t stream);
 int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, const float *b1, const float *b2, const float *ln1_gamma,
                       const float *ln1_beta, const float *ln2_gamma, const float *ln2_beta, float eps, float p, uint64_t seed,
                       unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, int Npost, const float *post_bias,
-                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld, hipStream_t stream);
+                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld,
+                      const float *pre_bias, const float *pre_res, unsigned site_pre, hipStream_t stream);
 
 /* NHWC convolution as implicit GEMM: x [N,H,W,Cin] (Cin % 4 == 0), w [Cout][KH][KW][Cin],
  * y [N,Ho,Wo,Cout] = act(conv(x,w) * scale[Cout] + bias[Cout] + res).  Replaces detectron2 Conv2d+FrozenBN+ReLU

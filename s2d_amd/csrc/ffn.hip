@@ -48,6 +48,7 @@ constexpr int PART = 32 * FRAG;             // 32 KB: 16 k-steps x (hi, lo)  |  
 constexpr int CHUNKB = 2 * PART;            // image bytes per chunk of 32 hidden units
 constexpr int LDS_B1 = 2 * CHUNKB;          // byte offset of the bias copy (behind the two chunk buffers)
 constexpr int FMAX = 2048;                  // hidden width limit of the bias copy
+constexpr int LDS_PB = LDS_B1 + FMAX * 4;   // PRE: the output projection's bias (256 floats) behind it
 
 // MFMA row rho of a 32-row tile <-> unit / column 16 h + 4 g + i   (rho = 8 g + 4 h + i): a lane half's 16 accumulator registers
 // (reg = 4 g + i at rows 8 g + 4 h + i) are then the 16 consecutive units 16 h + reg
@@ -95,12 +96,13 @@ __device__ __forceinline__ void mfma_v0(f32x16 &c, const f16x8 a, const f16x8 b,
 __host__ __device__ __forceinline__ int kcol(int ks, int h) { return 32 * (ks >> 1) + 16 * h + 8 * (ks & 1); }
 
 // one thread = one lane's 16 bytes of one fragment.  Image: [F / 32 chunks x 64 fragments: W1 part | W2 k-step 0 | W2 k-step 1]
-// [npost / 32 parts x 32 fragments: the rows 32 j + perm_row(r) of Wpost, as a W1 part]
+// [npost / 32 parts x 32 fragments: the rows 32 j + perm_row(r) of Wpost, as a W1 part][npre / 32 parts: Wpre likewise]
 __global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int F,
-                                                       const float *__restrict__ Wpost, int npost, u32x4 *__restrict__ out)
+                                                       const float *__restrict__ Wpost, int npost, const float *__restrict__ Wpre, int npre,
+                                                       u32x4 *__restrict__ out)
 {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long nfrag = (long)(F / 32) * 64 + (long)(npost / 32) * 32;
+    const long nfrag = (long)(F / 32) * 64 + (long)((npost + npre) / 32) * 32;
     if (gid >= nfrag * 64) return;
     const int lane = (int)(gid & 63);
     const long fidx = gid >> 6;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float *__restrict__
         const long f2 = fidx - (long)(F / 32) * 64;
         const int frag = (int)(f2 & 31);
         lo = frag & 1;
-        src = Wpost + (32 * (f2 >> 5) + perm_row(r)) * FC + kcol(frag >> 1, h);
+        const long part = f2 >> 5;
+        src = (part < npost / 32 ? Wpost + (32 * part + perm_row(r)) * FC : Wpre + (32 * (part - npost / 32) + perm_row(r)) * FC) + kcol(frag >> 1, h);
     }
     u32x4 w;
 #pragma unroll
@@ -147,11 +150,13 @@ struct FfnParams {
     // POST: the next encoder layer's merged projection of the output row, out_post[row][n] = y . Wpost[n]^T + post_bias[n]
     // (+ post_pos[row % post_S][n] for n < post_npos: the row-periodic (pos . W^T + b) term of the sampling offsets / attention logits)
     const float *post_bias, *post_pos;
+    const float *pre_bias, *pre_res;     // PRE: out_proj bias [256]; the layer input rows [M, 256] (the attention's residual)
+    unsigned int site_pre;
     float *post_out;
     int post_parts, post_S, post_npos, post_ld, post_ldpos;
 };
 
-template <bool DROP, bool LN1, bool LN2, bool POST>
+template <bool DROP, bool LN1, bool LN2, bool POST, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_f16x3_kernel(FfnParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [W1 buf 0 | W1 buf 1 | W2 buf 0 | W2 buf 1 | b1]
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned int mrow = p.row0 + (unsigned int)rowc;                   // mask row (lanes past M replicate row M - 1 exactly: their stores of
                                                                              // the projection phase are unconditional and must carry its values)
 
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB + p.post_parts * PART, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB + (p.post_parts + (PRE ? 8 : 0)) * PART, 0x00020000);
     // a wave copies pieces wave * n .. wave * n + n - 1 of a part of 4 n pieces (n = 8: 32 KB; n = 4: one k-step of W2, 16 KB)
     auto dma_part = [&](int src_byte, int dst_byte, auto n_) {
         constexpr int n = decltype(n_)::value;
@@ -174,13 +179,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                      lane * 16, src_byte + piece * FRAG, 0, 0);
         }
     };
+    // ---- helpers shared by the phases of the launch ----
+    uint32_t rb[2][4], rt[2];           // Philox state / result of the chunk's two 8-unit mask blocks; rt: the c0 a half-done round holds back
+    f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
+                                        // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
+    const unsigned char *lane_lds = lds + lane * 16;
+    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any bit set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads
+
+    // Philox4x32-10 of mask block e, round r, in two halves (idx = 4 r + 2 e + half):
+    //   half 0: M1 * c2 -> rt = hi ^ c1 ^ k0, c1 = lo;   half 1: M0 * c0 -> c2 = hi ^ c3 ^ k1, c3 = lo, c0 = rt
+    auto philox_half = [&](int idx) {
+        const int r = idx >> 2, e = (idx >> 1) & 1;
+        if (!(idx & 1)) {
+            const uint64_t pr = (uint64_t)0xCD9E8D57u * rb[e][2];
+            rt[e] = (uint32_t)(pr >> 32) ^ rb[e][1] ^ (p.k0 + 0x9E3779B9u * (uint32_t)r);
+            rb[e][1] = (uint32_t)pr;
+        } else {
+            const uint64_t pr = (uint64_t)0xD2511F53u * rb[e][0];
+            rb[e][2] = (uint32_t)(pr >> 32) ^ rb[e][3] ^ (p.k1 + 0xBB67AE85u * (uint32_t)r);
+            rb[e][3] = (uint32_t)pr;
+            rb[e][0] = rt[e];
+        }
+    };
+    auto dma_piece = [&](int src_byte, int dst_byte) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
+    };
+    // piece `sub` (0..3) of a run of four consecutive 1-KB pieces: the instruction's immediate offset advances the source and the LDS
+    // address alike, so the four share one M0 value and one scalar offset (two scalar instructions saved per piece)
+    auto dma_piece4 = [&](int src_byte, int dst_byte, auto sub_) {
+        constexpr int SUB = decltype(sub_)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, SUB * FRAG, 0);
+    };
+    auto frag_read = [&](int slot, const unsigned char *at) {
+        if (dbg & 8) return;
+        fr[slot][0] = *reinterpret_cast<const f16x8 *>(at);
+        fr[slot][1] = *reinterpret_cast<const f16x8 *>(at + FRAG);
+    };
+
     // phase 0's weights first (they are the longest wait of the prologue), then the bias copy and the input tile
-    dma_part(0, 0, std::integral_constant<int, 8>{});                       // W1 of chunk 0
-    dma_part(PART, 2 * PART, std::integral_constant<int, 4>{});              // W2 k-step 0 of chunk 0
-    dma_part((p.nchunks > 1 ? 1 : 0) * CHUNKB, PART, std::integral_constant<int, 8>{});    // W1 of chunk 1
+    const int pre_base = p.nchunks * CHUNKB + p.post_parts * PART;           // the image: [chunks][projection parts][out_proj parts]
+    auto chunk_loop_prologue = [&](auto w1_) {
+        if (decltype(w1_)::value) dma_part(0, 0, std::integral_constant<int, 8>{});                       // W1 of chunk 0
+        dma_part(PART, 2 * PART, std::integral_constant<int, 4>{});              // W2 k-step 0 of chunk 0
+        if (decltype(w1_)::value) dma_part((p.nchunks > 1 ? 1 : 0) * CHUNKB, PART, std::integral_constant<int, 8>{});    // W1 of chunk 1
+        for (int i = tid; i < PART / 2 / 16; i += 256)            // W2 k-step 1 buffer 1: what chunk 0's (empty) pass A multiplies by zero
+            reinterpret_cast<u32x4 *>(lds + 3 * PART + PART / 2)[i] = u32x4{0u, 0u, 0u, 0u};
+    };
+    if (PRE) {                                                               // the out_proj phase walks the whole weight area first
+        dma_part(pre_base, 0, std::integral_constant<int, 8>{});
+        dma_part(pre_base + PART, PART, std::integral_constant<int, 8>{});
+    } else chunk_loop_prologue(std::true_type{});
     for (int i = tid; i < p.nchunks * 32; i += 256) reinterpret_cast<float *>(lds + LDS_B1)[i] = p.b1[i];
-    for (int i = tid; i < PART / 2 / 16; i += 256)            // W2 k-step 1 buffer 1: what chunk 0's (empty) pass A multiplies by zero
-        reinterpret_cast<u32x4 *>(lds + 3 * PART + PART / 2)[i] = u32x4{0u, 0u, 0u, 0u};
+    if (PRE) reinterpret_cast<float *>(lds + LDS_PB)[tid] = p.pre_bias[tid];
 
     // ---- input tile -> fp16 hi / lo B fragments of GEMM 1.  The row is loaded in the accumulator layout (this lane: columns
     // 32 t + 16 h + 0..15 for t = 0..7, lane ^ 32 the other halves) and parked in the output accumulators, which are idle until the
@@ -214,6 +264,106 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
                 ym[t][4 * q] = a[0]; ym[t][4 * q + 1] = a[1]; ym[t][4 * q + 2] = a[2]; ym[t][4 * q + 3] = a[3];
             }
+        if constexpr (PRE) {
+            // ---- the attention's output projection in front of everything: x1 = res + dropout1( Wo . samp + bo ), tile by tile into the
+            // parked row (ms_deform_attn.py:124 output_proj, msdeformattn.py:125 dropout1 + residual).  Same part machinery as the
+            // projection phase at the end (four-buffer ring, pieces two parts ahead, builtin MFMAs on two accumulator pairs, the
+            // previous tile's epilogue in the gaps), with the part index a compile-time constant: a tile's values go into ym[tile].
+            tile_to_frags();                                        // the sampled values as B fragments
+            const float *resr = p.pre_res + rowc * FC + 16 * h;
+            const unsigned char *pbo = lds + LDS_PB + 64 * h;      // the projection's bias, copied to LDS by the prologue
+            f32x16 qm[2], qx[2], zero16, binit;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+            f32x4 res4[2][4];                                       // the residual's tile, loaded a whole part before its use (HBM latency:
+                                                                    // nothing else runs on the SIMD to hide it)
+            uint32_t mk[2][4];                                      // the finished mask words of the previous tile
+            auto res_load = [&](int t, int b) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res4[b][q] = *reinterpret_cast<const f32x4 *>(resr + 32 * t + 4 * q);
+            };
+            auto bias_init = [&](int t) {                           // a lane's accumulator registers are 16 consecutive columns: C = bias
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(pbo + 128 * t + 16 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) binit[4 * q + e] = v[e];
+                }
+            };
+            auto pre_out = [&](const f32x16 &m, const f32x16 &x, auto t_, int q) {     // quarter q of tile T -> ym[T][4 q ..]
+                constexpr int T = decltype(t_)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = __builtin_fmaf(x[4 * q + e], 1.0f / 2048.0f, m[4 * q + e]);
+                    if (DROP) {
+                        const uint32_t w = mk[q >> 1][2 * (q & 1) + (e >> 1)];
+                        v *= ((e & 1) ? (w >> 16) : (w & 0xFFFFu)) >= p.thresh ? p.dscale : 0.f;
+                    }
+                    ym[T][4 * q + e] = v + res4[T & 1][q][e];
+                }
+            };
+            auto pre_part = [&](auto j_) {
+                constexpr int J = decltype(j_)::value, CUR = J & 1;
+                const unsigned char *w = lane_lds + (J & 3) * PART, *wn = lane_lds + ((J + 1) & 3) * PART;
+                // two parts ahead; behind the last part come the chunk loop's first weights (W1 of chunks 0 and 1 live in ring buffers 0, 1)
+                const int src2 = J + 2 < 8 ? pre_base + (J + 2) * PART : (J == 6 || p.nchunks < 2 ? 0 : CHUNKB), dst2 = ((J + 2) & 3) * PART;
+                if (DROP) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { rb[e][0] = mrow; rb[e][1] = (uint32_t)(4 * J + 2 * h + e); rb[e][2] = p.site_pre; rb[e][3] = 0u; }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int sl = ks & 3, sn = (ks + 2) & 3;
+                    if (ks == 14) {
+                        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");     // this part's 8 pieces + 4 loads may stay in flight
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (DROP) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) mk[e][c] = rb[e][c];
+                        }
+                        if (J < 7) bias_init(J + 1);
+                    }
+                    frag_read(sn, ks < 14 ? w + (2 * ks + 4) * FRAG : wn + (2 * (ks - 14)) * FRAG);
+                    if (ks == 0) qm[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xh[ks], binit, 0, 0, 0); else mfma_a(qm[CUR], fr[sl][0], xh[ks]);
+                    if (ks == 0) res_load(J, CUR);
+                    if (DROP && 3 * ks < 40) philox_half(3 * ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 0) qx[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xl[ks], zero16, 0, 0, 0); else mfma_a(qx[CUR], fr[sl][0], xl[ks]);
+                    if (ks < 8) {
+                        const int s4 = src2 + (wave * 8 + (ks & 4)) * FRAG, d4 = dst2 + (wave * 8 + (ks & 4)) * FRAG;
+                        switch (ks & 3) {
+                        case 0: dma_piece4(s4, d4, std::integral_constant<int, 0>{}); break;
+                        case 1: dma_piece4(s4, d4, std::integral_constant<int, 1>{}); break;
+                        case 2: dma_piece4(s4, d4, std::integral_constant<int, 2>{}); break;
+                        default: dma_piece4(s4, d4, std::integral_constant<int, 3>{}); break;
+                        }
+                    }
+                    if (DROP && 3 * ks + 1 < 40) philox_half(3 * ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_a(qx[CUR], fr[sl][1], xh[ks]);
+                    if (J > 0 && ks >= 6 && ks < 14 && !(ks & 1)) pre_out(qm[CUR ^ 1], qx[CUR ^ 1], std::integral_constant<int, (J > 0 ? J - 1 : 0)>{}, (ks - 6) >> 1);
+                    if (DROP && 3 * ks + 2 < 40) philox_half(3 * ks + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // parts 0, 1 (and the sampled tile's loads)
+            __syncthreads();
+            frag_read(0, lane_lds);
+            frag_read(1, lane_lds + 2 * FRAG);
+            bias_init(0);
+            pre_part(std::integral_constant<int, 0>{}); pre_part(std::integral_constant<int, 1>{});
+            pre_part(std::integral_constant<int, 2>{}); pre_part(std::integral_constant<int, 3>{});
+            pre_part(std::integral_constant<int, 4>{}); pre_part(std::integral_constant<int, 5>{});
+            pre_part(std::integral_constant<int, 6>{}); pre_part(std::integral_constant<int, 7>{});
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre_out(qm[1], qx[1], std::integral_constant<int, 7>{}, q);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                        // every wave is done with the ring: the rest of the chunk loop's start
+            chunk_loop_prologue(std::false_type{});
+        }
         if (LN1) {
             float s = 0.f;
 #pragma unroll
@@ -237,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     f32x4 v = {ym[t][4 * q], ym[t][4 * q + 1], ym[t][4 * q + 2], ym[t][4 * q + 3]};
                     v = (v - mean1) * rstd1 * ga + be;
                     ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3];
-                    if (p.Xn && rowok) *reinterpret_cast<f32x4 *>(p.Xn + row * FC + 32 * t + 16 * h + 4 * q) = v;
+                    if (PRE || (p.Xn && rowok)) *reinterpret_cast<f32x4 *>(p.Xn + rowc * FC + 32 * t + 16 * h + 4 * q) = v;     // PRE: the epilogue's residual
                 }
         }
         tile_to_frags();
@@ -257,32 +407,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     f32x16 am, ax;                      // GEMM 1 accumulators of the current chunk
     u32x4 hw[2], lw[2];                 // fp16 hi / lo B fragments (k-steps 0, 1) of the chunk's activation, as packed words
-    uint32_t rb[2][4], rt[2];           // Philox state / result of the chunk's two 8-unit mask blocks; rt: the c0 a half-done round holds back
-    f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
-                                        // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
     float hv0 = 0.f, hv1 = 0.f;         // the activation word being formed
     MfmaPrev pv;                        // the previous asm MFMA's operands (see mfma_v)
     pv.a = xh[0]; pv.b = xh[0];
     unsigned int hhi = 0u;
-    const unsigned char *lane_lds = lds + lane * 16;
-    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any bit set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads
 
     // ---- filler work, cut into units of at most ~6 vector instructions: one unit per MFMA gap (a lone wave hides ~5 beside an MFMA) ----
-    // Philox4x32-10 of mask block e, round r, in two halves (idx = 4 r + 2 e + half):
-    //   half 0: M1 * c2 -> rt = hi ^ c1 ^ k0, c1 = lo;   half 1: M0 * c0 -> c2 = hi ^ c3 ^ k1, c3 = lo, c0 = rt
-    auto philox_half = [&](int idx) {
-        const int r = idx >> 2, e = (idx >> 1) & 1;
-        if (!(idx & 1)) {
-            const uint64_t pr = (uint64_t)0xCD9E8D57u * rb[e][2];
-            rt[e] = (uint32_t)(pr >> 32) ^ rb[e][1] ^ (p.k0 + 0x9E3779B9u * (uint32_t)r);
-            rb[e][1] = (uint32_t)pr;
-        } else {
-            const uint64_t pr = (uint64_t)0xD2511F53u * rb[e][0];
-            rb[e][2] = (uint32_t)(pr >> 32) ^ rb[e][3] ^ (p.k1 + 0xBB67AE85u * (uint32_t)r);
-            rb[e][3] = (uint32_t)pr;
-            rb[e][0] = rt[e];
-        }
-    };
     // activation word q = idx >> 2 of k-step s (units 16 h + 8 s + 2 q, + 1) in four quarters: combine + ReLU, mask, fp16 hi, scaled fp16 lo
     auto hquarter = [&](int s, int idx) {
         const int q = idx >> 2, part = idx & 3, r0 = 8 * s + 2 * q;
@@ -302,15 +432,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lw[s][q] = pk_lo(hv0, hv1, hhi);
         }
     };
-    auto dma_piece = [&](int src_byte, int dst_byte) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
-    };
-    // piece `sub` (0..3) of a run of four consecutive 1-KB pieces: the instruction's immediate offset advances the source and the LDS
-    // address alike, so the four share one M0 value and one scalar offset (two scalar instructions saved per piece)
-    auto dma_piece4 = [&](int src_byte, int dst_byte, auto sub_) {
-        constexpr int SUB = decltype(sub_)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, SUB * FRAG, 0);
-    };
     // the 16 pieces a wave copies per chunk, all behind the chunk's barrier (which frees their destinations):
     //   k 0..7  W1 of chunk pc + 2 -> W1 buffer pc & 1 (GEMM 1 of chunk pc has read it);  k 8..11  W2 k-step 0 of chunk pc + 1 -> S0 buffer
     //   (pc + 1) & 1;  k 12..15  W2 k-step 1 of chunk pc -> S1 buffer pc & 1 (read by the next chunk's pass A).  Past the last chunk the
@@ -329,11 +450,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (k < 8) go(min(pc + 2, last) * CHUNKB + (wave * 8 + (k & 4)) * FRAG, cur * PART + (wave * 8 + (k & 4)) * FRAG);
         else if (k < 12) go(min(pc + 1, last) * CHUNKB + PART + wave * 4 * FRAG, 2 * PART + (cur ^ 1) * (PART / 2) + wave * 4 * FRAG);
         else go(pc * CHUNKB + PART + PART / 2 + wave * 4 * FRAG, 3 * PART + cur * (PART / 2) + wave * 4 * FRAG);
-    };
-    auto frag_read = [&](int slot, const unsigned char *at) {
-        if (dbg & 8) return;
-        fr[slot][0] = *reinterpret_cast<const f16x8 *>(at);
-        fr[slot][1] = *reinterpret_cast<const f16x8 *>(at + FRAG);
     };
     auto bias_read = [&](int pc) {      // am := b1 of chunk pc's units 16 h + 0..15 (the accumulator's initial value)
         const float *bp = reinterpret_cast<const float *>(lds + LDS_B1) + 32 * pc + 16 * h;
@@ -452,8 +568,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 x = *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
-            if (LN1) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>((PRE ? p.Xn + rowc * FC + 16 * h : xr) + 32 * t + 4 * q);     // PRE: the normalised x1 this lane stored
+            if (LN1 && !PRE) {
                 const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.g1 + 32 * t + 16 * h + 4 * q), be = *reinterpret_cast<const f32x4 *>(p.be1 + 32 * t + 16 * h + 4 * q);
                 x = (x - mean1) * rstd1 * ga + be;
             }
@@ -596,17 +712,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" {
 
-long s2d_ffn_pack_words(int C, int F, int Npost)
+long s2d_ffn_pack_words(int C, int F, int Npost, int pre)
 {
-    if (C != FC || F <= 0 || F % 32 || F > FMAX || Npost < 0 || Npost % 32 || Npost > 4096) return -1;
-    return (long)(F / 32) * (CHUNKB / 4) + (long)(Npost / 32) * (PART / 4);
+    if (C != FC || F <= 0 || F % 32 || F > FMAX || Npost < 0 || Npost % 32 || Npost > 4096 || (pre != 0 && pre != 1)) return -1;
+    return (long)(F / 32) * (CHUNKB / 4) + (long)(Npost / 32 + (pre ? FC / 32 : 0)) * (PART / 4);
 }
 
-int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, void *out, hipStream_t stream)
+int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float *Wpost, int Npost, const float *Wpre, void *out,
+                     hipStream_t stream)
 {
-    if (s2d_ffn_pack_words(C, F, Npost) < 0 || !W1 || !W2 || !out || (Npost > 0 && !Wpost)) return S2D_ERR_ARG;
-    const long n = ((long)(F / 32) * 64 + (long)(Npost / 32) * 32) * 64;
-    hipLaunchKernelGGL(ffn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, W1, W2, F, Wpost, Npost, reinterpret_cast<u32x4 *>(out));
+    if (s2d_ffn_pack_words(C, F, Npost, Wpre != nullptr) < 0 || !W1 || !W2 || !out || (Npost > 0 && !Wpost)) return S2D_ERR_ARG;
+    const int npre = Wpre ? FC : 0;
+    const long n = ((long)(F / 32) * 64 + (long)((Npost + npre) / 32) * 32) * 64;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, W1, W2, F, Wpost, Npost, Wpre, npre,
+                       reinterpret_cast<u32x4 *>(out));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -614,12 +733,14 @@ int s2d_ffn_pack_f16(const float *W1, const float *W2, int C, int F, const float
 int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, const float *b1, const float *b2, const float *ln1_gamma,
                       const float *ln1_beta, const float *ln2_gamma, const float *ln2_beta, float eps, float p, uint64_t seed,
                       unsigned site_hidden, unsigned site_out, unsigned row0, float *xn, float *y, int Npost, const float *post_bias,
-                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld, hipStream_t stream)
+                      const float *post_pos, int post_S, int post_npos, long post_ldpos, float *post_out, long post_ld,
+                      const float *pre_bias, const float *pre_res, unsigned site_pre, hipStream_t stream)
 {
-    if (s2d_ffn_pack_words(C, F, Npost) < 0 || !x || !pack || !b1 || !b2 || !y || M <= 0 || M > 0x7FFFFF00L) return S2D_ERR_ARG;
+    if (s2d_ffn_pack_words(C, F, Npost, pre_bias != nullptr) < 0 || !x || !pack || !b1 || !b2 || !y || M <= 0 || M > 0x7FFFFF00L) return S2D_ERR_ARG;
     if ((ln1_gamma == nullptr) != (ln1_beta == nullptr) || (ln2_gamma == nullptr) != (ln2_beta == nullptr)) return S2D_ERR_ARG;
     if (xn && !ln1_gamma) return S2D_ERR_ARG;
     if (!(p >= 0.f && p < 1.f)) return S2D_ERR_ARG;
+    if (pre_bias && (!pre_res || !xn || !ln1_gamma || !ln2_gamma)) return S2D_ERR_ARG;     // the out_proj phase exists for the encoder layer's form only
     if (Npost > 0 && (!post_bias || !post_out || post_ld < Npost || (post_ld & 3) || post_npos < 0 || post_npos > Npost || (post_npos & 31) ||
                       (post_npos > 0 && (!post_pos || post_S <= 0 || post_ldpos < post_npos || (post_ldpos & 3))) || M * post_ld > 0x7FFFFFFFL * 4))
         return S2D_ERR_ARG;
@@ -631,19 +752,22 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     q.dscale = 1.f / (1.f - p);
     q.k0 = (unsigned int)seed; q.k1 = (unsigned int)(seed >> 32); q.site_h = site_hidden; q.site_o = site_out; q.row0 = row0;
     q.post_bias = post_bias; q.post_pos = post_npos > 0 ? post_pos : post_bias; q.post_out = post_out; q.post_parts = Npost / 32;
+    q.pre_bias = pre_bias; q.pre_res = pre_res; q.site_pre = site_pre;
     q.post_S = post_npos > 0 ? post_S : 1; q.post_npos = post_npos; q.post_ld = (int)post_ld; q.post_ldpos = (int)post_ldpos;
-    const int smem = LDS_B1 + FMAX * 4;
+    const int smem = LDS_PB + FC * 4;
     const dim3 grid(cdiv(M, 128)), block(256);
-    static S2dDevOnce attr[16];
-    const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr, post = Npost > 0;
+    static S2dDevOnce attr[32];
+    const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr, post = Npost > 0, pre = pre_bias != nullptr;
     const void *fn = nullptr;
-#define S2D_FFN_CASE(D, A, B, P) if (drop == D && ln1 == A && ln2 == B && post == P) fn = (const void *)ffn_f16x3_kernel<D, A, B, P>;
-    S2D_FFN_CASE(false, false, false, false) S2D_FFN_CASE(false, false, true, false) S2D_FFN_CASE(false, true, true, false)
-    S2D_FFN_CASE(true, false, false, false) S2D_FFN_CASE(true, false, true, false) S2D_FFN_CASE(true, true, true, false)
-    S2D_FFN_CASE(false, true, true, true) S2D_FFN_CASE(true, true, true, true)
+#define S2D_FFN_CASE(D, A, B, P, R) if (drop == D && ln1 == A && ln2 == B && post == P && pre == R) fn = (const void *)ffn_f16x3_kernel<D, A, B, P, R>;
+    S2D_FFN_CASE(false, false, false, false, false) S2D_FFN_CASE(false, false, true, false, false) S2D_FFN_CASE(false, true, true, false, false)
+    S2D_FFN_CASE(true, false, false, false, false) S2D_FFN_CASE(true, false, true, false, false) S2D_FFN_CASE(true, true, true, false, false)
+    S2D_FFN_CASE(false, true, true, true, false) S2D_FFN_CASE(true, true, true, true, false)
+    S2D_FFN_CASE(false, true, true, false, true) S2D_FFN_CASE(true, true, true, false, true)
+    S2D_FFN_CASE(false, true, true, true, true) S2D_FFN_CASE(true, true, true, true, true)
 #undef S2D_FFN_CASE
     if (!fn) return S2D_ERR_ARG;          // combinations without a caller are not instantiated
-    const int slot = (post ? 8 : 0) + (drop ? 4 : 0) + (ln1 ? 2 : 0) + (ln2 ? 1 : 0);
+    const int slot = (pre ? 16 : 0) + (post ? 8 : 0) + (drop ? 4 : 0) + (ln1 ? 2 : 0) + (ln2 ? 1 : 0);
     if (!attr[slot].done()) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return S2D_ERR_LAUNCH;
         attr[slot].mark();

@@ -82,6 +82,8 @@ class MSDeformAttn(nn.Module):
             both = ops.gemm_nt(src.view(-1, C), w_all, bias=b_all, res=pos_oa, res_rows=S, res_cols=n_oa)
         both = both.view(N, S, n_oa + C)          # (given: the previous layer's FFN launch already projected its output rows)
         samp = ops.msda_fused_forward(both[..., n_oa:], shapes, both[..., :n_oa], self.n_heads, self.n_points)
+        if res is None:                           # the caller applies output_proj + dropout1 + residual itself (the fused FFN launch)
+            return samp
         out = ops.gemm_nt(samp.view(-1, C), self.output_proj.weight, bias=self.output_proj.bias, res=res.view(-1, C), dropout=dropout)
         if tape is not None:
             tape.append((self, src, pos, shapes, both, samp, dropout))
@@ -149,6 +151,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.dropout_p = dropout
 
     fuse_ffn = os.environ.get("S2D_FUSE_FFN", "1") != "0"      # False: the two-launch FFN + separate LayerNorms also on the forward-only path (A/B measurements, tests)
+    fuse_pre = os.environ.get("S2D_FUSE_PRE", "1") != "0"       # False: output_proj + dropout1 + residual stay the attention's own GEMM launch (A/B runs)
     fuse_next = os.environ.get("S2D_FUSE_NEXT", "1") != "0"     # False: the next layer's merged projection stays its own launch (A/B runs)
 
     def forward(self, src, pos, shapes, tape=None, both=None, nxt=None):
@@ -161,8 +164,16 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         seed = ops.next_dropout_seed() if p > 0.0 else 0
         d1, d2, d3 = ((p, seed, 0), (p, seed, 1), (p, seed, 2)) if p > 0.0 else (None, None, None)
         sub = [] if tape is not None else None
-        x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1, both=both)
-        if tape is None and self.fuse_ffn and ops.ffn_fusable(self.linear1.weight, self.linear2.weight):
+        fused = tape is None and self.fuse_ffn and ops.ffn_fusable(self.linear1.weight, self.linear2.weight)
+        pre = None
+        if fused and self.fuse_pre:
+            # ... and the attention's output projection, dropout1 and residual in front of norm1 too: the launch reads the sampled values
+            samp = self.self_attn.forward_fused(src, pos, shapes, res=None, both=both)
+            pre = (self.self_attn.output_proj.weight, self.self_attn.output_proj.bias, src.view(-1, C), 0)
+            x1 = samp
+        else:
+            x1 = self.self_attn.forward_fused(src, pos, shapes, res=src, tape=sub, dropout=d1, both=both)
+        if fused:
             # forward / loss path (nothing kept for a backward): norm1, the whole FFN with both masks, the residual and norm2 in ONE
             # launch (csrc/ffn.hip) -- the 1024-wide hidden activation never reaches memory.  Same masks as the taped path below.
             # nxt (the next layer's attention module): its merged projection of this layer's output rows rides in the same launch;
@@ -170,7 +181,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             out = ops.ffn_fused(x1.view(-1, C), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                                 ln1=(self.norm1.weight, self.norm1.bias), ln2=(self.norm2.weight, self.norm2.bias),
                                 dropout=(p, seed, 1, 2) if p > 0.0 else None, eps=self.norm1.eps,
-                                post=nxt.projection(pos) if nxt is not None else None)
+                                post=nxt.projection(pos) if nxt is not None else None, pre=pre)
             return (out[0].view(N, S, C), out[1]) if nxt is not None else out.view(N, S, C)
         s1 = ops.layernorm(x1, self.norm1.weight, self.norm1.bias)
         h = ops.gemm_nt(s1.view(-1, C), self.linear1.weight, bias=self.linear1.bias, relu=True, dropout=d2)

@@ -254,20 +254,20 @@ def _owner(t):
     return t._base if t._base is not None else t
 
 
-def _ffn_pack(W1, W2, Wpost=None):
+def _ffn_pack(W1, W2, Wpost=None, Wpre=None):
     """cached MFMA-fragment image of an FFN's two weight matrices (+ the projection applied behind it), s2d_ffn_pack_f16; rebuilt when
     an owner changes (parameter version; packed copies are replaced by their module, which changes the key)"""
     F, C = W1.shape
     Np = 0 if Wpost is None else Wpost.shape[0]
-    ts = (W1, W2) + (() if Wpost is None else (Wpost,))
-    key = tuple(t.data_ptr() for t in ts) + (F, Np)
+    ts = (W1, W2) + (() if Wpost is None else (Wpost,)) + (() if Wpre is None else (Wpre,))
+    key = tuple(t.data_ptr() for t in ts) + (F, Np, Wpre is not None)
     owners = [_owner(t) for t in ts]
     ver = tuple(o._version + getattr(o, "_s2d_version", 0) for o in owners)
     ent = _FFN_PACK.get(key)
     if ent is None or ent[1] != ver or any(r() is not o for r, o in zip(ent[2], owners)):
         same = ent is not None and all(r() is o for r, o in zip(ent[2], owners))
-        img = ent[0] if same else torch.empty((lib().call("s2d_ffn_pack_words", C, F, Np),), device=W1.device, dtype=torch.int32)
-        lib().call("s2d_ffn_pack_f16", W1, W2, C, F, Wpost, Np, img, _stream())
+        img = ent[0] if same else torch.empty((lib().call("s2d_ffn_pack_words", C, F, Np, int(Wpre is not None)),), device=W1.device, dtype=torch.int32)
+        lib().call("s2d_ffn_pack_f16", W1, W2, C, F, Wpost, Np, Wpre, img, _stream())
         if not same and len(_FFN_PACK) >= 64:
             for k in [k for k, e in _FFN_PACK.items() if any(r() is None for r in e[2])]:
                 del _FFN_PACK[k]
@@ -278,15 +278,17 @@ def _ffn_pack(W1, W2, Wpost=None):
 def ffn_fusable(W1, W2):
     """the one-launch FFN exists for the split-fp16 arithmetic, model width 256 and hidden widths that are multiples of 32 (<= 2048)"""
     return (_MODE == "f16x3" and not amp_active() and W1.dim() == 2 and W1.shape[1] == 256 and tuple(W2.shape) == (256, W1.shape[0])
-            and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0]), 0) > 0)
+            and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0]), 0, 0) > 0)
 
 
-def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False, post=None):
+def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False, post=None, pre=None):
     """y = LN2?( xn + drop( W2 . drop( relu( W1 . xn + b1 ) ) + b2 ) ),  xn = LN1?(x)   in one launch (csrc/ffn.hip).
     x [M, 256]; ln1 / ln2 = (gamma, beta) or None; dropout = (p, seed, site_hidden, site_out[, row0]) or None.
     post = (Wpost [Np, 256], bias [Np], pos [S, npos] or None): also out_post[M, Np] = y . Wpost^T + (pos[row % S] on the first npos
     columns -- it carries their bias, `bias` is not read there -- and bias on the others): the next encoder layer's merged
     projection, applied while the row is in registers (needs ln1 and ln2).
+    pre = (Wpre [256, 256], bias [256], res [M, 256], site): x is the deformable attention's sampled values and the FFN input becomes
+    res + drop( Wpre . x + bias ) (mask site `site` of the same seed): the attention's output projection, dropout1 and residual.
     -> y, (y, xn) with want_xn (requires ln1), with post additionally out_post as the last element."""
     for t in (x, W1, b1, W2, b2) + tuple(ln1 or ()) + tuple(ln2 or ()):
         _chk(t)
@@ -294,7 +296,7 @@ def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, wan
     F = W1.shape[0]
     assert ffn_fusable(W1, W2) and C == 256 and (not want_xn or ln1 is not None)
     y = torch.empty_like(x)
-    xn = torch.empty_like(x) if want_xn else None
+    xn = torch.empty_like(x) if (want_xn or pre is not None) else None
     p, seed, site_h, site_o, row0 = 0.0, 0, 0, 0, 0
     if dropout is not None and dropout[0] > 0.0:
         p, seed, site_h, site_o = dropout[:4]
@@ -314,10 +316,20 @@ def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, wan
             S, npos = pp.shape
             ldpos = pp.stride(0)
         out_post = torch.empty((M, Np), device=x.device, dtype=torch.float32)
+    Wq = qb = qres = None
+    site_pre = 0
+    if pre is not None:
+        Wq, qb, qres, site_pre = pre
+        assert ln1 is not None and ln2 is not None and tuple(Wq.shape) == (C, C) and qres.shape == x.shape
+        for t in (Wq, qb, qres):
+            _chk(t)
+    Nq = C if pre is not None else 0
     # counted as its contractions; bytes: input, output(s), weights once
-    with _Timed(4.0 * M * F * C + 2.0 * M * Np * C, ("ffn", 1, M, F + Np // 2, C, 4.0 * (2 * M * C + M * Np + 2 * F * C + Np * C))):
-        lib().call("s2d_ffn_fused_f32", x, M, C, F, _ffn_pack(W1, W2, Wp), b1, b2, g1, be1, g2, be2, float(eps), float(p),
-                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site_h), int(site_o), int(row0), xn, y, Np, pb, pp, S, npos, ldpos, out_post, Np, _stream())
+    with _Timed(4.0 * M * F * C + 2.0 * M * (Np + Nq) * C,
+                ("ffn", 1, M, F + (Np + Nq) // 2, C, 4.0 * ((2 + (pre is not None)) * M * C + M * Np + 2 * F * C + (Np + Nq) * C))):
+        lib().call("s2d_ffn_fused_f32", x, M, C, F, _ffn_pack(W1, W2, Wp, Wq), b1, b2, g1, be1, g2, be2, float(eps), float(p),
+                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site_h), int(site_o), int(row0), xn, y, Np, pb, pp, S, npos, ldpos, out_post, Np,
+                   qb, qres, int(site_pre), _stream())
     res = (y,) + ((xn,) if want_xn else ()) + ((out_post,) if post is not None else ())
     return res if len(res) > 1 else y
 

@@ -63,3 +63,17 @@ for p in (0.3, 0.0):
           f"{tf + tp:.3f}) | max rel diff of the projection {float((outp - refp).abs().max() / refp.abs().max()):.2e}", flush=True)
     print(f"p={p}: two launches + 2 LN {t2:.3f} ms | fused LN1+FFN+LN2 {tf:.3f} ms ({flops / tf / 1e9:.0f} TFLOP/s alg.) | "
           f"fused FFN+LN2 {tf2:.3f} | fused FFN {tf0:.3f} | max rel diff {err:.2e}", flush=True)
+    # the attention's output projection + dropout1 + residual in front
+    Wo = torch.nn.Parameter(torch.randn((256, 256), device=dev, generator=g) * 0.07)
+    bo = torch.randn((256,), device=dev, generator=g) * 0.1
+    samp = torch.randn((M, 256), device=dev, generator=g)
+    d1 = (p, 7, 0) if p > 0 else None
+    to = timeit(lambda: ops.gemm_nt(samp, Wo, bias=bo, res=x, dropout=d1))
+    x1 = ops.gemm_nt(samp, Wo, bias=bo, res=x, dropout=d1)
+    refq = ops.ffn_fused(x1, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, post=(Wp, bp, pos))
+    tq = timeit(lambda: ops.ffn_fused(samp, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, pre=(Wo, bo, x, 0)))
+    tqp = timeit(lambda: ops.ffn_fused(samp, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, post=(Wp, bp, pos), pre=(Wo, bo, x, 0)))
+    q = ops.ffn_fused(samp, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=drop, post=(Wp, bp, pos), pre=(Wo, bo, x, 0))
+    print(f"p={p}: output_proj as its own launch {to:.3f} ms | out_proj+LN1+FFN+LN2 {tq:.3f} ms (vs {to + tf:.3f}) | with the projection too {tqp:.3f} ms "
+          f"(vs {to + tfp:.3f}) | max rel diff {float((q[0] - refq[0]).abs().max() / refq[0].abs().max()):.2e} / "
+          f"{float((q[-1] - refq[1]).abs().max() / refq[1].abs().max()):.2e}", flush=True)

@@ -117,6 +117,53 @@ def test_ffn_fused_with_next_layer_projection(oracle, M, S, p):
     assert torch.allclose(out, two, rtol=0, atol=3e-6 * float(two.abs().max()))
 
 
+@pytest.mark.parametrize("M,S,p,post", [(200, 50, 0.0, False), (1000, 333, 0.3, True), (4097, 4097, 0.3, False), (128, 7, 0.0, True),
+                                        (1, 1, 0.3, True), (40000, 2500, 0.3, True)])
+def test_ffn_fused_with_attention_output_projection(oracle, M, S, p, post):
+    """the launch that starts from the deformable attention's sampled values: x1 = res + dropout1(output_proj(samp)) (mask site 0;
+    ms_deform_attn.py:124, msdeformattn.py:124-125), then norm1, the FFN, norm2 (and optionally the next layer's projection) --
+    against the float64 oracle of the whole chain and against the launches it replaces"""
+    from s2d_amd import ops
+    F = 1024
+    W1, b1, W2, b2, g1, be1, g2, be2 = _params(F, 41)
+    samp = synth.randn(42, 1, (M, 256)) * 1.2
+    res = synth.randn(42, 2, (M, 256)) * 1.5
+    Wo = synth.randn(43, 1, (256, 256)) * 0.07
+    bo = synth.randn(43, 2, (256,)) * 0.1
+    seed = 0x0FEDCBA987654321
+    drop = (p, seed, 1, 2) if p > 0 else None
+    a = samp.astype(np.float64) @ Wo.astype(np.float64).T + bo
+    if p > 0:
+        a = a * oracle.dropout_multipliers(M, 256, p, seed, 0)
+    x1 = res + a
+    ref, refn = _oracle_ffn(oracle, x1, W1, b1, W2, b2, (g1, be1), (g2, be2), drop)
+    W1d, W2d, Wod = torch.nn.Parameter(_dev(W1)), torch.nn.Parameter(_dev(W2)), torch.nn.Parameter(_dev(Wo))
+    kw = dict(ln1=(_dev(g1), _dev(be1)), ln2=(_dev(g2), _dev(be2)), dropout=drop)
+    wargs = (W1d, _dev(b1), W2d, _dev(b2))
+    pre = (Wod, _dev(bo), _dev(res), 0)
+    pk = {}
+    if post:
+        Wp = synth.randn(44, 1, (544, 256)) * 0.05
+        bp = np.concatenate([np.zeros(288, np.float32), synth.randn(44, 2, (256,)) * 0.1]).astype(np.float32)
+        pos = synth.randn(44, 3, (S, 288)) * 0.5
+        pk = dict(post=(ops.mark_static(_dev(Wp)), _dev(bp), _dev(pos)))
+    out = ops.ffn_fused(_dev(samp), *wargs, pre=pre, want_xn=True, **pk, **kw)
+    y, xn = out[0], out[1]
+    np.testing.assert_allclose(xn.cpu().numpy(), refn, rtol=0, atol=5e-6 * np.abs(refn).max())
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    if post:
+        refp = ref @ Wp.astype(np.float64).T + bp
+        refp[:, :288] += pos[np.arange(M) % S]
+        np.testing.assert_allclose(out[2].cpu().numpy(), refp, rtol=0, atol=2e-5 * np.abs(refp).max())
+    # the launches it replaces: the projection GEMM with dropout1 + residual in its epilogue, then the launch without the phase
+    x1d = ops.gemm_nt(_dev(samp), Wod, bias=_dev(bo), res=_dev(res), dropout=(p, seed, 0) if p > 0 else None)
+    two = ops.ffn_fused(x1d, *wargs, **pk, **kw)
+    two_y = two[0] if post else two
+    assert torch.allclose(y, two_y, rtol=0, atol=5e-6 * float(two_y.abs().max()))
+    again = ops.ffn_fused(_dev(samp), *wargs, pre=pre, want_xn=True, **pk, **kw)
+    assert all(torch.equal(u, v) for u, v in zip(out, again))              # run to run: same bits
+
+
 def test_encoder_forward_with_and_without_fused_projection():
     """the pixel decoder's encoder stack, forward-only path: fused FFN launches that carry the next layer's projection against the
     stack with every projection as its own launch and against the fully unfused stack (same dropout masks: same seeds)"""
@@ -136,11 +183,11 @@ def test_encoder_forward_with_and_without_fused_projection():
     pos = torch.randn((S, 256), generator=g).to(DEV)
     shp = torch.tensor(shapes, dtype=torch.int64)
 
-    def run(fuse_ffn, fuse_next):
+    def run(fuse_ffn, fuse_next, fuse_pre=False):
         ops._DROP_CALLS[0] = 1000                      # same Philox keys in every arrangement
         src, both = src0, None
         for i, l in enumerate(layers):
-            l.fuse_ffn, l.fuse_next = fuse_ffn, fuse_next
+            l.fuse_ffn, l.fuse_next, l.fuse_pre = fuse_ffn, fuse_next, fuse_pre
             nxt = layers[i + 1].self_attn if (fuse_ffn and fuse_next and i + 1 < len(layers)) else None
             out = l(src, pos, shp, None, both=both, nxt=nxt)
             src, both = out if nxt is not None else (out, None)
@@ -149,15 +196,19 @@ def test_encoder_forward_with_and_without_fused_projection():
     a, b, c = run(True, True), run(True, False), run(False, False)
     sc = float(c.abs().max())
     assert float((a - b).abs().max()) < 5e-6 * sc and float((a - c).abs().max()) < 2e-5 * sc
+    d, e = run(True, True, True), run(True, False, True)          # ... and with the attention's output projection in the launch as well
+    assert float((d - a).abs().max()) < 1e-5 * sc and float((e - a).abs().max()) < 1e-5 * sc
     for l in layers:
-        l.fuse_ffn = l.fuse_next = True
+        l.fuse_ffn = l.fuse_next = l.fuse_pre = True
 
 
 def test_ffn_fused_rejects_unsupported_sizes():
     from s2d_amd._lib import lib
-    assert lib().call("s2d_ffn_pack_words", 128, 1024, 0) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 1000, 0) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 4096, 0) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 1024, 100) == -1
-    assert lib().call("s2d_ffn_pack_words", 256, 1024, 0) == 32 * 16384
-    assert lib().call("s2d_ffn_pack_words", 256, 1024, 544) == 32 * 16384 + 17 * 8192
+    assert lib().call("s2d_ffn_pack_words", 128, 1024, 0, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1000, 0, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 4096, 0, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 100, 0) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 0, 2) == -1
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 0, 0) == 32 * 16384
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 544, 0) == 32 * 16384 + 17 * 8192
+    assert lib().call("s2d_ffn_pack_words", 256, 1024, 544, 1) == 32 * 16384 + 25 * 8192
