@@ -262,9 +262,15 @@ constexpr int ROWS = 2 * SPANMAX + 3;   // LDS rows of one staged block: slack, 
 // Q = 100 pads to 112 rows instead of 128 -- the sigmoid / softplus work per (query, point) is what bounds the kernel -- and a
 // workgroup brings 7 waves instead of 4 to hide its LDS latency.  Lane (query l & 15, point group l >> 4) evaluates points
 // 8 (l >> 4) .. + 7 of a 32-point batch: the A fragment of one MFMA over the whole batch; targets in one or two 16-column tiles.
-template <bool Q16>
+// MODE 2 (96 < Q <= 112, the shipped Q = 100): waves 0..2 take 32-query tiles, wave 3 the queries 96..111 as ONE 16-row tile -- half
+// the per-lane sampling work of a 32-row tile whose rows 100..127 are padding -- and, having time to spare, also both tap-table setups
+// of the batch two ahead (lanes 0..31 the logit-map side, lanes 32..63 the target side), which in the other modes make waves 0 and 1
+// the ones every barrier waits for.  Per batch and lane: waves 0..2 16 samples + the target tile, wave 3 8 samples + target tile +
+// setups.  Same sums in the same order per (query, target): a query's row of the contraction does not depend on its tile shape.
+template <int MODE>
 __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
 {
+    constexpr bool Q16 = MODE == 1;
     constexpr int TN = 32, SLOTS = 8, SPT = SB / SLOTS;     // 4 samples per thread on the target side
     constexpr int TROW = 20;                               // words per target row: 16 data (32 fp16) + 4 pad
     // The points arrive sorted by the logit-map cell they fall in (cell_key_kernel + radix sort), so the 32 points of a
@@ -293,7 +299,8 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     const int b = prob % p.B;
     const int N = min(p.tgt_count[b], p.Nmax);
     if (N == 0 || N > 32) return;                           // N > 32: matcher_cost_kernel<4>
-    const int q = Q16 ? wv * 16 + l16 : wv * 32 + l32;
+    const bool w16 = Q16 || (MODE == 2 && wv == 3);        // this wave works on a 16-query tile (wave-uniform)
+    const int q = Q16 ? wv * 16 + l16 : (w16 ? 96 + l16 : wv * 32 + l32);
     // Rows q >= Q and target columns >= N are computed on clamped (valid) data and never read by the finalize kernel:
     // a row of the contraction depends on its own query only, a column on its own target only.  All global accesses are
     // buffer loads with 32-bit byte offsets.
@@ -312,7 +319,8 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     const unsigned int toff = (unsigned int)((long)(tn < N ? tn : 0) * tplane);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     // tap setup: lanes 0..31 of wave 0 do the logit-map side of sample l32, lanes 0..31 of wave 1 the target side
-    const bool setq = tid < SB, sett = tid >= 64 && tid < 64 + SB;
+    constexpr int SETW = MODE == 2 ? 3 : 0;
+    const bool setq = wv == SETW && lane < SB, sett = MODE == 2 ? (wv == 3 && lane >= 32) : (tid >= 64 && tid < 64 + SB);
     const int l4 = p.ldq >> 2;
 
     f32x16 aAm, aAx, aDm, aDx;
@@ -327,7 +335,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     // out-of-image corners (zero padding): the offset is clamped to a valid element and the weight zeroed, so every
     // access is unconditional
     auto setup = [&](int buf, float u, float v, bool tail) {
-        if (tid < 64) {                                     // wave 0: lanes 0..31 hold a sample each, 32..63 are neutral
+        if (wv == SETW) {                                   // the setup wave: lanes 0..31 hold a sample each, 32..63 are neutral
             const Bil a = bil_setup(u, v, p.hm, p.wm);
             const float fx = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f, fy = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
             const int cx = min(max((int)floorf(fx), 0), p.wm - 1), cy = min(max((int)floorf(fy), 0), p.hm - 1);
@@ -372,9 +380,10 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
                 }
                 *reinterpret_cast<i32x4 *>(bqi[buf][l32]) = o;
                 *reinterpret_cast<f32x4 *>(bqw[buf][l32]) = w;
-                if (tid == 0) { bmeta[buf][0] = cmin; bmeta[buf][1] = span; bmeta[buf][2] = staged ? 1 : 0; }
+                if (lane == 0) { bmeta[buf][0] = cmin; bmeta[buf][1] = span; bmeta[buf][2] = staged ? 1 : 0; }
             }
-        } else if (sett) {
+        }
+        if (sett) {
             const Bil d = bil_setup(u, v, p.H, p.W);
             const i32x4 o = {max(d.i00, 0), max(d.i01, 0), max(d.i10, 0), max(d.i11, 0)};
             const f32x4 w = {(d.i00 < 0 || tail) ? 0.f : d.w00, (d.i01 < 0 || tail) ? 0.f : d.w01,
@@ -388,7 +397,9 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     auto rows_dma = [&](int tb, int buf) {
         const int cmin = bmeta[tb][0], span = bmeta[tb][1];
         if (!bmeta[tb][2] || wv >= 4) return;
-        const int c4 = lane & 31;
+        // MODE 2: the row's last 16 floats (padding: Q <= 112) receive a second copy of queries 96..111 -- the 16-query wave's odd
+        // point groups read that copy, so the two groups of a 32-lane LDS access fall on banks 0..15 and 16..31
+        const int c4 = (MODE == 2 && (lane & 31) >= 28) ? (lane & 31) - 4 : (lane & 31);
 #pragma unroll
         for (int r = 0; r < SPANMAX / 4; ++r) {
             const int rp = wv * (SPANMAX / 4) + r;           // row pair 0 .. SPANMAX-1
@@ -462,7 +473,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         rows_dma(r1, cur ^ 1);                              // batch i+1's logit rows -> rows [cur^1] (last read before the previous barrier)
         // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
         const bool staged_now = bmeta[r0][2] != 0;
-        const float *rb = rowbuf + (long)cur * ROWS * 128 + qr;
+        const float *rb = rowbuf + (long)cur * ROWS * 128 + ((MODE == 2 && w16) ? 96 + l16 + 16 * (g16 & 1) : qr);
         // softplus(x) = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)): the two sums are kept apart and ln2 is applied once.
         // A tail sample (zero tap weights) has x == 0 exactly; only the one partial batch of a chunk pays for the masks.
         unsigned int xh[2][4], xl[2][4], gh[2][4], gl[2][4];
@@ -472,7 +483,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
             if constexpr (!decltype(staged)::value) {
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][(Q16 ? 8 * g16 : 16 * st + 8 * h) + s8]);
+                    const i32x4 qi = *reinterpret_cast<const i32x4 *>(bqi[r0][(w16 ? 8 * g16 : 16 * st + 8 * h) + s8]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         m[s8][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, (int)((unsigned int)qi[e] + q4), 0, 0));
@@ -483,7 +494,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
                 float xv[2], sv[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int s8 = 2 * jp + e, k = (Q16 ? 8 * g16 : 16 * st + 8 * h) + s8;
+                    const int s8 = 2 * jp + e, k = (w16 ? 8 * g16 : 16 * st + 8 * h) + s8;
                     const f32x4 qw = *reinterpret_cast<const f32x4 *>(bqw[r0][k]);
                     float m0, m1, m2, m3;
                     if constexpr (decltype(staged)::value) {
@@ -513,6 +524,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         };
 #pragma unroll
         for (int st = 0; st < (Q16 ? 1 : 2); ++st) {
+            if (st == 1 && w16) break;                       // wave-uniform
             if (staged_now) {
                 if (nvalid == SB) query_half(st, std::false_type{}, std::true_type{}); else query_half(st, std::true_type{}, std::true_type{});
             } else {
@@ -522,7 +534,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         setup(r2, un, vn, tailn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target gathers) have landed
         __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1] and taps [r2] complete
-        if constexpr (!Q16) {
+        if (!w16) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const f16x8 th = *reinterpret_cast<const f16x8 *>(&Th[cur][l32][8 * st + 4 * h]);
@@ -562,7 +574,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     }
     const long pc = (long)prob * p.chunks + (long)t * CHM + c;
     float spsum = relusum + 0.693147181f * lg2sum;
-    if constexpr (!Q16) {
+    if (!w16) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -581,7 +593,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
             if (t == 1 && !two) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qq = wv * 16 + 4 * g16 + r;
+                const int qq = (Q16 ? wv * 16 : 96) + 4 * g16 + r;
                 p.wsA[(pc * QP + qq) * NP + 16 * t + l16] = bAm[t][r] + bAx[t][r] * (1.0f / 2048.0f);
                 p.wsD[(pc * QP + qq) * NP + 16 * t + l16] = bDm[t][r] + bDx[t][r] * (1.0f / 2048.0f);
             }
@@ -603,9 +615,10 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     }
 }
 
-__global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p) { matcher_cost_f16_body<false>(p); }
+__global__ __launch_bounds__(256, 2) void matcher_cost_f16_kernel(CostParams p) { matcher_cost_f16_body<0>(p); }
+__global__ __launch_bounds__(256, 2) void matcher_cost_f16_mix_kernel(CostParams p) { matcher_cost_f16_body<2>(p); }
 // two 7-wave workgroups per CU: 128 registers
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void matcher_cost_f16_q16_kernel(CostParams p) { matcher_cost_f16_body<true>(p); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void matcher_cost_f16_q16_kernel(CostParams p) { matcher_cost_f16_body<1>(p); }
 
 // C[prob][q][n] = w_mask*cost_mask + w_class*(-softmax(logits)[q][0]) + w_dice*cost_dice   (matcher.py:280-287)
 __global__ void matcher_finalize_kernel(CostParams p, const float *__restrict__ cls, float wc, float wm_, float wd,
@@ -810,6 +823,8 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_rows) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_mix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_rows) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(matcher_cost_f16_q16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_rows) != hipSuccess)
             return S2D_ERR_LAUNCH;
@@ -819,7 +834,10 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     // logit rows at once and every row starts at bank 0
     int q16 = 0;
     if (const char *e = getenv("S2D_MATCHER_Q16")) q16 = atoi(e);
+    int mix = Q > 96 && Q <= 112;                           // three 32-query tiles + one 16-query tile (S2D_MATCHER_MIX=0: four 32-query tiles)
+    if (const char *e = getenv("S2D_MATCHER_MIX")) mix = mix && atoi(e);
     if (q16) hipLaunchKernelGGL(matcher_cost_f16_q16_kernel, dim3(grid), dim3(64 * max(4, cdiv(Q, 16))), lds_rows, stream, p);
+    else if (mix) hipLaunchKernelGGL(matcher_cost_f16_mix_kernel, dim3(grid), dim3(256), lds_rows, stream, p);
     else hipLaunchKernelGGL(matcher_cost_f16_kernel, dim3(grid), dim3(256), lds_rows, stream, p);
     if (Nmax > 32) hipLaunchKernelGGL(matcher_cost_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(matcher_finalize_kernel, dim3(cdiv((long)Q * Nmax, 256), nprob), dim3(256), 0, stream, p,

@@ -269,6 +269,33 @@ def test_matcher_16_row_tile_kernel_opt_in(monkeypatch):
             assert torch.equal(x, y)
 
 
+def test_matcher_three_32_row_tiles_plus_one_16_row_tile(monkeypatch):
+    """96 < Q <= 112 (the shipped Q = 100) runs three 32-query tiles + one 16-query tile whose wave also builds the tap tables
+    (matcher_cost_f16_mix_kernel); S2D_MATCHER_MIX=0 is the four-tile kernel: same cost matrices to f32 summation order, same
+    assignments -- one and two target tiles, a logit row stride > Q, a point count that leaves a partial batch, injected sparse points
+    (direct-gather batches), Q at both ends of the range"""
+    import torch
+    from s2d_amd import ops
+    dev = torch.device("cuda")
+    for (NL, B, Q, ldq, T, hm, wm, N, P) in [(3, 2, 100, 100, 2, 40, 56, 10, 4096), (2, 1, 97, 104, 1, 24, 32, 20, 1000),
+                                            (2, 2, 112, 128, 2, 24, 40, 3, 777), (1, 1, 100, 100, 1, 46, 80, 32, 50)]:
+        g = torch.Generator(device=dev).manual_seed(Q + P)
+        ml = torch.randn((NL, B, T * hm * wm, ldq), generator=g, device=dev) * 4       # columns >= Q: the GEMM's padding, never used
+        cls = torch.randn((NL, B, Q, 2), generator=g, device=dev)
+        tgt = (torch.rand((B, N, T, hm * 4, wm * 4), generator=g, device=dev) < 0.3).to(torch.uint8)
+        cnt = torch.full((B,), N, dtype=torch.int32, device=dev)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("S2D_MATCHER_MIX", mode)
+            C = ops.matcher_cost(ml, cls, tgt, cnt, (Q, T, hm, wm), P, (2.0, 5.0, 5.0), seed=5)
+            out[mode] = (C, ops.lsap(C, cnt, B))
+        a, b = out["0"][0], out["1"][0]
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+        for x, y in zip(out["0"][1], out["1"][1]):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("P,H,W", [(250, 64, 96), (256, 64, 96), (1000, 32, 128)])
 def test_point_loss_vs_oracle_both_paths(oracle, P, H, W):
     """point loss vs the CPU restatement where the sampled logits cannot be kept (3P or P/4 not a multiple of 4: the
