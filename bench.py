@@ -410,8 +410,6 @@ def main():
     ap.add_argument("--one-stream", "--no-overlap", dest="one_stream", action="store_true",
                     help="time the one-stream schedule (default: teacher forward + GT criterion on a second HIP stream; the other "
                          "schedule is timed after the metric and reported under `schedules`, with a bitwise comparison of the losses)")
-    ap.add_argument("--schedule", default=None, choices=["twin", "decoders"],
-                    help="arrangement of the overlapped schedule (KDVideoMaskFormer.schedule; default: the library's, S2D_SCHEDULE)")
     ap.add_argument("--no-other-schedule", action="store_true",
                     help="profiling runs: time only the chosen schedule (no second timing pass, no bitwise comparison), so that a kernel "
                          "trace of the process holds one schedule's launches")
@@ -478,9 +476,6 @@ def main():
         targets = TargetSet.from_list(masks, device=dev)
         losses = model.forward_losses(images, targets)
         return sum(losses.values())
-
-    if args.schedule:
-        model.schedule = args.schedule
 
     def seeded_step(two_streams):
         model.overlap_teacher = model.overlap_criteria = two_streams
@@ -593,14 +588,11 @@ def main():
                "config": {"workload": f"KDVideoMaskFormer fwd+loss (student+teacher fwd, GT+KD VideoSetCriterion), {args.config}: "
                                       f"{B} clips/GPU x T={T} x {H0}x{W0}, Q={Q}, P={P}, N={N} sparse GT instances/clip, encoder dropout {args.dropout}",
                           "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"dp{world} (clips sharded, no collective)",
-                          "streams": (3 if model.schedule == "decoders" else 2) if two else 1, "encoder_dropout": args.dropout,
+                          "streams": 2 if two else 1, "encoder_dropout": args.dropout,
                           "teacher_intermediate_masks": "full maps" if model.teacher_aux_masks else
                           "only at the pixels its own attention masks read (no loss reads them; final prediction bit-identical)",
                           "kd_targets_per_clip": model.last["kd_count"].cpu().tolist()},
-               "schedules": {"timed": ("one stream" if not two else "two streams (teacher forward + GT criterion on a second HIP stream)"
-                                       if model.schedule == "twin" else
-                                       "three streams (the two video decoders on a high-priority stream: the student's beside the teacher's "
-                                       "trunk / pixel decoder, the teacher's beside the GT criterion)"),
+               "schedules": {"timed": "two streams (teacher forward + GT criterion on a second HIP stream)" if two else "one stream",
                              "other_ms_per_step": None if args.no_other_schedule else round(other_ms, 3),
                              "other": "one stream" if two else "two streams",
                              "losses_bitwise_equal_between_schedules": None if same is None else bool(same),

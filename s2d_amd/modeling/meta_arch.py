@@ -6,8 +6,6 @@ nn.Sequential(backbone, head) so checkpoint keys are student.0.* / student.1.*; 
 .device).  The forward is the measured hot path: normalise/pad -> student -> teacher -> GT criterion -> KD targets ->
 KD criterion -> rename/weight, all enqueued on the current stream without a host synchronisation.
 """
-import os
-
 import torch
 from torch import nn
 
@@ -189,13 +187,6 @@ class KDVideoMaskFormer(nn.Module):
         # they are evaluated at the attention masks' source pixels only; True computes the full maps like the reference.
         self.teacher_aux_masks = False
         self.overlap_teacher, self._side = False, None
-        # How the overlapped schedule arranges the two networks (overlap_teacher and overlap_criteria both set):
-        #   "twin"     teacher forward beside the student forward, GT criterion beside the KD criterion (two streams);
-        #   "decoders" the two video decoders -- ~1 500 launches on 200 query rows each, which leave most of the chip idle -- go to a
-        #              third, high-priority stream: the student's runs beside the rest of the teacher's trunk / pixel decoder, the
-        #              teacher's beside the GT criterion; the KD criterion follows alone.
-        self.schedule = os.environ.get("S2D_SCHEDULE", "twin")
-        self._deco = None
 
     @classmethod
     def from_config(cls, cfg):  # kd_video_maskformer_model.py:130-231
@@ -268,8 +259,6 @@ class KDVideoMaskFormer(nn.Module):
         # criterion: it runs on a second HIP stream so the launch tails and the small decoder kernels of one network
         # fill the CUs the other leaves idle.  Every kernel is deterministic, so the schedule does not change results.
         main = torch.cuda.current_stream()
-        if self.overlap_teacher and self.overlap_criteria and self.schedule == "decoders":
-            return self._forward_losses_decoders(images, gt_targets, coords_gt, coords_kd, kd_nmax, main)
         if self.overlap_teacher:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=images.device)
@@ -301,49 +290,6 @@ class KDVideoMaskFormer(nn.Module):
         out = {k: v * wd[k] for k, v in losses.items() if k in wd}
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
         if getattr(self, "keep_kd_targets", False):       # tests: the pseudo-target planes the KD matcher saw (1.5 GB at c4 otherwise freed)
-            self.last["kd_targets"] = tgt
-        return out
-
-    def _forward_losses_decoders(self, images, gt_targets, coords_gt, coords_kd, kd_nmax, main):
-        """forward_losses with the "decoders" schedule (see __init__).  Same kernels on the same data as every other schedule -- each is
-        deterministic, so the results are bitwise those of one stream.  Memory: a tensor crosses streams only forward in this
-        order, and every stream joins main before the step ends, so a pool never hands a block out again while another stream's
-        reader of it is pending."""
-        Hp, Wp = images.shape[1:3]
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=images.device)
-        if self._deco is None:
-            self._deco = torch.cuda.Stream(device=images.device, priority=-1)
-        side, deco = self._side, self._deco
-        side.wait_stream(main)
-        deco.wait_stream(main)
-        s_head, t_head = self.student[1], self.teacher[1]
-        mf, ms = s_head.pixel_decoder.forward_features(self.student[0](images))
-        ev_s = main.record_event()
-        with torch.cuda.stream(side):
-            tmf, tms = t_head.pixel_decoder.forward_features(self.teacher[0](images))
-            ev_t = side.record_event()
-        with torch.cuda.stream(deco):
-            deco.wait_event(ev_s)
-            student = s_head.predictor(ms, mf, True, True)
-            ev_sd = deco.record_event()
-            deco.wait_event(ev_t)
-            teacher = t_head.predictor(tms, tmf, True, self.teacher_aux_masks)
-            tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
-                                                self.score_threshold_distillation, self.num_predictions_distillation)
-            if self.distillation_nms:
-                tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
-        main.wait_event(ev_sd)
-        losses = self.criterion(student, gt_targets, False, coords_gt)
-        main.wait_stream(deco)
-        main.wait_stream(side)
-        kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd)
-        for k, v in kd.items():
-            losses[k.replace("loss_", "kd_loss_")] = v
-        wd = self.criterion.weight_dict
-        out = {k: v * wd[k] for k, v in losses.items() if k in wd}
-        self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
-        if getattr(self, "keep_kd_targets", False):
             self.last["kd_targets"] = tgt
         return out
 
