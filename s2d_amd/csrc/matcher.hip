@@ -256,6 +256,11 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
     lo = __builtin_bit_cast(unsigned int, l);
 }
 
+// timing experiments only (scripts/build_matcher_dbg.sh): 1 no target gathers, 2 no staged-row DMA, 4 no tap-table setup, 8 no query sampling.
+// Results of such builds are wrong by construction.
+#ifndef S2D_MATCHER_DBG
+#define S2D_MATCHER_DBG 0
+#endif
 constexpr int SPANMAX = 24;     // staged logit rows per tap row (upper / lower): a 32-point batch spans ~12 cells at S2D density
 constexpr int ROWS = 2 * SPANMAX + 3;   // LDS rows of one staged block: slack, upper run, slack, lower run, slack
 // Q16: 16-query row tiles (v_mfma_f32_16x16x32_f16), one per wave, ceil(Q / 16) waves (at least the four the target side needs):
@@ -396,7 +401,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     // instruction fills two 512-B LDS rows (lanes 0..31 / 32..63; ldq / 4 <= 32 float4s of each are real data)
     auto rows_dma = [&](int tb, int buf) {
         const int cmin = bmeta[tb][0], span = bmeta[tb][1];
-        if (!bmeta[tb][2] || wv >= 4) return;
+        if (!bmeta[tb][2] || wv >= 4 || (S2D_MATCHER_DBG & 2)) return;
         // MODE 2: the row's last 16 floats (padding: Q <= 112) receive a second copy of queries 96..111 -- the 16-query wave's odd
         // point groups read that copy, so the two groups of a 32-lane LDS access fall on banks 0..15 and 16..31
         const int c4 = (MODE == 2 && (lane & 31) >= 28) ? (lane & 31) - 4 : (lane & 31);
@@ -417,6 +422,13 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     // as two fp16 pairs (hi / scaled lo) of row tn
     auto target_gather = [&](int tb, unsigned char (&tv)[SPT][4]) {
         if (tid >= 256) return;
+        if (S2D_MATCHER_DBG & 1) {
+#pragma unroll
+            for (int j = 0; j < SPT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tv[j][e] = (unsigned char)(tid & 1);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[tb][slot * SPT + j]);
@@ -525,13 +537,18 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
 #pragma unroll
         for (int st = 0; st < (Q16 ? 1 : 2); ++st) {
             if (st == 1 && w16) break;                       // wave-uniform
+            if (S2D_MATCHER_DBG & 8) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) { xh[st][jp] = 0x3c003c00u + lane; xl[st][jp] = lane; gh[st][jp] = 0x38003800u; gl[st][jp] = tid; }
+                continue;
+            }
             if (staged_now) {
                 if (nvalid == SB) query_half(st, std::false_type{}, std::true_type{}); else query_half(st, std::true_type{}, std::true_type{});
             } else {
                 if (nvalid == SB) query_half(st, std::false_type{}, std::false_type{}); else query_half(st, std::true_type{}, std::false_type{});
             }
         }
-        setup(r2, un, vn, tailn);
+        if (!(S2D_MATCHER_DBG & 4)) setup(r2, un, vn, tailn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target gathers) have landed
         __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1] and taps [r2] complete
         if (!w16) {
