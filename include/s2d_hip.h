@@ -281,11 +281,12 @@ int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v,
 
 /* ---- VideoHungarianMatcher on the device -------------------------------------------------------------- */
 /* A criterion pass handles NL prediction layers x B clips = NL*B independent "problems" (problem = layer*B +
- * clip) in one call.  Targets of the pass: tgt u8 [B][Nmax][T][H][W] with the per-clip count in DEVICE memory
- * (tgt_count[B]) so that distillation targets, whose number depends on teacher scores, need no host sync.
+ * clip) in one call.  Targets of the pass: tgt u8 [B][Nmax][T][H][W] -- binary masks, nonzero = set (the reference's
+ * bool gt_masks, matcher.py:246; a clip with <= 32 targets is read through bit-interleaved words) -- with the per-clip count in DEVICE
+ * memory (tgt_count[B]) so that distillation targets, whose number depends on teacher scores, need no host sync.
  * mask_logits are pixel-major [NL][B][T*hm*wm][ldq]; class_logits [NL][B][Q][2]. */
 
-long s2d_matcher_workspace_floats(int NL, int B, int T, int P);
+long s2d_matcher_workspace_floats(int NL, int B, int T, int P, int H, int W);
 
 /* C[problem][Q][Nmax] (columns >= tgt_count[clip] are zero) = w_mask*cost_mask + w_class*cost_class +
  * w_dice*cost_dice at P shared random points per problem: matcher.py:236-287 (batch_sigmoid_ce_loss :38-62,

@@ -60,6 +60,7 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, int H, int W)
 
 struct CostParams {
     const float *ml;         // [NL][B][T*hm*wm][ldq]
+    const unsigned int *tbits;   // [B][T][H][W]: bit n = target n of the clip is set at that pixel (n < min(count, 32)); the f16 kernels' target side
     const uint8_t *tgt;      // [B][Nmax][T][H][W]
     const int *tgt_count;    // [B]
     const float *coords;     // [NL][B][P][2]  (band-sorted copy made by sort_points)
@@ -239,6 +240,34 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(CostParams p)
     }
 }
 
+// The target side of the f16 kernels reads ONE word per (point, tap) for all <= 32 targets of the clip: the binary target planes
+// [B][Nmax][T][H][W] (bytes, nonzero = set; the reference's bool gt_masks, matcher.py:246) are interleaved once per call into
+// [B][T][H][W] words.  A 32-point batch then costs 128 dword loads instead of 4 096 byte gathers over up to 32 planes -- measured
+// 1.36 ms of the 5.9 ms call at c4 (profiles/r4_experiments/matcher_dbg.txt).  Four pixels per thread.
+__global__ __launch_bounds__(256) void target_bits_kernel(const uint8_t *__restrict__ tgt, const int *__restrict__ tgt_count, int Nmax, int T,
+                                                           long HW, unsigned int *__restrict__ out)
+{
+    const int bt = blockIdx.y, b = bt / T, t = bt % T;
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= HW) return;
+    const int N = min(min(tgt_count[b], Nmax), 32);
+    const uint8_t *src = tgt + ((long)b * Nmax * T + t) * HW + i4;
+    unsigned int w[4] = {0u, 0u, 0u, 0u};
+    const bool full = i4 + 4 <= HW && (HW & 3) == 0;
+    for (int n = 0; n < N; ++n) {
+        const uint8_t *pl = src + (long)n * T * HW;
+        if (full) {
+            const unsigned int v = *reinterpret_cast<const unsigned int *>(pl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] |= (((v >> (8 * e)) & 0xFFu) ? 1u : 0u) << n;
+        } else {
+            for (int e = 0; e < 4 && i4 + e < HW; ++e) w[e] |= (pl[e] ? 1u : 0u) << n;
+        }
+    }
+    unsigned int *dst = out + (long)bt * HW + i4;
+    for (int e = 0; e < 4 && i4 + e < HW; ++e) dst[e] = w[e];
+}
+
 // N <= 32 targets: the two [Q x N] contractions on the f16 matrix cores with the split-fp16 x3 scheme of
 // gemm_bf16.hip (x = h + l*2^-11, main and cross accumulators): 12 MFMAs of 32 cycles per 32-sample batch instead of
 // 32 fp32-input MFMAs of 64 cycles, at fp32-class accuracy (~3*2^-22 relative).  |logit| < 65504 is required.
@@ -294,6 +323,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     __shared__ __attribute__((aligned(16))) int bqi[3][SB][4], bti[3][SB][4];      // per sample: 4 tap offsets / weights,
     __shared__ __attribute__((aligned(16))) float bqw[3][SB][4], btw[3][SB][4];   // read back as one 16-B LDS load each
     __shared__ int bmeta[3][4];                                                  // cmin, span, staged
+    __shared__ __attribute__((aligned(16))) unsigned int twl[2][SB][4];          // per sample: the 4 taps' target words (bit n = target n)
     __shared__ float tpart[SLOTS][TN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int l16 = lane & 15, g16 = lane >> 4;
@@ -315,13 +345,10 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         const_cast<float *>(p.ml + ((long)prob * p.T + t) * mapf), 0, (int)(mapf * 4), 0x00020000);
     const int qr = q < p.Q ? q : 0;
     const unsigned int q4 = (unsigned int)qr * 4u;
-    const long tplane = (long)p.T * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(p.tgt + ((long)b * p.Nmax * p.T + t) * p.H * p.W), 0,
-        (int)((long)p.Nmax * tplane - (long)t * p.H * p.W), 0x00020000);
+        const_cast<unsigned int *>(p.tbits + ((long)b * p.T + t) * p.H * p.W), 0, (int)((long)p.H * p.W * 4), 0x00020000);
     const float *cr = p.coords + (long)prob * p.P * 2;
     const int tn = tid % TN, slot = tid / TN;
-    const unsigned int toff = (unsigned int)((long)(tn < N ? tn : 0) * tplane);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     // tap setup: lanes 0..31 of wave 0 do the logit-map side of sample l32, lanes 0..31 of wave 1 the target side
     constexpr int SETW = MODE == 2 ? 3 : 0;
@@ -420,29 +447,28 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
     };
     // target tile: thread (tn, slot) samples target tn at the 4 consecutive points 4*slot .. 4*slot+3 and stores them
     // as two fp16 pairs (hi / scaled lo) of row tn
-    auto target_gather = [&](int tb, unsigned char (&tv)[SPT][4]) {
-        if (tid >= 256) return;
-        if (S2D_MATCHER_DBG & 1) {
-#pragma unroll
-            for (int j = 0; j < SPT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tv[j][e] = (unsigned char)(tid & 1);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const i32x4 ti = *reinterpret_cast<const i32x4 *>(bti[tb][slot * SPT + j]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tv[j][e] = __builtin_amdgcn_raw_buffer_load_b8(rsT, (int)(toff + (unsigned int)ti[e]), 0, 0);
-        }
+    // target side: thread (sample tid >> 2, tap tid & 3) of the first two waves loads the word of its tap -- all targets of the clip at
+    // once -- a batch ahead, parks it in LDS before the batch's barrier; thread (tn, slot) then interpolates target tn at the 4
+    // consecutive points 4*slot .. 4*slot+3 from its bit of those words and stores them as two fp16 pairs (hi / scaled lo) of row tn
+    unsigned int tword = 0u;
+    auto target_gather = [&](int tb) {
+        if (tid >= 4 * SB) return;
+        if (S2D_MATCHER_DBG & 1) { tword = (unsigned int)tid * 0x9E3779B9u; return; }
+        tword = __builtin_amdgcn_raw_buffer_load_b32(rsT, bti[tb][tid >> 2][tid & 3] * 4, 0, 0);
     };
-    auto target_tile = [&](int tb, int buf, const unsigned char (&tv)[SPT][4]) {
+    auto target_stash = [&](int buf) {
+        if (tid < 4 * SB) twl[buf][tid >> 2][tid & 3] = tword;
+    };
+    auto target_tile = [&](int tb, int buf) {
         if (tid >= 256) return;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         float val[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const f32x4 tw = *reinterpret_cast<const f32x4 *>(btw[tb][slot * SPT + j]);
-            val[j] = fmaf((float)tv[j][3], tw[3], fmaf((float)tv[j][2], tw[2], fmaf((float)tv[j][1], tw[1], (float)tv[j][0] * tw[0])));
+            const u32x4 wd = *reinterpret_cast<const u32x4 *>(twl[buf][slot * SPT + j]);
+            val[j] = fmaf((float)((wd[3] >> tn) & 1u), tw[3], fmaf((float)((wd[2] >> tn) & 1u), tw[2],
+                          fmaf((float)((wd[1] >> tn) & 1u), tw[1], (float)((wd[0] >> tn) & 1u) * tw[0])));
             tsum += val[j];
         }
         unsigned int h0, l0, h1, l1;
@@ -467,10 +493,12 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         load_uv(base0 + bstep, u, v, tail);                // all-tail (zero weights, no load) past the end
         setup(1, u, v, tail);
         __syncthreads();
-        unsigned char tv[SPT][4];
-        target_gather(0, tv);
+        target_gather(0);
         rows_dma(0, 0);
-        target_tile(0, 0, tv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        target_stash(0);
+        __syncthreads();
+        target_tile(0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // rows [0] visible
@@ -480,8 +508,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
         const int nvalid = min(SB, p.P - base);
         float un, vn; bool tailn;
         load_uv(base + 2 * bstep, un, vn, tailn);
-        unsigned char tv[SPT][4];
-        target_gather(r1, tv);                              // batch i+1 (all-tail tables past the end: offsets 0)
+        target_gather(r1);                                  // batch i+1 (all-tail tables past the end: offsets 0)
         rows_dma(r1, cur ^ 1);                              // batch i+1's logit rows -> rows [cur^1] (last read before the previous barrier)
         // query side: lane (q, h) samples its query at points 16*st + 8*h + j  (the lane's A-fragment k range)
         const bool staged_now = bmeta[r0][2] != 0;
@@ -549,8 +576,9 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
             }
         }
         if (!(S2D_MATCHER_DBG & 4)) setup(r2, un, vn, tailn);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target gathers) have landed
-        __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1] and taps [r2] complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's row DMAs (and target words) have landed
+        target_stash(cur ^ 1);
+        __syncthreads();  // target tile [cur] (written last iteration), rows [cur^1], target words [cur^1] and taps [r2] complete
         if (!w16) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -587,7 +615,7 @@ __device__ __forceinline__ void matcher_cost_f16_body(const CostParams &p)
                 bDm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ghv, th, bDm[t], 0, 0, 0);
             }
         }
-        target_tile(r1, cur ^ 1, tv);
+        target_tile(r1, cur ^ 1);
     }
     const long pc = (long)prob * p.chunks + (long)t * CHM + c;
     float spsum = relusum + 0.693147181f * lg2sum;
@@ -791,11 +819,12 @@ extern "C" {
 
 
 
-long s2d_matcher_workspace_floats(int NL, int B, int T, int P)
+long s2d_matcher_workspace_floats(int NL, int B, int T, int P, int H, int W)
 {
     const long nprob = (long)NL * B, ch = (long)T * CHM, n = nprob * P;
     // partial sums + raw / sorted coordinates + 4 key/value arrays + radix-sort scratch (checked against rocPRIM's need at launch)
-    return nprob * ch * (2L * QP * NP + 3 * 128) + 4 * n + 4 * n + (4 * n + (1L << 20)) + 64;
+    // + the interleaved target words [B][T][H][W]
+    return nprob * ch * (2L * QP * NP + 3 * 128) + 4 * n + 4 * n + (4 * n + (1L << 20)) + 64 + (long)B * T * H * W;
 }
 
 int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, const uint8_t *tgt, const int *tgt_count,
@@ -819,6 +848,10 @@ int s2d_matcher_cost_f32(const float *mask_logits, const float *class_logits, co
     unsigned int *keys_in = (unsigned int *)(sorted + 2 * n), *keys_out = keys_in + n, *vals_in = keys_out + n, *vals_out = vals_in + n;
     void *tmp = vals_out + n;
     const size_t tmp_bytes = (size_t)(4 * n + (1L << 20)) * 4;
+    unsigned int *tbits = reinterpret_cast<unsigned int *>(tmp) + (4 * n + (1L << 20)) + 64;
+    if ((long)H * W * 4 > 0x7FFFFFFFL) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(target_bits_kernel, dim3(cdiv(cdiv((long)H * W, 4), 256), B * T), dim3(256), 0, stream, tgt, tgt_count, Nmax, T, (long)H * W, tbits);
+    p.tbits = tbits;
     if (!coords) {
         hipLaunchKernelGGL(gen_points_kernel, dim3(cdiv(P, 256), nprob), dim3(256), 0, stream, raw, seed, P);
         coords = raw;

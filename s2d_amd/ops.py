@@ -607,7 +607,7 @@ def matcher_cost(mask_logits, class_logits, tgt, tgt_count, dims, P, weights, co
     NL, B = mask_logits.shape[:2]
     Q, T, hm, wm = dims
     Nmax, H, W = tgt.shape[1], tgt.shape[3], tgt.shape[4]
-    n = lib().call("s2d_matcher_workspace_floats", NL, B, T, int(P))
+    n = lib().call("s2d_matcher_workspace_floats", NL, B, T, int(P), H, W)
     ws = torch.empty((n,), device=tgt.device, dtype=torch.float32)
     C = torch.empty((NL * B, Q, Nmax), device=tgt.device, dtype=torch.float32)
     wc, wm_, wd = weights
