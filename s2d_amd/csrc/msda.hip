@@ -347,6 +347,127 @@ __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const fl
     *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
 }
 
+// One HEAD per workgroup, the coarsest level of that head in LDS.  The gather is bound by the line rate of the vector L1: every bilinear
+// tap of a (query, head) is one 128-B line, 48 per (query, head) at L x P = 12.  A head's 32 channels of the coarsest level are
+// H x W x 128 B -- 115 KB at the S2D geometry (23 x 40) -- so a workgroup that works on ONE head copies that plane into LDS once and
+// serves the P samples of that level from it with ds_read_b128 (256 B/clk/CU against the L1's 64): 32 lines per (query, head) instead
+// of 48, for any offsets (nothing is windowed: every tap of the level is in the plane).  Workgroup = (frame, head, chunk of the
+// frame's query patches); patch = 16 x 8 queries of one level, wave w = 8 x-adjacent queries of patch row w / 2 (8 lanes x float4 =
+// the head's 32 channels of a query), so the lines neighbouring queries share stay in the CU's L1 as in the TILED form.  blockIdx.x
+// % 8 is the head, so an XCD's L2 only ever sees the lines of one head.  Same formulas and accumulation order as msda_fused_kernel
+// (SHARE form): bit-identical results.
+template <int LP_>
+__global__ __launch_bounds__(1024) void msda_fused_head_kernel(const float *__restrict__ value, int ldv, Levels lv, const float *__restrict__ oa,
+                                                               int ldoa, int S, int M, int L, int P, int ls, int npatch, int chunks,
+                                                               float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float plane[];     // [H_ls * W_ls][32]
+    constexpr int D = 32;
+    const int n = blockIdx.y, m = blockIdx.x % M, chunk = blockIdx.x / M;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 7;
+    {
+        const int npx = lv.H[ls] * lv.W[ls];
+        const float *src = value + ((long)n * S + lv.start[ls]) * ldv + m * D;
+        for (int i = threadIdx.x; i < npx * 8; i += 1024)
+            *reinterpret_cast<f32x4 *>(plane + (long)(i >> 3) * D + (i & 7) * 4) = *reinterpret_cast<const f32x4 *>(src + (long)(i >> 3) * ldv + (i & 7) * 4);
+    }
+    __syncthreads();
+    const int p_lo = (int)((long)chunk * npatch / chunks), p_hi = (int)((long)(chunk + 1) * npatch / chunks);
+    for (int pi = p_lo; pi < p_hi; ++pi) {
+        int lq = 0, tb = pi, ntx = 1;
+        for (; lq < L; ++lq) {
+            ntx = (lv.W[lq] + 15) >> 4;
+            const int nt = ntx * ((lv.H[lq] + 7) >> 3);
+            if (tb < nt) break;
+            tb -= nt;
+        }
+        const int Hq = lv.H[lq], Wq = lv.W[lq];
+        const int qy_ = (tb / ntx) * 8 + (w >> 1), qx_ = (tb % ntx) * 16 + (w & 1) * 8 + (lane >> 3);
+        const bool live_q = qy_ < Hq && qx_ < Wq;                  // a patch overhanging the level's border: computed on a clamped query, not stored
+        const int qy = min(qy_, Hq - 1), qx = min(qx_, Wq - 1);
+        const int q = (int)lv.start[lq] + qy * Wq + qx;
+        const float ref_x = ((float)qx + 0.5f) / (float)Wq;
+        const float ref_y = ((float)qy + 0.5f) / (float)Hq;
+        const float *row = oa + ((long)n * S + q) * ldoa;
+        const float *offp_g = row + m * (LP_ * 2);
+        const float *lgp = row + M * LP_ * 2 + m * LP_;
+        float own_ox[2], own_oy[2], own_e[2], own_lg[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = c + 8 * r;
+            const bool live = i < LP_;
+            const int ic = live ? i : LP_ - 1;
+            const float2 o = *reinterpret_cast<const float2 *>(offp_g + 2 * ic);
+            own_ox[r] = o.x; own_oy[r] = o.y;
+            own_lg[r] = live ? lgp[ic] : -INFINITY;
+            mx = fmaxf(mx, own_lg[r]);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) own_e[r] = expf(own_lg[r] - mx);
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) den += __shfl(own_e[i >> 3], i & 7, 8);
+        const float inv = 1.f / den;
+        float sw1[2], sw2[2], sw3[2], sw4[2], saw[2];
+        int spix[2], smask[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = c + 8 * r;
+            const int ic = i < LP_ ? i : LP_ - 1;
+            const int l = ic / P;
+            const int H = lv.H[l], W = lv.W[l];
+            const float lx = ref_x + own_ox[r] / (float)W, ly = ref_y + own_oy[r] / (float)H;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // cuh:293
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+            sw1[r] = hh * hw; sw2[r] = hh * lw; sw3[r] = lh * hw; sw4[r] = lh * lw;
+            saw[r] = own_e[r] * inv;
+            spix[r] = h0 * W + w0;
+            smask[r] = !in ? 0 : ((h0 >= 0 && w0 >= 0) ? 1 : 0) | ((h0 >= 0 && w1 <= W - 1) ? 2 : 0) | ((h1 <= H - 1 && w0 >= 0) ? 4 : 0) |
+                                 ((h1 <= H - 1 && w1 <= W - 1) ? 8 : 0);
+        }
+        f32x4 acc = f32x4(0.f);
+#pragma unroll
+        for (int i = 0; i < LP_; ++i) {
+            const int r = i >> 3, src = i & 7;
+            const int l = i / P;
+            const int W = lv.W[l];
+            const int mask = __shfl(smask[r], src, 8);
+            if (mask == 0) continue;                               // uniform over the query's 8 lanes
+            const int pix = __shfl(spix[r], src, 8);
+            const float c1 = __shfl(sw1[r], src, 8), c2 = __shfl(sw2[r], src, 8), c3 = __shfl(sw3[r], src, 8), c4 = __shfl(sw4[r], src, 8);
+            const float aw = __shfl(saw[r], src, 8);
+            f32x4 v1 = f32x4(0.f), v2 = f32x4(0.f), v3 = f32x4(0.f), v4 = f32x4(0.f);
+            if (l == ls) {                                         // workgroup-uniform: this level's taps come from the plane in LDS
+                const float *p1 = plane + (long)pix * D + c * 4;
+                if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
+                if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + D);
+                if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * D);
+                if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * D);
+            } else {
+                const float *p1 = value + ((long)n * S + lv.start[l] + pix) * ldv + m * D + c * 4;
+                if (__builtin_amdgcn_readfirstlane(mask) == 15 && __all(mask == 15)) {
+                    v1 = *reinterpret_cast<const f32x4 *>(p1);
+                    v2 = *reinterpret_cast<const f32x4 *>(p1 + ldv);
+                    v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * ldv);
+                    v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * ldv);
+                } else {
+                    if (mask & 1) v1 = *reinterpret_cast<const f32x4 *>(p1);
+                    if (mask & 2) v2 = *reinterpret_cast<const f32x4 *>(p1 + ldv);
+                    if (mask & 4) v3 = *reinterpret_cast<const f32x4 *>(p1 + (long)W * ldv);
+                    if (mask & 8) v4 = *reinterpret_cast<const f32x4 *>(p1 + (long)(W + 1) * ldv);
+                }
+            }
+            acc += (c1 * v1 + c2 * v2 + c3 * v3 + c4 * v4) * aw;  // cuh:85-88, :299
+        }
+        if (live_q) *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * 4) = acc;
+    }
+}
+
 // Windowed form of the fused kernel for the queries of the LAST level when it is the finest (three quarters of the pyramid's
 // queries at the S2D geometry).  The gather above is bound by the line rate of the vector L1 (every bilinear tap of a head is one
 // 128-B line; 48 taps per (query, head)), not by HBM.  Deformable offsets are local -- at the reference's initialisation
@@ -1320,6 +1441,13 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
         if (const char *r = getenv("S2D_MSDA_WIN_R")) winR = min(max(atoi(r), 1), 8);
         int lq = 0;
         for (int l = 1; l < L; ++l) if ((long)lv.H[l] * lv.W[l] > (long)lv.H[lq] * lv.W[lq]) lq = l;
+        // opt-in (S2D_MSDA_HEAD=1, read per call): one head per workgroup with the coarsest level's plane of that head in LDS
+        // (msda_fused_head_kernel), when that plane fits.  A third fewer L1 lines per (query, head), bit-identical, and SLOWER at c4
+        // (0.77-0.80 vs 0.66-0.72 ms): profiles/r4_experiments/not_adopted.txt
+        int ls = 0;
+        for (int l = 1; l < L; ++l) if ((long)lv.H[l] * lv.W[l] < (long)lv.H[ls] * lv.W[ls]) ls = l;
+        bool head_ok = false;
+        if (const char *e = getenv("S2D_MSDA_HEAD")) head_ok = atoi(e) != 0 && L > 1 && (long)lv.H[ls] * lv.W[ls] * 128 <= 150 * 1024 && (ldv & 3) == 0;
         WinGeo wg;
         // the windowed kernel takes the last level's queries when that level is the finest and holds most of the pyramid
         bool win_ok = winmode && tiled && M == 8 && L == 3 && P == 4 && lq == L - 1 && 2L * lv.H[lq] * lv.W[lq] > S && (long)S * ldv * 4 < 0x7fffffffL;
@@ -1359,6 +1487,19 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
             if (ntile > 0)
                 hipLaunchKernelGGL((msda_fused_kernel<12, false, true, true>), dim3(ntile, N), dim3(1024), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P,
                                    ntile, out, lq);
+        } else if (tiled && M == 8 && head_ok) {
+            static S2dDevOnce attr;
+            if (!attr.done()) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_head_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                    return S2D_ERR_LAUNCH;
+                attr.mark();
+            }
+            int npatch = 0;
+            for (int l = 0; l < L; ++l) npatch += ((lv.W[l] + 15) / 16) * ((lv.H[l] + 7) / 8);
+            // ~4 workgroups per CU in total (one resident per CU: the plane takes most of its LDS)
+            const int chunks = max(1, min(npatch, (int)cdiv(1024L, (long)N * M)));
+            hipLaunchKernelGGL((msda_fused_head_kernel<12>), dim3(chunks * M, N), dim3(1024), (size_t)lv.H[ls] * lv.W[ls] * 128, stream, value, ldv, lv, offs_logits, ldoa,
+                               S, M, L, P, ls, npatch, chunks, out);
         } else if (tiled && M == 8) {
             int ntile = 0;
             for (int l = 0; l < L; ++l) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);

@@ -19,8 +19,10 @@ for name in ("random offsets (sigma 2 px)", "smooth offsets (bias + 0.3 px noise
         bias = (g.view(8, 1, 1, 2) * torch.arange(1, 5, device=dev).view(1, 1, 4, 1)).expand(8, 3, 4, 2).reshape(-1)
         both[..., :192] = bias + (0.3 * torch.randn((N, S, 192), device=dev) if name.startswith("smooth") else 0.0)
     value, oa = both[..., 288:], both[..., :288]
-    for _ in range(3): y = ops.msda_fused_forward(value, np.array(shapes), oa)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): y = ops.msda_fused_forward(value, np.array(shapes), oa)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    print(f"S2D_MSDA_TILED={os.environ.get('S2D_MSDA_TILED', '1')}  {name:40s} {dt*1e3:.3f} ms  checksum {float(y.double().sum()):.6f}", flush=True)
+    for head in ("1", "0", "1", "0"):                   # S2D_MSDA_HEAD is read per call: one head per workgroup (coarsest level in LDS) vs the patch kernel
+        os.environ["S2D_MSDA_HEAD"] = head
+        for _ in range(3): y = ops.msda_fused_forward(value, np.array(shapes), oa)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): y = ops.msda_fused_forward(value, np.array(shapes), oa)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+        print(f"S2D_MSDA_TILED={os.environ.get('S2D_MSDA_TILED', '1')} S2D_MSDA_HEAD={head}  {name:40s} {dt*1e3:.3f} ms  checksum {float(y.double().sum()):.6f}", flush=True)

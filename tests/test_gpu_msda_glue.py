@@ -97,6 +97,37 @@ def test_msda_windowed_kernel_opt_in_matches_the_gather_kernel(oracle, monkeypat
         close(win.cpu().numpy(), ref, 1e-5)
 
 
+def test_msda_head_per_workgroup_kernel_matches_the_patch_kernel(oracle, monkeypatch):
+    """the opt-in fused kernel with one head per workgroup and the coarsest level's plane of that head in LDS (S2D_MSDA_HEAD=1)
+    bit for bit against the default 4 x 4-patch gather kernel and against the oracle: level extents that are /
+    are not multiples of the 16 x 8 query patch, the coarsest level first / last / in the middle, offsets within a pixel and far
+    outside the maps (zero-padding corners), column-slice operands, one frame and several"""
+    import torch
+    from s2d_amd import ops
+    cases = (([(6, 10), (12, 20), (23, 40)], 2.0, 2), ([(23, 40), (46, 80), (92, 160)], 3.0, 1), ([(22, 37), (5, 9), (11, 19)], 0.4, 3),
+             ([(8, 16), (16, 32), (3, 5)], 30.0, 2))
+    for shapes, scale, N in cases:
+        S = sum(h * w for h, w in shapes)
+        M, D, L, P = 8, 32, 3, 4
+        value = synth.randn(21, 1, (N, S, M * D))
+        off = synth.randn(21, 2, (N, S, M, L, P, 2), scale)
+        lg = synth.randn(21, 3, (N, S, M, L * P))
+        oa = np.concatenate([off.reshape(N, S, -1), lg.reshape(N, S, -1)], -1)
+        both = _dev(np.concatenate([oa, value], -1))
+        v, o = both[..., oa.shape[-1]:], both[..., :oa.shape[-1]]
+        monkeypatch.setenv("S2D_MSDA_HEAD", "0")
+        base = ops.msda_fused_forward(v, np.array(shapes), o)
+        monkeypatch.setenv("S2D_MSDA_HEAD", "1")
+        head = ops.msda_fused_forward(v, np.array(shapes), o)
+        assert torch.equal(head, base)
+        ref_pts = oracle.reference_points(shapes)
+        norm = np.array([[w_, h_] for (h_, w_) in shapes], np.float32)
+        loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        aw = oracle.softmax(lg, -1).reshape(N, S, M, L, P)
+        ref = oracle.msda_core(value.reshape(N, S, M, D), np.array(shapes), oracle.level_start_index(shapes), loc.astype(np.float32), aw.astype(np.float32))
+        close(head.cpu().numpy(), ref, 1e-5)
+
+
 def test_normalize_pad_maxpool(oracle):
     from s2d_amd import ops
     fr = synth.smooth_frames_u8(3, 1, 2, 45, 70)
