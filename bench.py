@@ -62,7 +62,9 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     from s2d_amd import ops
     from s2d_amd.modeling import TargetSet
     from s2d_amd.optim import FullModelGradientClippingAdamW, param_groups_like_reference
-    model.overlap_teacher = model.overlap_criteria = False
+    # the iteration's forward on two streams (teacher forward beside the student's, GT criterion + its point-loss backward beside the KD
+    # pass's; tests/test_gpu_fullsize.py: same losses and gradients bit for bit); S2D_TRAIN_ONE_STREAM=1 times the one-stream form
+    model.overlap_teacher = model.overlap_criteria = os.environ.get("S2D_TRAIN_ONE_STREAM", "0") != "1"
     model.last = None
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -95,7 +97,8 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     ar = 1000 * _max_over_ranks(sum(t_ar[WARM:]) / iters, world, cdev or dev)
     return {"what": "one full training iteration per rank on its batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
                     "(HIP gradient kernels, no autograd graph) + gradient all-reduce (per part of the student, started while the backward of the remaining parts "
-                    "runs; allreduce_ms = what is left to wait for after the backward) + full-model clip + AdamW + EMA teacher update; fp32, one stream",
+                    "runs; allreduce_ms = what is left to wait for after the backward) + full-model clip + AdamW + EMA teacher update; fp32, "
+                    + ("teacher forward and GT criterion on a second stream" if model.overlap_teacher else "one stream"),
             "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(world * frames.shape[0] / (ms / 1000), 2),
             "allreduce_ms": round(ar, 2), "allreduce_bytes": int(opt.grad_arena.numel() * 4), "n_gpus": world,
             "iterations": iters, "warmup_iterations": WARM, "loss_per_iteration_rank0": losses,

@@ -325,9 +325,15 @@ class KDVideoMaskFormer(nn.Module):
         feats = backbone(images, tb)
         mf, ms = head.pixel_decoder.forward_features(feats, tp)
         student = head.predictor(ms, mf, True, True, td)
-        main.wait_stream(side)
-        losses = self.criterion(student, gt_targets, False, coords_gt, keep_ctx=True)
-        ctx_gt = self.criterion.last_ctx
+        # overlap_criteria (with overlap_teacher): the GT criterion and the backward of its point loss run on the side stream beside
+        # the KD criterion's, as in forward_losses -- same host order of the calls, so the same seeds
+        crit_side = side if (self.overlap_teacher and self.overlap_criteria) else main
+        if crit_side is not main:
+            side.wait_stream(main)        # student outputs ready
+        main.wait_stream(side)            # pseudo targets ready
+        with torch.cuda.stream(crit_side):
+            losses = self.criterion(student, gt_targets, False, coords_gt, keep_ctx=True)
+            ctx_gt = self.criterion.last_ctx
         kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd, keep_ctx=True)
         ctx_kd = self.criterion.last_ctx
         for k, v in kd.items():
@@ -338,14 +344,17 @@ class KDVideoMaskFormer(nn.Module):
         Q, T, hm, wm = student.dims
         d_cls = torch.zeros_like(student.class_logits)
         sources = []
-        for ctx, pre in ((ctx_gt, ""), (ctx_kd, "kd_")):
+        for ctx, pre, strm in ((ctx_gt, "", crit_side), (ctx_kd, "kd_", main)):
             w_mask, w_dice = wd.get(pre + "loss_mask", 0.0), wd.get(pre + "loss_dice", 0.0)
             for i in range(NL - 1):
                 if wd.get(pre + f"loss_mask_{i}", w_mask) != w_mask or wd.get(pre + f"loss_dice_{i}", w_dice) != w_dice:
                     raise NotImplementedError("per-layer loss weights that differ between decoder layers")
             if w_mask != 0.0 or w_dice != 0.0:
-                rows = ops.point_loss_backward(ctx["point_loss"], w_mask * loss_scale, w_dice * loss_scale).view(NL, B, ctx["maxm"], T * hm * wm)
+                with torch.cuda.stream(strm):
+                    rows = ops.point_loss_backward(ctx["point_loss"], w_mask * loss_scale, w_dice * loss_scale).view(NL, B, ctx["maxm"], T * hm * wm)
                 sources.append((rows, ctx["idx_q"]))
+        main.wait_stream(crit_side)
+        for ctx, pre in ((ctx_gt, ""), (ctx_kd, "kd_")):
             w_ce = wd.get(pre + "loss_ce", 0.0)
             if w_ce != 0.0:
                 d_cls[NL - 1] += ops.class_loss_backward(student.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),

@@ -14,7 +14,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 B, T, H0, W0, Q, P, N = bench.CONFIGS[cfg]
 model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0)).to(dev)
 model.train()
-model.overlap_teacher = os.environ.get('ONE_STREAM') is None
+model.overlap_teacher = model.overlap_criteria = os.environ.get('ONE_STREAM') is None
 frames, masks = bench.synth_batch(0, B, T, H0, W0, N, dev)
 bench.calibrate_teacher(model, ops.normalize_pad(frames))
 groups = param_groups_like_reference(model.student, 1e-4, 0.05)

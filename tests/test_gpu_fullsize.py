@@ -149,7 +149,14 @@ def test_train_step_at_config4_gradients_finite_and_reproducible(setup):
 
     l1, g1 = once()
     l2, g2 = once()
+    # ... and the overlapped schedule of the iteration (teacher forward beside the student's, GT criterion and its point-loss backward
+    # beside the KD pass's, on a second stream) gives the same losses and the same 345 gradients, bit for bit
+    model.overlap_teacher = model.overlap_criteria = True
+    l3, g3 = once()
+    model.overlap_teacher = model.overlap_criteria = False
     model.last_tapes = None
+    assert l3 == l1 and all(torch.equal(a, b) for a, b in zip(g1, g3))
+    del g3
     assert len(g1) == 345 and l1 == l2
     assert all(bool(torch.isfinite(g).all()) for g in g1)
     spread = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(g1, g2))
