@@ -88,7 +88,7 @@ def weight_grad(dy, x, out=None, beta=0.0):
     K = x.shape[1]
     assert x.shape[0] == M
     if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # no transposed copies: the TN kernel
-        S, chunk = _slices(M, ((N + 127) // 128) * ((K + 63) // 64))
+        S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128 if K >= 128 else (K + 63) // 64))      # the TN kernel's tiles: 128 x 128 / 128 x 64
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
         lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, _st())
         if out is None:

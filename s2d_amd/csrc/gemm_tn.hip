@@ -40,9 +40,13 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
     lo = __builtin_bit_cast(unsigned int, l);
 }
 
-__global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
+// BNs = 128 (outputs at least 128 columns wide): a wave owns 64 x 64 of a 128 x 128 tile -- per 32 contraction rows 24 MFMAs against 8
+// loads, 16 splits and 32 LDS stores per thread, where the 128 x 64 tile has 12 MFMAs against 6 loads, 12 splits and 24 stores: the
+// transposing / splitting work per MFMA is what bounds this kernel, not the MFMAs.
+template <int BNs>
+__global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(TnParams p)
 {
-    constexpr int BM = 128, BNs = 64;
+    constexpr int BM = 128, NB = BNs / 64;                  // NB: 32-column MFMA tiles per wave along the output columns
     __shared__ __attribute__((aligned(16))) unsigned int As[BM * TROWW];
     __shared__ __attribute__((aligned(16))) unsigned int Bs[BNs * TROWW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,10 +64,11 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
     // (a half-wave = 8 column groups x 4 row pairs: its 32 transposing stores land in 32 different banks, its loads are 128-B runs)
     const int ca = (tid & 7) | (((tid >> 5) & 3) << 3), ra_ = ((tid >> 3) & 3) | ((tid >> 7) << 2);
     // B tile: 32 rows x 64 columns; a thread takes 4 columns of the row pair (2 rb, 2 rb + 1)
-    const int cb = (tid & 7) | (((tid >> 5) & 1) << 3), rb_ = ((tid >> 3) & 3) | ((tid >> 6) << 2);
+    // (BNs = 128: the A tile's mapping)
+    const int cb = BNs == 128 ? ca : (tid & 7) | (((tid >> 5) & 1) << 3), rb_ = BNs == 128 ? ra_ : ((tid >> 3) & 3) | ((tid >> 6) << 2);
     const unsigned int a_col = (unsigned int)(m0 + 4 * ca), b_col = (unsigned int)(n0 + 4 * cb);
     const unsigned int a_bad = a_col < (unsigned int)p.Mo ? 0u : TOOB, b_bad = b_col < (unsigned int)p.No ? 0u : TOOB;
-    f32x4 va[4], vb[2];
+    f32x4 va[4], vb[2 * NB];
     auto load_tile = [&](int kt) {
         const long r = r_lo + (long)kt * TBK;
 #pragma unroll
@@ -75,11 +80,13 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
                 va[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long m = r + 2 * rb_ + t;
-            const unsigned int off = (unsigned int)((m * p.ldb + b_col) * 4L) | b_bad | (m < r_hi && m < p.rowsB ? 0u : TOOB);
-            vb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
-        }
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long m = r + 2 * rb_ + t + 16 * i;
+                const unsigned int off = (unsigned int)((m * p.ldb + b_col) * 4L) | b_bad | (m < r_hi && m < p.rowsB ? 0u : TOOB);
+                vb[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
+            }
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -92,36 +99,47 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
                 row[0] = hi; row[16] = lo;
             }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned int hi, lo;
-            split_pair(vb[0][j], vb[1][j], hi, lo);
-            unsigned int *row = &Bs[(16 * j + cb) * TROWW + rb_];                    // column 4 cb + j lives in LDS row 16 j + cb
-            row[0] = hi; row[16] = lo;
-        }
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned int hi, lo;
+                split_pair(vb[2 * i][j], vb[2 * i + 1][j], hi, lo);
+                unsigned int *row = &Bs[((BNs / 4) * j + cb) * TROWW + rb_ + 8 * i];    // column 4 cb + j lives in LDS row (BNs / 4) j + cb
+                row[0] = hi; row[16] = lo;
+            }
     };
-    f32x16 accm[2], accx[2];
+    f32x16 accm[2][NB], accx[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accx[i][r] = 0.f; }
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][t][r] = 0.f; accx[i][t][r] = 0.f; }
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
         store_tile();
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
         const unsigned int *as = &As[(wm * 64 + l32) * TROWW + 4 * h];
-        const unsigned int *bs = &Bs[(wn * 32 + l32) * TROWW + 4 * h];
+        const unsigned int *bs = &Bs[(wn * 32 * NB + l32) * TROWW + 4 * h];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f16x8 bh = *reinterpret_cast<const f16x8 *>(bs + 8 * s);
-            const f16x8 bl = *reinterpret_cast<const f16x8 *>(bs + 16 + 8 * s);
+            f16x8 bh[NB], bl[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                bh[t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * TROWW + 8 * s);
+                bl[t] = *reinterpret_cast<const f16x8 *>(bs + t * 32 * TROWW + 16 + 8 * s);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f16x8 ah = *reinterpret_cast<const f16x8 *>(as + i * 32 * TROWW + 8 * s);
                 const f16x8 al = *reinterpret_cast<const f16x8 *>(as + i * 32 * TROWW + 16 + 8 * s);
-                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i], 0, 0, 0);
-                accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[i], 0, 0, 0);
-                accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[i], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    accx[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t], accx[i][t], 0, 0, 0);
+                    accx[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t], accx[i][t], 0, 0, 0);
+                    accm[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t], accm[i][t], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -129,16 +147,20 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f16x3_kernel(TnParams p)
     float *C = p.C + (long)blockIdx.y * p.sC;
     // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
     // (the permutation that spreads the transposing stores over the banks); undo it here
-    const int col = n0 + 4 * (l32 & 15) + 2 * wn + (l32 >> 4);
-    if (col >= p.No) return;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tn = 0; tn < NB; ++tn) {
+        // BNs = 128: LDS row c = 64 wn + 32 tn + l32 of the B image <-> output column 4 (c % 32) + c / 32
+        const int col = BNs == 128 ? n0 + 4 * l32 + 2 * wn + tn : n0 + 4 * (l32 & 15) + 2 * wn + (l32 >> 4);
+        if (col >= p.No) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int row = m0 + 4 * rr + 2 * wm + tm;
-            if (row < p.Mo) C[(long)row * p.No + col] = accm[tm][r] + accx[tm][r] * (1.0f / 2048.0f);
-        }
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + 4 * rr + 2 * wm + tm;
+                if (row < p.Mo) C[(long)row * p.No + col] = accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+            }
+    }
 }
 
 }  // namespace
@@ -156,7 +178,10 @@ extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, 
     const long S = (rowsA + chunk - 1) / chunk;
     if (S > 65535) return S2D_ERR_ARG;
     TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk, slice_stride};
-    hipLaunchKernelGGL(gemm_tn_f16x3_kernel, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+    static int wide = -1;                                   // S2D_TN_WIDE=0: the 128 x 64 tile for every shape (A/B runs)
+    if (wide < 0) { const char *e = getenv("S2D_TN_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide && No >= 128) hipLaunchKernelGGL(gemm_tn_f16x3_kernel<128>, dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_tn_f16x3_kernel<64>, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
