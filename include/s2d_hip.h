@@ -483,8 +483,8 @@ int s2d_optim_adamw_ema_f32(const void *const *ptrs, const long *numel, const do
  * [NL*B*min(Q,Nmax)*T][hm*wm] = d(w_mask * loss_mask + w_dice * loss_dice, all layers) / d(logit map of row
  * ((layer*B + b)*maxm + slot)*T + t); rows of unmatched slots and dropped frames are zero.  The selected points are
  * exactly the forward's (same threshold, same tie rule); their gradients are scattered through the bilinear taps into an
- * LDS tile (half a row plane at a time) and written out once.  bit_scratch: 512 * H*W/32 words.  Only for passes whose active
- * rows all took the stored-sample path. */
+ * LDS tile (one map part at a time) and written out once.  bit_scratch: unused (may be NULL) -- the forward leaves every target
+ * plane of the pass bit-packed in the workspace.  Only for passes whose active rows all took the stored-sample path. */
 int s2d_point_loss_backward_f32(const float *mask_logits, const uint8_t *tgt, const int *tgt_count, const int *nonempty,
                                 const int *idx_q, const int *idx_t, const int *n_match, const float *coords_over,
                                 const float *coords_rand, uint64_t seed, int NL, int B, int Q, int ldq, int T, int hm, int wm,

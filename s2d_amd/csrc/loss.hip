@@ -246,7 +246,8 @@ struct LossParams {
     float *part;              // [rows][chunks][4]
     int chunks;
     float *xbuf;              // [xcap][n_over + n_rand]: sampled logits of the first xcap active rows (sampled ONCE)
-    unsigned int *bits_global; // [ACC_BLOCKS][H*W/32] or null: the accumulate pass's bit-packed target plane when it does not fit LDS
+    unsigned int *tpack;       // [B][Nmax][T][H*W/32]: every target plane of the pass bit-packed once (pack_planes_kernel); bit i of word w = pixel 32 w + i
+    int bits_global;           // the accumulate pass reads a row's plane from tpack directly (it does not fit LDS) instead of copying it to LDS
     int xcap;
     int *pbound;              // [rows][PB_STRIDE]: RNG mode, first oversampled-point index of every map part of the row (strata)
 };
@@ -894,6 +895,30 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
     }
 }
 
+// every target plane of the pass (clip b, target n < count[b], frame t) as bits, once: one thread = 32 pixels = one word
+__global__ __launch_bounds__(256) void pack_planes_kernel(LossParams p)
+{
+    const long HW = (long)p.H * p.W, wpp = HW / 32;
+    const int plane = blockIdx.y;                              // (b * Nmax + n) * T + t
+    const int n = (plane / p.T) % p.Nmax, b = plane / (p.T * p.Nmax);
+    if (n >= min(p.tgt_count[b], p.Nmax)) return;
+    const long wd = (long)blockIdx.x * 256 + threadIdx.x;
+    if (wd >= wpp) return;
+    const uint8_t *pl = p.tgt + (long)plane * HW;
+    const uint4 a = reinterpret_cast<const uint4 *>(pl)[wd * 2], c = reinterpret_cast<const uint4 *>(pl)[wd * 2 + 1];
+    const unsigned int ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    unsigned int out = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned int w4 = ws[k];
+        out |= ((w4 & 0xFFu) ? 1u : 0u) << (4 * k);
+        out |= ((w4 & 0xFF00u) ? 1u : 0u) << (4 * k + 1);
+        out |= ((w4 & 0xFF0000u) ? 1u : 0u) << (4 * k + 2);
+        out |= ((w4 & 0xFF000000u) ? 1u : 0u) << (4 * k + 3);
+    }
+    p.tpack[(long)plane * wpp + wd] = out;
+}
+
 // accumulate for rows with stored samples: item = row.  The row's whole target plane is bit-packed into LDS
 // (H*W/8 bytes: 118 KB at 736x1280), the stored logits are streamed, only (u,v) is regenerated for the target taps.
 // BWD = true: the same walk over the same selected points (same threshold, same tie rule), but instead of summing the loss
@@ -904,10 +929,10 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
 struct LossBwdArgs {
     float *gplane;            // [rows][hm*wm], zero-initialised
     float w_mask, w_dice;     // loss weights (weight_dict) of loss_mask / loss_dice
-    unsigned int *bit_scratch; // [gridDim.x][H*W/32]: the row's bit-packed target plane (LDS holds the gradient tile instead)
+    unsigned int *bit_scratch; // unused since the planes are packed once per pass (LossParams::tpack); kept for the entry point's signature
 };
-// GBITS: the row's bit-packed target plane lives in global scratch (backward: LDS holds the gradient tile; forward: frames beyond
-// 1.15 M pixels), read back coherently, instead of in the dynamic LDS
+// GBITS: the row's bit-packed target plane is read in place from the pass's packed planes (backward: LDS holds the gradient tile;
+// forward: frames beyond 1.15 M pixels) instead of from a copy in the dynamic LDS
 template <bool BWD, bool GBITS = BWD>
 __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams p, LossBwdArgs ba)
 {
@@ -930,7 +955,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
     const PartGeom sg_ = part_geom(p.hm, p.wm);
     if ((int)threadIdx.x < sg_.nparts) { const VRange vr = part_vrange(threadIdx.x, sg_.nparts, sg_.rows_per_part, p.hm); s_v0[threadIdx.x] = vr.v0; s_dv[threadIdx.x] = vr.dv; }
     static_assert(GBITS || !BWD, "the backward keeps its gradient tile in the dynamic LDS");
-    unsigned int *tb = GBITS ? (BWD ? ba.bit_scratch : p.bits_global) + (long)blockIdx.x * (HW / 32) : tbits;
+    const unsigned int *tb = tbits;                           // GBITS: the row's words in p.tpack (set per row below)
     // BWD: the dynamic LDS is the gradient tile [hh][wm], accumulated in FIXED POINT (int32, LDS integer atomics): integer sums
     // do not depend on the order the points arrive in, so the gradient is bitwise reproducible -- float atomics made it the last
     // gradient of the training step that was not.  Scale per row: a power of two such that FX_CAP tap weights of the largest
@@ -961,26 +986,17 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         const int t = r % p.T, s = (r / p.T) % p.maxm, b = r / (p.T * p.maxm);
         const int prob = layer * p.B + b;
         const int n = p.idx_t[(long)prob * p.maxm + s];
-        const uint8_t *pl = p.tgt + (((long)b * p.Nmax + n) * p.T + t) * HW;
+        // the row's target plane as bits: packed once per criterion pass for every (clip, target, frame) by pack_planes_kernel -- each
+        // plane is the target of up to NL rows -- and copied to LDS here (H * W / 8 bytes instead of H * W read per row), or read in place
+        const unsigned int *pk = p.tpack + (((long)b * p.Nmax + n) * p.T + t) * (HW / 32);
         __syncthreads();
         if (threadIdx.x < PB_STRIDE) s_pb[threadIdx.x] = p.pbound[rowid * PB_STRIDE + threadIdx.x];   // visible after the barrier below
-        // bit-pack the plane: each thread turns 32 bytes (two 16-B loads) into one word
+        if constexpr (GBITS) tb = pk;
+        else {
 #pragma unroll 4
-        for (long wd = threadIdx.x; wd < HW / 32; wd += LTHREADS) {
-            const uint4 a = reinterpret_cast<const uint4 *>(pl)[wd * 2], c = reinterpret_cast<const uint4 *>(pl)[wd * 2 + 1];
-            const unsigned int ws[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-            unsigned int out = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned int w4 = ws[k];
-                out |= ((w4 & 0xFFu) ? 1u : 0u) << (4 * k);
-                out |= ((w4 & 0xFF00u) ? 1u : 0u) << (4 * k + 1);
-                out |= ((w4 & 0xFF0000u) ? 1u : 0u) << (4 * k + 2);
-                out |= ((w4 & 0xFF000000u) ? 1u : 0u) << (4 * k + 3);
-            }
-            tb[wd] = out;
+            for (long w4 = threadIdx.x; w4 < HW / 128; w4 += LTHREADS) reinterpret_cast<uint4 *>(tbits)[w4] = reinterpret_cast<const uint4 *>(pk)[w4];
+            for (long wd = (HW / 128) * 4 + threadIdx.x; wd < HW / 32; wd += LTHREADS) tbits[wd] = pk[wd];
         }
-        if constexpr (GBITS) __threadfence();
         if (threadIdx.x == 0) { tie_n = 0u; tie_base = 0u; }
         __syncthreads();
         const unsigned int thr = p.prefix[rowid];
@@ -1086,7 +1102,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
                     v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
                 }
-                point(xv, sample_bits<GBITS>(tb, p.H, p.W, u, v), u, v);
+                point(xv, sample_bits(tb, p.H, p.W, u, v), u, v);
             };
             // Only ~1 in 4 oversampled points passes the threshold, scattered over the lanes: evaluating them in place
             // would run the heavy path at 25 % lane utilisation.  Each wave instead compacts its selected points (ballot
@@ -1188,7 +1204,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
                 if (BWD && !ranged_ties) { const int y0 = y0_of(v); if (y0 < own_lo || y0 >= own_hi) return; }
-                point(xb[i], sample_bits<GBITS>(tb, p.H, p.W, u, v), u, v);
+                point(xb[i], sample_bits(tb, p.H, p.W, u, v), u, v);
             };
             if (nties <= (unsigned int)TIECAP) {
                 for (unsigned int j = threadIdx.x; j < nties; j += LTHREADS) {
@@ -1397,7 +1413,7 @@ long s2d_point_loss_workspace_bytes(int NL, int B, int Q, int Nmax, int T, int h
     const long xrows = rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS;
     const long HW = (long)H * W;
     return rows * (3 * 4 + (long)hm * wm * 4 + 2048 * 4 + 4 + 4 + 4 + LOSS_CHUNKS * 16 + PB_STRIDE * 4) + 4L * (NL + 1) + 1024 +
-           xrows * (long)(n_over + n_rand + 8) * 4 + (plane_in_lds(HW) ? 0 : 256 + (long)ACC_BLOCKS * (HW / 32) * 4);
+           xrows * (long)(n_over + n_rand + 8) * 4 + 256 + (long)B * Nmax * T * (HW / 32 + 1) * 4;      // + the packed target planes
 }
 
 // parameter block + workspace carve-up shared by the forward and the backward entry points (same arguments, same layout)
@@ -1434,11 +1450,11 @@ static int loss_setup(LossParams &p, long &rows, const float *mask_logits, const
     // beside ~13 KB of static LDS: up to 1.15 M pixels) and from a per-workgroup scratch behind the sample buffer otherwise
     const bool can_stream = (p.n_over % 4 == 0) && (p.n_rand % 4 == 0) && ((long)H * W % 32 == 0);
     p.xcap = can_stream ? (int)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) : 0;
-    p.bits_global = nullptr;
-    if (can_stream && !plane_in_lds((long)H * W)) {
-        char *e = (char *)p.xbuf + (long)p.xcap * (p.n_over + p.n_rand + 8) * 4;
-        p.bits_global = (unsigned int *)(((uintptr_t)e + 255) & ~(uintptr_t)255);
+    {
+        char *e = (char *)p.xbuf + (long)(rows < XBUF_MAX_ROWS ? rows : XBUF_MAX_ROWS) * (p.n_over + p.n_rand + 8) * 4;
+        p.tpack = (unsigned int *)(((uintptr_t)e + 255) & ~(uintptr_t)255);
     }
+    p.bits_global = can_stream && !plane_in_lds((long)H * W);
     const PartGeom pg = part_geom(hm, wm);
     if ((wm & 3) || pg.rows_per_part < 1 || pg.nparts > LOSS_CHUNKS) return S2D_ERR_ARG;
     p.chunks = pg.nparts;
@@ -1495,6 +1511,8 @@ int s2d_point_loss_f32(const float *mask_logits, const uint8_t *tgt, const int *
     if (p.xcap > 0) hipLaunchKernelGGL(hist_stream_kernel<2>, dim3(2048), dim3(256), 0, stream, p);
     if (rows > p.xcap) hipLaunchKernelGGL(hist_kernel<2>, g, dim3(LTHREADS), lds_hist, stream, p);
     hipLaunchKernelGGL(select_kernel<2>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+    if (p.xcap > 0)
+        hipLaunchKernelGGL(pack_planes_kernel, dim3(cdiv((long)H * W / 32, 256), B * Nmax * T), dim3(256), 0, stream, p);
     if (p.xcap > 0 && !p.bits_global)
         hipLaunchKernelGGL(accumulate_stream_kernel<false>, dim3(ACC_BLOCKS), dim3(LTHREADS), (size_t)((long)H * W / 8), stream, p, LossBwdArgs{nullptr, 0.f, 0.f, nullptr});
     else if (p.xcap > 0)

@@ -681,9 +681,7 @@ def point_loss_backward(ctx, w_mask, w_dice):
     if active > min(rows, 4096):
         raise NotImplementedError(f"{active} matched (layer, target, frame) rows in one criterion pass: the gradient path keeps 4096")
     g = torch.empty((rows, hm * wm), device=ctx[0].device, dtype=torch.float32)
-    H, W = ctx[17], ctx[18]
-    scratch = torch.empty((512 * (H * W // 32),), device=ctx[0].device, dtype=torch.int32)
-    lib().call("s2d_point_loss_backward_f32", *ctx, float(w_mask), float(w_dice), g, scratch, _stream())
+    lib().call("s2d_point_loss_backward_f32", *ctx, float(w_mask), float(w_dice), g, None, _stream())
     return g
 
 
