@@ -593,6 +593,10 @@ __device__ __forceinline__ float sample_part(const float *__restrict__ sm, int h
     return acc;
 }
 
+// timing experiments only (scripts/build_loss_dbg.sh; results wrong by construction): 1 no histogram atomics, 2 no LDS taps, 4 no sample store
+#ifndef S2D_LOSS_DBG
+#define S2D_LOSS_DBG 0
+#endif
 // level 0: bits 30..20, level 1: bits 19..10, level 2: bits 9..0 of |x|
 template <int LEVEL>
 __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
@@ -623,7 +627,8 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
         auto tally = [&](int i, float xv) {
             const unsigned int key = __float_as_uint(fabsf(xv));
-            if (LEVEL == 0 && li < p.xcap) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
+            if (LEVEL == 0 && li < p.xcap && !(S2D_LOSS_DBG & 4)) p.xbuf[(long)li * (p.n_over + p.n_rand) + i] = xv;
+            if ((S2D_LOSS_DBG & 1) && LEVEL == 0) { if (key == 0x12345u) h[0] = 1u; return; }
             if (LEVEL == 0) atomicAdd(&h[key >> 20], 1u);
             else if (LEVEL == 1) { if ((key >> 20) == (pre >> 20)) atomicAdd(&h[(key >> 10) & 1023u], 1u); }
             else { if ((key >> 10) == (pre >> 10)) atomicAdd(&h[key & 1023u], 1u); }
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
                 const int y0 = min(max((int)floorf(y), ylo), y0max);
+                if (S2D_LOSS_DBG & 2) tally(i, x * y + (float)y0); else
                 tally(i, sample_part_padded(sm, wp, r0, x, y, (int)floorf(x), y0));
             }
         } else {
