@@ -402,9 +402,11 @@ int s2d_rle_strings_u8(const int *positions, const long *frame_off, int F, long 
  * a view that starts some rows later, e.g. a convolution tap on the padded grid).  Same split-fp16 x3 arithmetic as
  * s2d_gemm_nt_f32 mode 2.  Slice s writes its [Mo][No] tile at C_slices + s * slice_stride (0 = Mo * No; larger: several
  * launches -- the taps of a convolution -- interleave their tiles so that one s2d_reduce_slices_f32 finishes them all).
- * Mo, No, lda, ldb multiples of 4; A, B 16-B aligned; each operand < 4 GiB. */
+ * Mo, No, lda, ldb multiples of 4; A, B 16-B aligned; each operand < 4 GiB.
+ * colsum_slices (optional, [slices][Mo]): slice s also leaves the column sums of its rows of A -- the bias gradient of the same dY
+ * (s2d_reduce_slices_f32 adds the slices) -- so dY is not read a second time for it. */
 int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
-                    long chunk, long slice_stride, hipStream_t stream);
+                    long chunk, long slice_stride, float *colsum_slices, hipStream_t stream);
 
 /* out[c][r] = in[r][c]; in [R][ldi], out [C][ldo].  dW = dY^T . X runs as an NT GEMM on the transposed operands. */
 int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream);

@@ -38,6 +38,22 @@ def acc_wgrad(param, dy, x):
         acc(param, weight_grad(dy, x))
 
 
+def acc_wbgrad(wparam, bparam, dy, x):
+    """acc_wgrad + acc_bgrad of one linear layer with ONE pass over dy (the bias gradient rides in the weight gradient's kernel)"""
+    gw, gb = wparam.grad, bparam.grad
+    N, K = dy.shape[1], x.shape[1]
+    if (gw is not None and gw.is_contiguous() and gw.numel() == N * K and gw.dtype == torch.float32 and
+            gb is not None and gb.is_contiguous() and gb.numel() == N and gb.dtype == torch.float32):
+        weight_grad(dy, x, out=gw.view(N, K), beta=1.0, bias_out=gb.view(-1), bias_beta=1.0)
+    elif gw is None and gb is None:
+        db = torch.empty((N,), device=dy.device, dtype=torch.float32)
+        acc(wparam, weight_grad(dy, x, bias_out=db))
+        acc(bparam, db)
+    else:
+        acc_wgrad(wparam, dy, x)
+        acc_bgrad(bparam, dy)
+
+
 def acc_bgrad(param, dy):
     """param.grad += column sums of dy (see acc_wgrad)"""
     g = param.grad
@@ -81,8 +97,9 @@ def _tn_ok(M, N, K):
     return N % 4 == 0 and K % 4 == 0 and M * N * 4 <= 0xFFFFFF00 and M * K * 4 <= 0xFFFFFF00
 
 
-def weight_grad(dy, x, out=None, beta=0.0):
-    """dW [N,K] = dy[M,N]^T @ x[M,K]  (out given: out = beta * out + dW)"""
+def weight_grad(dy, x, out=None, beta=0.0, bias_out=None, bias_beta=0.0):
+    """dW [N,K] = dy[M,N]^T @ x[M,K]  (out given: out = beta * out + dW).  bias_out [N] given: also bias_out = bias_beta * bias_out +
+    column sums of dy -- inside the TN kernel, which has dy in registers anyway, instead of a second pass over it."""
     ops._chk(dy); ops._chk(x)
     M, N = dy.shape
     K = x.shape[1]
@@ -90,12 +107,17 @@ def weight_grad(dy, x, out=None, beta=0.0):
     if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # no transposed copies: the TN kernel
         S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128 if K >= 128 else (K + 63) // 64))      # the TN kernel's tiles: 128 x 128 / 128 x 64
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
-        lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, _st())
+        bpart = torch.empty((S, N), device=dy.device, dtype=torch.float32) if bias_out is not None else None
+        lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, bpart, _st())
         if out is None:
             out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
             beta = 0.0
         lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
+        if bias_out is not None:
+            lib().call("s2d_reduce_slices_f32", bpart, S, N, N, float(bias_beta), bias_out, _st())
         return out
+    if bias_out is not None:
+        bias_grad(dy, out=bias_out, beta=bias_beta)
     S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128))
     Mp = S * chunk
     dyt, xt = transpose(dy, Mp), transpose(x, Mp)
@@ -272,7 +294,7 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
             for kx in range(KW):
                 shift = ky * Wp + kx                                   # the tap: B starts `shift` grid positions later
                 lib().call("s2d_gemm_tn_f32", dg, xp.data_ptr() + shift * Ci * 4, part.data_ptr() + (ky * KW + kx) * Co * Ci * 4, Co, Ci, P,
-                           P - shift, Co, Ci, chunk, taps * Co * Ci, _st())
+                           P - shift, Co, Ci, chunk, taps * Co * Ci, None, _st())
         dw = torch.empty((taps, Co, Ci), device=x.device, dtype=torch.float32)
         lib().call("s2d_reduce_slices_f32", part, S, taps * Co * Ci, taps * Co * Ci, 0.0, dw, _st())    # one reduction for all taps
         return dw.view(KH, KW, Co, Ci).permute(2, 0, 1, 3).contiguous()

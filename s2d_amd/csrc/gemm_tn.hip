@@ -28,6 +28,7 @@ struct TnParams {
     long rowsA, rowsB;          // contraction rows available in A / B (B may be shorter: shifted view)
     long lda, ldb, chunk;
     long sC;                    // elements between the partial tiles of consecutive slices (>= Mo * No)
+    float *colsum;              // optional [slices][Mo]: per-slice column sums of A (the bias gradient of the same dY), or NULL
 };
 
 // hi / lo fp16 pairs of two values that are consecutive along the contraction
@@ -69,6 +70,10 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
     const unsigned int a_col = (unsigned int)(m0 + 4 * ca), b_col = (unsigned int)(n0 + 4 * cb);
     const unsigned int a_bad = a_col < (unsigned int)p.Mo ? 0u : TOOB, b_bad = b_col < (unsigned int)p.No ? 0u : TOOB;
     f32x4 va[4], vb[2 * NB];
+    // column sums of A ride along in the workgroups of the first column tile: dY is in registers here anyway (a separate pass would
+    // read it again: 1.27 GB for the encoder's linear1)
+    const bool do_cs = p.colsum != nullptr && (blockIdx.x % tiles_n) == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int kt) {
         const long r = r_lo + (long)kt * TBK;
 #pragma unroll
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
             }
     };
     auto store_tile = [&]() {
+        if (do_cs) cs += (va[0] + va[1]) + (va[2] + va[3]);          // rows past the slice read as zero
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -144,6 +150,17 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
         }
         __syncthreads();
     }
+    if (do_cs) {                                             // the 8 threads that share 4 columns, added in a fixed order (As is free: the loop ended on a barrier)
+        float *red = reinterpret_cast<float *>(As);              // [8][128]
+        *reinterpret_cast<f32x4 *>(red + ra_ * 128 + 4 * ca) = cs;
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.Mo) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
+            p.colsum[(long)blockIdx.y * p.Mo + m0 + tid] = t;
+        }
+    }
     float *C = p.C + (long)blockIdx.y * p.sC;
     // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
     // (the permutation that spreads the transposing stores over the banks); undo it here
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
 }  // namespace
 
 extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
-                               long chunk, long slice_stride, hipStream_t stream)
+                               long chunk, long slice_stride, float *colsum_slices, hipStream_t stream)
 {
     if (slice_stride == 0) slice_stride = (long)Mo * No;
     if (slice_stride < (long)Mo * No) return S2D_ERR_ARG;
@@ -177,7 +194,7 @@ extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, 
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return S2D_ERR_ARG;
     const long S = (rowsA + chunk - 1) / chunk;
     if (S > 65535) return S2D_ERR_ARG;
-    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk, slice_stride};
+    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk, slice_stride, colsum_slices};
     static int wide = -1;                                   // S2D_TN_WIDE=0: the 128 x 64 tile for every shape (A/B runs)
     if (wide < 0) { const char *e = getenv("S2D_TN_WIDE"); wide = e ? atoi(e) : 1; }
     if (wide && No >= 128) hipLaunchKernelGGL(gemm_tn_f16x3_kernel<128>, dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);

@@ -100,18 +100,17 @@ class MSDeformAttn(nn.Module):
         n_off = self.sampling_offsets.weight.shape[0]
         d2 = d_out.reshape(-1, C)                                         # d(src + dropout1(proj)): the residual path takes it as is
         dm = d2 if drop is None or drop[0] <= 0.0 else ops.dropout(d2, *drop)   # d(proj): the forward's mask, regenerated
-        B.acc_wgrad(self.output_proj.weight, dm, samp.view(-1, C))
-        B.acc_bgrad(self.output_proj.bias, dm)
+        B.acc_wbgrad(self.output_proj.weight, self.output_proj.bias, dm, samp.view(-1, C))
         d_samp = B.input_grad(dm, self.output_proj.weight).view(N, S, C)
         d_val, d_oa = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points)
         d_both = torch.cat([d_oa, d_val], -1).view(-1, n_oa + C)
-        dw = B.weight_grad(d_both, src.view(-1, C))                       # rows: offsets | logits | value
+        db = torch.empty((n_oa + C,), device=src.device, dtype=torch.float32)
+        dw = B.weight_grad(d_both, src.view(-1, C), bias_out=db)          # rows: offsets | logits | value; the bias gradient in the same pass
         d_pos_oa = B.sum_slices(d_oa)                                     # the row-periodic term: same pos row for every frame
         dw_pos = B.weight_grad(d_pos_oa.contiguous(), pos.view(S, C))
         B.acc(self.sampling_offsets.weight, dw[:n_off] + dw_pos[:n_off])
         B.acc(self.attention_weights.weight, dw[n_off:n_oa] + dw_pos[n_off:])
         B.acc(self.value_proj.weight, dw[n_oa:])
-        db = B.bias_grad(d_both)
         B.acc(self.sampling_offsets.bias, db[:n_off])
         B.acc(self.attention_weights.bias, db[n_off:n_oa])
         B.acc(self.value_proj.bias, db[n_oa:])
@@ -199,11 +198,11 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         B.acc(self.norm2.weight, dg); B.acc(self.norm2.bias, db)
         d2 = d_x2.view(-1, C)                                           # d(s1 + dropout3(linear2)): the residual takes it as is
         dm = ops.dropout(d2, p, seed, 2) if p > 0.0 else d2               # d(linear2 output)
-        B.acc_wgrad(self.linear2.weight, dm, h); B.acc_bgrad(self.linear2.bias, dm)
+        B.acc_wbgrad(self.linear2.weight, self.linear2.bias, dm, h)
         # h = dropout2(relu(z)) = relu(z) * m / (1 - p): positive exactly where the unit is active AND kept, so the ReLU
         # gate on h is the combined gate and the dropout factor is a constant per-channel scale
         d_h = B.input_grad(dm, self.linear2.weight, gate=h, gate_scale=1.0 / (1.0 - p) if p > 0.0 else 1.0)
-        B.acc_wgrad(self.linear1.weight, d_h, s1.view(-1, C)); B.acc_bgrad(self.linear1.bias, d_h)
+        B.acc_wbgrad(self.linear1.weight, self.linear1.bias, d_h, s1.view(-1, C))
         d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
         d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)
         B.acc(self.norm1.weight, dg); B.acc(self.norm1.bias, db)

@@ -84,7 +84,7 @@ class SelfAttentionLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc_wgrad(m.out_proj.weight, d2, a.view(-1, C)); Bk.acc_bgrad(m.out_proj.bias, d2)
+        Bk.acc_wbgrad(m.out_proj.weight, m.out_proj.bias, d2, a.view(-1, C))
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
         dq, dk, dv = Bk.masked_attn_backward(q, qk[..., C:], v, a, lse, d_a, H=self.nhead)
         d_qk = torch.cat([dq, dk], -1).view(-1, 2 * C)
@@ -131,7 +131,7 @@ class CrossAttentionLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc_wgrad(m.out_proj.weight, d2, a.view(-1, C)); Bk.acc_bgrad(m.out_proj.bias, d2)
+        Bk.acc_wbgrad(m.out_proj.weight, m.out_proj.bias, d2, a.view(-1, C))
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
         dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead)
         dq2 = dq.view(-1, C)
@@ -166,9 +166,9 @@ class FFNLayer(nn.Module):
         d_x, dg, db = Bk.layernorm_backward(x.view(B, Q, C), d_out.contiguous(), self.norm.weight)
         Bk.acc(self.norm.weight, dg); Bk.acc(self.norm.bias, db)
         d2 = d_x.view(-1, C)
-        Bk.acc_wgrad(self.linear2.weight, d2, h); Bk.acc_bgrad(self.linear2.bias, d2)
+        Bk.acc_wbgrad(self.linear2.weight, self.linear2.bias, d2, h)
         d_h = Bk.input_grad(d2, self.linear2.weight, gate=h)
-        Bk.acc_wgrad(self.linear1.weight, d_h, tgt.view(-1, C)); Bk.acc_bgrad(self.linear1.bias, d_h)
+        Bk.acc_wbgrad(self.linear1.weight, self.linear1.bias, d_h, tgt.view(-1, C))
         return Bk.input_grad(d_h, self.linear1.weight, res=d2).view(B, Q, C)
 
 
@@ -191,7 +191,7 @@ class MLP(nn.Module):
         from .. import backward as Bk
         for i in reversed(range(len(self.layers))):
             l = self.layers[i]
-            Bk.acc_wgrad(l.weight, d, acts[i]); Bk.acc_bgrad(l.bias, d)
+            Bk.acc_wbgrad(l.weight, l.bias, d, acts[i])
             d = Bk.input_grad(d, l.weight, gate=acts[i] if i > 0 else None)      # acts[i] (i > 0) is the ReLU output feeding layer i
         return d
 
@@ -304,7 +304,8 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             dk2, dv2 = d_ks[lvl].view(-1, d_ks[lvl].shape[-1]), d_vs[lvl].view(-1, d_vs[lvl].shape[-1])
             kin2, x2 = kins[lvl].view(-1, C), xs[lvl].reshape(-1, C)
             le = self.level_embed.weight[lvl:lvl + 1].detach().contiguous()
-            dWk, dbk = Bk.weight_grad(dk2, kin2), Bk.bias_grad(dk2)
+            dbk = torch.empty((dk2.shape[1],), device=dk2.device, dtype=torch.float32)
+            dWk = Bk.weight_grad(dk2, kin2, bias_out=dbk)
             dbv = Bk.bias_grad(dv2)                                                # also d(level_embed . Wv^T + bv)
             dWv = Bk.weight_grad(dv2, x2) + dbv[:, None] * le                      # + outer(d bracket, level_embed)
             d_kin = Bk.input_grad(dk2, wk)

@@ -38,6 +38,26 @@ def test_linear_backward_vs_autograd(M, N, K):
     assert rel(acc.cpu().numpy(), 2 * wd.grad.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 256, 256), (1234, 544, 256), (70000, 1024, 256), (999, 64, 128), (4096, 132, 64)])
+def test_bias_gradient_inside_the_weight_gradient_kernel(M, N, K):
+    """weight_grad(bias_out=...): the column sums of dY leave the TN kernel with the weight gradient (one pass over dY) -- against a
+    float64 column sum, with accumulation into existing gradients (beta = 1), and the weight gradient itself unchanged by the option"""
+    from s2d_amd import backward as B
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy = torch.randn((M, N), device=DEV, generator=g)
+    x = torch.randn((M, K), device=DEV, generator=g)
+    ref = dy.double().sum(0)
+    db = torch.full((N,), 3.0, device=DEV)
+    dw = B.weight_grad(dy, x, bias_out=db, bias_beta=1.0)
+    assert float((db.double() - 3.0 - ref).abs().max()) < 2e-6 * float(dy.abs().sum(0).max())
+    assert torch.equal(dw, B.weight_grad(dy, x))
+    db2 = torch.empty((N,), device=DEV)
+    B.weight_grad(dy, x, bias_out=db2)
+    db3 = torch.empty((N,), device=DEV)
+    B.weight_grad(dy, x, bias_out=db3)
+    assert torch.equal(db2, db3)
+
+
 def test_transpose_odd_shapes():
     from s2d_amd import backward
     for R, C, pad in ((1, 1, None), (65, 130, None), (1000, 37, 1024), (129, 64, 160)):
