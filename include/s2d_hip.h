@@ -167,6 +167,12 @@ int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host,
                                  const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
                                  int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
                                  long workspace_bytes, hipStream_t stream);
+/* The same with row strides: value rows (n, s) are M * D floats at stride ldv, grad_value rows at stride ldg (column slices of
+ * the merged projection output / of its gradient buffer: no contiguous copy of value, no concatenation of the gradients). */
+int s2d_msda_backward_sorted_strided_f32(const float *value, long ldv, const int64_t *shapes_host, const int64_t *level_start_host,
+                                         const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                                         int L, int Lq, int P, float *grad_value, long ldg, float *grad_loc, float *grad_attn_w,
+                                         void *workspace, long workspace_bytes, hipStream_t stream);
 
 /* The drop-in op with the reference's own argument kinds: spatial shapes [L,2] and level starts [L] as int64 DEVICE tensors,
  * read inside the kernels exactly as ms_deformable_im2col_gpu_kernel does (ops/src/cuda/ms_deform_attn_cuda.cu:60-75 passes

@@ -386,23 +386,39 @@ def maxpool_backward(x, dy):
 
 
 # --------------------------------------------------------------------------- multi-scale deformable attention (fused form)
-def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4):
+def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4, merged=False):
     """gradients of ops.msda_fused_forward(value [N,S,C], shapes, offs_logits [N,S,>=288]) -> (d_value [N,S,C],
-    d_offs_logits [N,S,M*L*P*3]).  value / offs_logits may be the column slices of the merged projection output."""
+    d_offs_logits [N,S,M*L*P*3]).  value / offs_logits may be the column slices of the merged projection output (read in place
+    through their row stride).  merged=True: both gradients are written into ONE buffer [N,S, M*L*P*3 + C] laid out like the
+    merged projection output (offsets | logits | value) and that buffer is returned with them as its column slices --
+    -> (d_value view, d_offs_logits view, buffer): the projection's weight / input gradients take it without a concatenation."""
     N, S, C = value.shape
     sh = ops._host_i64(shapes)
     L = sh.shape[0]
     D = C // M
     dev = value.device
+    assert value.stride(2) == 1 and value.stride(0) == S * value.stride(1)
     loc = torch.empty((N, S, M, L, P, 2), device=dev, dtype=torch.float32)
     attn = torch.empty((N, S, M, L, P), device=dev, dtype=torch.float32)
     lib().call("s2d_msda_fused_prep_f32", offs_logits, offs_logits.stride(1), sh, N, S, M, L, P, loc, attn, _st())
     lsi = ops._host_i64(torch.cat([torch.zeros(1, dtype=torch.int64), torch.as_tensor(sh).prod(1).cumsum(0)[:-1]]))
-    gv, gl, ga = ops.msda_backward(value.contiguous().view(N, S, M, D), sh, lsi, loc, attn, grad_out.contiguous())
     ldd = M * L * P * 3
-    doa = torch.empty((N, S, ldd), device=dev, dtype=torch.float32)
-    lib().call("s2d_msda_fused_chain_f32", attn, gl, ga, sh, N, S, M, L, P, doa, ldd, _st())
-    return gv.view(N, S, C), doa
+    if merged:
+        buf = torch.empty((N, S, ldd + C), device=dev, dtype=torch.float32)
+        doa, gv, ldo, ldg = buf[..., :ldd], buf[..., ldd:], ldd + C, ldd + C
+    else:
+        buf = None
+        doa = torch.empty((N, S, ldd), device=dev, dtype=torch.float32)
+        gv = torch.empty((N, S, C), device=dev, dtype=torch.float32)
+        ldo, ldg = ldd, C
+    gl, ga = torch.empty_like(loc), torch.empty_like(attn)
+    go = grad_out.contiguous()
+    nb = lib().call("s2d_msda_backward_workspace_bytes", sh, N, M, L, S, P)
+    ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
+    lib().call("s2d_msda_backward_sorted_strided_f32", value, value.stride(1), sh, lsi, loc, attn, go, N, S, M, D, L, S, P, gv, ldg, gl, ga,
+               ws, nb, _st())
+    lib().call("s2d_msda_fused_chain_f32", attn, gl, ga, sh, N, S, M, L, P, doa, ldo, _st())
+    return (gv, doa, buf) if merged else (gv, doa)
 
 
 # --------------------------------------------------------------------------- masked attention

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void msda_cell_bounds_kernel(const unsigned in
 template <class G>
 __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__restrict__ gout, const SampleRec *__restrict__ rec,
                                                              const int *__restrict__ off, G geo, long ntgt, int S, int M, int L,
-                                                             float *__restrict__ gvalue)
+                                                             float *__restrict__ gvalue, long ldg)
 {
     constexpr int D = 32;
     const Levels &lv = geo.levels();
@@ -843,8 +843,9 @@ __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__rest
     const long t = item >> 3;                                       // target row (n, s, m)
     const int c = (int)(item & 7);
     if (t >= ntgt) return;                                          // whole 8-lane groups leave together
+    float *gdst = gvalue + (t / M) * ldg + (t % M) * D + c * 4;       // row (n, s) of grad_value: M * D floats at stride ldg
     if (geo.bad()) {                                                // dev form with rejected shapes: zeros, no indexing by them
-        *reinterpret_cast<f32x4 *>(gvalue + t * D + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(gdst) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const int m = (int)(t % M);
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__rest
             for (int j = 0; j < 8; ++j) acc += wj[j] * g[j];        // fixed order: ascending sample id inside the cell
         }
     }
-    *reinterpret_cast<f32x4 *>(gvalue + t * D + c * 4) = acc;
+    *reinterpret_cast<f32x4 *>(gdst) = acc;
 }
 
 // grad_sampling_loc / grad_attn_weight of the backward, query-owned (cuh:119-163 without the grad_value scatter): the forward's
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(256) void msda_bwd_value_kernel(const float *__rest
 template <class G>
 __global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restrict__ value, G geo, const float *__restrict__ loc,
                                                            const float *__restrict__ aw, const float *__restrict__ gout, int S, int M, int L,
-                                                           int Lq, int P, int blk_per_n, float *__restrict__ gloc, float *__restrict__ gaw)
+                                                           int Lq, int P, int blk_per_n, float *__restrict__ gloc, float *__restrict__ gaw, long ldv)
 {
     constexpr int D = 32;
     const Levels &lv = geo.levels();
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(256) void msda_bwd_loc_kernel(const float *__restri
     const int q = (int)((item >> 3) / M);
     const long qm = ((long)n * Lq + q) * M + m;
     const f32x4 tg = *reinterpret_cast<const f32x4 *>(gout + qm * D + c * 4);
-    const long rowstride = (long)M * D;
+    const long rowstride = ldv;
     const int LP = L * P;
     if (LP <= 16) {
         // as in the fused forward: lane j of the head's 8 prepares samples j and j + 8 (location / weight loads, floor, bilinear
@@ -1196,8 +1197,10 @@ static size_t sorted_ws_layout(long nsamp, long ncell, size_t *o_keys, size_t *o
 template <class G>
 static int launch_backward_sorted(const G &geo, long ncell_cap, const float *value, const float *loc, const float *attn_w,
                                   const float *grad_out, int N, int S, int M, int L, int Lq, int P, float *grad_value, float *grad_loc,
-                                  float *grad_attn_w, char *ws, long workspace_bytes, hipStream_t stream)
+                                  float *grad_attn_w, char *ws, long workspace_bytes, hipStream_t stream, long ldv = 0, long ldg = 0)
 {
+    if (ldv == 0) ldv = (long)M * 32;                        // rows of value / grad_value: M * D floats, contiguous unless a stride is given
+    if (ldg == 0) ldg = (long)M * 32;
     const long nsamp = (long)N * Lq * M * L * P;
     if (nsamp >= (1L << 31) || ncell_cap >= (1L << 32) - 1) return S2D_ERR_ARG;      // segment offsets are int
     size_t ok[2], ov[2], orec, oo, ot, tb;
@@ -1217,11 +1220,11 @@ static int launch_backward_sorted(const G &geo, long ncell_cap, const float *val
     S2D_CHECK_LAUNCH();
     const long ntgt = (long)N * S * M;
     hipLaunchKernelGGL((msda_bwd_value_kernel<G>), dim3(cdiv(ntgt * 8, 256)), dim3(256), 0, stream, grad_out, rec, off, geo, ntgt, S, M, L,
-                       grad_value);
+                       grad_value, ldg);
     S2D_CHECK_LAUNCH();
     const int nb = cdiv((long)Lq * M * 8, 256);
     hipLaunchKernelGGL((msda_bwd_loc_kernel<G>), dim3(nb, N), dim3(256), 0, stream, value, geo, loc, attn_w, grad_out, S, M, L, Lq, P, nb,
-                       grad_loc, grad_attn_w);
+                       grad_loc, grad_attn_w, ldv);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1330,6 +1333,19 @@ int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host,
     if (N <= 0 || Lq <= 0) return S2D_OK;
     return launch_backward_sorted(gv, (long)gv.g.kmax, value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w,
                                   reinterpret_cast<char *>(workspace), workspace_bytes, stream);
+}
+
+int s2d_msda_backward_sorted_strided_f32(const float *value, long ldv, const int64_t *shapes_host, const int64_t *level_start_host,
+                                         const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
+                                         int L, int Lq, int P, float *grad_value, long ldg, float *grad_loc, float *grad_attn_w,
+                                         void *workspace, long workspace_bytes, hipStream_t stream)
+{
+    GeomVal gv;
+    if (int e = host_geom(gv, shapes_host, level_start_host, L, S, N > 0 ? N : 1, M)) return e;
+    if (D != 32 || !workspace || ldv < (long)M * D || ldg < (long)M * D || (ldv & 3) || (ldg & 3)) return S2D_ERR_ARG;
+    if (N <= 0 || Lq <= 0) return S2D_OK;
+    return launch_backward_sorted(gv, (long)gv.g.kmax, value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w,
+                                  reinterpret_cast<char *>(workspace), workspace_bytes, stream, ldv, ldg);
 }
 
 long s2d_msda_dev_forward_workspace_bytes(void) { return GEOM_BYTES; }

@@ -102,11 +102,12 @@ class MSDeformAttn(nn.Module):
         dm = d2 if drop is None or drop[0] <= 0.0 else ops.dropout(d2, *drop)   # d(proj): the forward's mask, regenerated
         B.acc_wbgrad(self.output_proj.weight, self.output_proj.bias, dm, samp.view(-1, C))
         d_samp = B.input_grad(dm, self.output_proj.weight).view(N, S, C)
-        d_val, d_oa = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points)
-        d_both = torch.cat([d_oa, d_val], -1).view(-1, n_oa + C)
+        # both gradients land in one buffer laid out like the merged projection's output: no concatenation, no copy of the value slice
+        d_val, d_oa, d_both = B.msda_fused_backward(both[..., n_oa:], shapes, both[..., :n_oa], d_samp, self.n_heads, self.n_points, merged=True)
+        d_both = d_both.view(-1, n_oa + C)
         db = torch.empty((n_oa + C,), device=src.device, dtype=torch.float32)
         dw = B.weight_grad(d_both, src.view(-1, C), bias_out=db)          # rows: offsets | logits | value; the bias gradient in the same pass
-        d_pos_oa = B.sum_slices(d_oa)                                     # the row-periodic term: same pos row for every frame
+        d_pos_oa = B.sum_slices(d_both.view(N, S, n_oa + C))[:, :n_oa].contiguous()   # the row-periodic term: same pos row for every frame
         dw_pos = B.weight_grad(d_pos_oa.contiguous(), pos.view(S, C))
         B.acc(self.sampling_offsets.weight, dw[:n_off] + dw_pos[:n_off])
         B.acc(self.attention_weights.weight, dw[n_off:n_oa] + dw_pos[n_off:])
