@@ -602,6 +602,304 @@ __global__ void attn_bwd_merge_kernel(const float *__restrict__ part, int B, int
     dq[i] = a * factor;
 }
 
+// ---- backward on the matrix cores -------------------------------------------------------------------------------------------
+// Same mathematics as the two scalar kernels above, every product a split-fp16 x3 MFMA contraction (fp32-class).  A workgroup =
+// (key split, head, clip), its 4 waves take the split's 32-key tiles round robin; a wave owns a key tile against ALL 128 query
+// rows, so dK / dV of the tile are complete inside the wave (no cross-wave sums, no atomics) and are written once, and dQ is
+// accumulated per wave over its tiles, added across the 4 waves in a fixed order at the end and left as a per-split partial for
+// attn_bwd_merge_kernel (as before).  Nothing of size Q x K is stored: per (key tile, 32-query tile) the scores are formed TWICE,
+// once per orientation, because the two kinds of products want their (probability, dS) tile in different operand layouts --
+//   lane = query:  S^T = K.Q^T, dP^T = V.dO^T  ->  dS^T  is the B operand of  dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+//   lane = key:    S = Q.K^T,   dP = dO.V^T    ->  P, dS are the B operands of  dV^T[d][key] += dO^T[d][q] . P[q][key]  and
+//                                                                              dK^T[d][key] += Q^T[d][q] . dS[q][key]
+// (an accumulator tile has its column on the lane and 16 rows in registers: that IS the B-operand layout once the contraction
+// index is permuted the same way in the A operand, which is how the transposed copies Qt / Gt / Kt are stored) -- 42 MFMAs per
+// (key tile, query tile) instead of a 32 x 32 transpose through LDS.  Q, dO (split, row-major and transposed), delta = rowsum(dO o O)
+// and the log-sum-exp are staged once per workgroup; K / V tiles live in wave-private LDS, so the tile loop has no barrier.
+constexpr int QROW = 136;         // halves per row of the transposed Q / dO images (128 query slots + pad: rows 4 banks apart)
+constexpr int KROW = 40;          // halves per row of a wave's transposed K tile
+
+__device__ __forceinline__ int perm16(int k16) { return ((k16 >> 2) & 1) * 8 + (((k16 >> 3) << 2) | (k16 & 3)); }
+
+// 8 accumulator registers (one MFMA k-step's worth of a C-layout tile) -> hi / lo B fragments
+__device__ __forceinline__ void frag_from_acc(const float *v, f16x8 &fh, f16x8 &fl)
+{
+    u32x4 hv, lv;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        const float a = v[2 * jp], bq = v[2 * jp + 1];
+        const h16x2 hh = __builtin_amdgcn_cvt_pkrtz(a, bq);
+        const h16x2 ll = __builtin_amdgcn_cvt_pkrtz((a - (float)hh[0]) * 2048.f, (bq - (float)hh[1]) * 2048.f);
+        hv[jp] = __builtin_bit_cast(unsigned int, hh);
+        lv[jp] = __builtin_bit_cast(unsigned int, ll);
+    }
+    fh = __builtin_bit_cast(f16x8, hv);
+    fl = __builtin_bit_cast(f16x8, lv);
+}
+
+struct AttnBwdLds {
+    unsigned int Qs[128][LSTR], Gs[128][LSTR];                         // scaled q rows / dO rows: 16 words hi | 16 words lo
+    unsigned short Qth[32][QROW], Qtl[32][QROW], Gth[32][QROW], Gtl[32][QROW];   // [d][query slot], slots permuted per 16 (perm16)
+    float delta[128], lses[128];
+    uint32_t ign[QW];
+    unsigned int Ks[4][KT][LSTR], Vs[4][KT][LSTR];                      // per wave: the key tile's K / V rows, split
+    unsigned short Kth[4][32][KROW], Ktl[4][32][KROW];                  // per wave: K tile transposed, key slots permuted
+    uint32_t Ms[4][KT][QW];
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_mfma_kernel(AttnBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_bwd_smem[];
+    AttnBwdLds &L = *reinterpret_cast<AttnBwdLds *>(attn_bwd_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+
+    // ---- stage the head's queries: scaled q and dO, split; row-major and transposed; delta and lse
+    for (int i = tid; i < 128 * 8; i += 256) {
+        const int qq = i >> 3, c4 = i & 7;
+        f32x4 a = f32x4(0.f), g = f32x4(0.f);
+        if (qq < p.Q) {
+            a = *reinterpret_cast<const f32x4 *>(p.q + ((long)b * p.Q + qq) * p.C + hd * 32 + c4 * 4) * p.qscale;
+            g = *reinterpret_cast<const f32x4 *>(p.dout + ((long)b * p.Q + qq) * p.C + hd * 32 + c4 * 4);
+        }
+        u32x2 ah, al, gh, gl;
+        split4_h(a, ah, al);
+        split4_h(g, gh, gl);
+        *reinterpret_cast<u32x2 *>(&L.Qs[qq][c4 * 2]) = ah; *reinterpret_cast<u32x2 *>(&L.Qs[qq][16 + c4 * 2]) = al;
+        *reinterpret_cast<u32x2 *>(&L.Gs[qq][c4 * 2]) = gh; *reinterpret_cast<u32x2 *>(&L.Gs[qq][16 + c4 * 2]) = gl;
+        const int pos = (qq & ~15) + perm16(qq & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            L.Qth[c4 * 4 + e][pos] = (unsigned short)(ah[e >> 1] >> (16 * (e & 1)));
+            L.Qtl[c4 * 4 + e][pos] = (unsigned short)(al[e >> 1] >> (16 * (e & 1)));
+            L.Gth[c4 * 4 + e][pos] = (unsigned short)(gh[e >> 1] >> (16 * (e & 1)));
+            L.Gtl[c4 * 4 + e][pos] = (unsigned short)(gl[e >> 1] >> (16 * (e & 1)));
+        }
+    }
+    if (tid < 128) {
+        float dl = 0.f, ls = INFINITY;                       // rows past Q: probability exp2(s - inf) = 0
+        if (tid < p.Q) {
+            const float *op = p.o + ((long)b * p.Q + tid) * p.C + hd * 32, *gp = p.dout + ((long)b * p.Q + tid) * p.C + hd * 32;
+            for (int d = 0; d < 32; ++d) dl += op[d] * gp[d];
+            ls = p.lse[((long)b * p.H + hd) * 128 + tid];
+        }
+        L.delta[tid] = dl; L.lses[tid] = ls;
+    }
+    if (tid < QW) L.ign[tid] = (p.bits && p.unmasked) ? ~p.unmasked[b * QW + tid] : (p.bits ? 0u : 0xFFFFFFFFu);
+    __syncthreads();
+
+    const int ntiles_all = (p.K + KT - 1) / KT;
+    const int t_lo = split * p.tiles_per_split, t_hi = min(ntiles_all, t_lo + p.tiles_per_split);
+    // persistent accumulators hold main + cross / 2^11 already folded: the cross products of a (key tile, query tile) go to a short-lived
+    // accumulator and are added scaled right away -- 96 accumulator registers live across the loop instead of 192
+    f32x16 dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
+
+    // a lane stages 4 float4 of K and of V per tile: rows (lane >> 3) + 8 i, float4 #(lane & 7)
+    const int srow = lane >> 3, sc4 = lane & 7;
+    const float *kbase = p.k + (long)b * p.K * p.ldk + hd * 32 + sc4 * 4;
+    const float *vbase = p.v + (long)b * p.K * p.ldv + hd * 32 + sc4 * 4;
+    f32x4 rk[4], rv[4];
+    uint32_t rm[2];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long key = (long)tile * KT + srow + 8 * i;
+            rk[i] = f32x4(0.f); rv[i] = f32x4(0.f);
+            if (key < p.K) {
+                rk[i] = *reinterpret_cast<const f32x4 *>(kbase + key * p.ldk);
+                rv[i] = *reinterpret_cast<const f32x4 *>(vbase + key * p.ldv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int w = lane + 64 * i;                     // word w & 3 of key w >> 2
+            const long mk = (long)tile * KT + (w >> 2);
+            rm[i] = mk < p.K ? (p.bits ? p.bits[((long)b * p.K + mk) * QW + (w & 3)] & ~L.ign[w & 3] : 0u) : 0xFFFFFFFFu;      // bit set = the pair does not attend; keys past K never do
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 8 * i;
+            u32x2 kh, kl, vh, vl;
+            split4_h(rk[i], kh, kl);
+            split4_h(rv[i], vh, vl);
+            *reinterpret_cast<u32x2 *>(&L.Ks[wv][row][sc4 * 2]) = kh; *reinterpret_cast<u32x2 *>(&L.Ks[wv][row][16 + sc4 * 2]) = kl;
+            *reinterpret_cast<u32x2 *>(&L.Vs[wv][row][sc4 * 2]) = vh; *reinterpret_cast<u32x2 *>(&L.Vs[wv][row][16 + sc4 * 2]) = vl;
+            const int pos = (row & ~15) + perm16(row & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                L.Kth[wv][sc4 * 4 + e][pos] = (unsigned short)(kh[e >> 1] >> (16 * (e & 1)));
+                L.Ktl[wv][sc4 * 4 + e][pos] = (unsigned short)(kl[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int w = lane + 64 * i; L.Ms[wv][w >> 2][w & 3] = rm[i]; }
+    };
+
+    int tile = t_lo + wv;
+    if (tile < t_hi) load_tile(tile);
+    for (; tile < t_hi; tile += 4) {
+        store_tile();
+        if (tile + 4 < t_hi) load_tile(tile + 4);            // in flight during this tile's arithmetic
+        f32x16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+        // K / V fragments of the tile: rows = keys (A operand of the lane = query products, B operand of the lane = key ones)
+        f16x8 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            kh[st] = *reinterpret_cast<const f16x8 *>(&L.Ks[wv][l32][8 * st + 4 * h]);
+            kl[st] = *reinterpret_cast<const f16x8 *>(&L.Ks[wv][l32][16 + 8 * st + 4 * h]);
+            vh[st] = *reinterpret_cast<const f16x8 *>(&L.Vs[wv][l32][8 * st + 4 * h]);
+            vl[st] = *reinterpret_cast<const f16x8 *>(&L.Vs[wv][l32][16 + 8 * st + 4 * h]);
+        }
+        const uint32_t mkey[QW] = {L.Ms[wv][l32][0], L.Ms[wv][l32][1], L.Ms[wv][l32][2], L.Ms[wv][l32][3]};     // this lane's key x all queries
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (32 * j >= p.Q) break;                        // uniform
+            __builtin_amdgcn_sched_barrier(0);               // keep the four query tiles' fragment loads from being hoisted together (registers)
+            f16x8 qh[2], ql[2], gh[2], gl[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                qh[st] = *reinterpret_cast<const f16x8 *>(&L.Qs[32 * j + l32][8 * st + 4 * h]);
+                ql[st] = *reinterpret_cast<const f16x8 *>(&L.Qs[32 * j + l32][16 + 8 * st + 4 * h]);
+                gh[st] = *reinterpret_cast<const f16x8 *>(&L.Gs[32 * j + l32][8 * st + 4 * h]);
+                gl[st] = *reinterpret_cast<const f16x8 *>(&L.Gs[32 * j + l32][16 + 8 * st + 4 * h]);
+            }
+            f32x16 s, sx, dp, dpx;
+            // ---- lane = query: S^T[key][q], dP^T[key][q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; sx[r] = 0.f; dp[r] = 0.f; dpx[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[st], qh[st], sx, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[st], ql[st], sx, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[st], qh[st], s, 0, 0, 0);
+                dpx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[st], gh[st], dpx, 0, 0, 0);
+                dpx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[st], gl[st], dpx, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[st], gh[st], dp, 0, 0, 0);
+            }
+            {
+                const float lq = L.lses[32 * j + l32], dlq = L.delta[32 * j + l32];
+                f32x16 cx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cx[r] = 0.f;
+                // dQ^T[d][q] += K^T[d][key] . dS^T[key][q], one k-step (8 of the lane's 16 keys) at a time
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    float dst[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int r = 8 * st + jj;
+                        const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool dead = (L.Ms[wv][kr][j] >> l32) & 1u;
+                        const float arg = dead ? -INFINITY : (s[r] + sx[r] * (1.0f / 2048.0f)) - lq;       // exp2(-inf) = 0
+                        dst[jj] = __builtin_amdgcn_exp2f(arg) * ((dp[r] + dpx[r] * (1.0f / 2048.0f)) - dlq);
+                    }
+                    f16x8 bh, bl;
+                    frag_from_acc(dst, bh, bl);
+                    const f16x8 ath = *reinterpret_cast<const f16x8 *>(&L.Kth[wv][l32][16 * st + 8 * h]);
+                    const f16x8 atl = *reinterpret_cast<const f16x8 *>(&L.Ktl[wv][l32][16 * st + 8 * h]);
+                    cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(atl, bh, cx, 0, 0, 0);
+                    cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath, bl, cx, 0, 0, 0);
+                    dq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath, bh, dq[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[j][r] = __builtin_fmaf(cx[r], 1.0f / 2048.0f, dq[j][r]);
+            }
+            // ---- lane = key: S[q][key], dP[q][key]
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; sx[r] = 0.f; dp[r] = 0.f; dpx[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[st], kh[st], sx, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[st], kl[st], sx, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[st], kh[st], s, 0, 0, 0);
+                dpx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[st], vh[st], dpx, 0, 0, 0);
+                dpx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[st], vl[st], dpx, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[st], vh[st], dp, 0, 0, 0);
+            }
+            {
+                // dV^T[d][key] += dO^T[d][q] . P[q][key];  dK^T[d][key] += Q^T[d][q] . dS[q][key], one k-step (8 query rows) at a time:
+                // the lane's rows of step st are 16 st + 8 g + 4 h + e (g = 0, 1; e = 0..3): two 16-B reads of lse / delta
+                f32x16 dkx, dvx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dkx[r] = 0.f; dvx[r] = 0.f; }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    float pv[8], dsv[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int q0 = 32 * j + 16 * st + 8 * g + 4 * h;
+                        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&L.lses[q0]), d4 = *reinterpret_cast<const f32x4 *>(&L.delta[q0]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 8 * st + 4 * g + e;
+                            const bool dead = (mkey[j] >> (q0 - 32 * j + e)) & 1u;
+                            const float arg = dead ? -INFINITY : (s[r] + sx[r] * (1.0f / 2048.0f)) - l4[e];
+                            const float pr = __builtin_amdgcn_exp2f(arg);
+                            pv[4 * g + e] = pr;
+                            dsv[4 * g + e] = pr * ((dp[r] + dpx[r] * (1.0f / 2048.0f)) - d4[e]);
+                        }
+                    }
+                    f16x8 ph, pl, sh, sl;
+                    frag_from_acc(pv, ph, pl);
+                    frag_from_acc(dsv, sh, sl);
+                    const int col = 32 * j + 16 * st + 8 * h;
+                    const f16x8 gth = *reinterpret_cast<const f16x8 *>(&L.Gth[l32][col]), gtl = *reinterpret_cast<const f16x8 *>(&L.Gtl[l32][col]);
+                    const f16x8 qth = *reinterpret_cast<const f16x8 *>(&L.Qth[l32][col]), qtl = *reinterpret_cast<const f16x8 *>(&L.Qtl[l32][col]);
+                    dvx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gtl, ph, dvx, 0, 0, 0);
+                    dvx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gth, pl, dvx, 0, 0, 0);
+                    dv = __builtin_amdgcn_mfma_f32_32x32x16_f16(gth, ph, dv, 0, 0, 0);
+                    dkx = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtl, sh, dkx, 0, 0, 0);
+                    dkx = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sl, dkx, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_32x32x16_f16(qth, sh, dk, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dk[r] = __builtin_fmaf(dkx[r], 1.0f / 2048.0f, dk[r]); dv[r] = __builtin_fmaf(dvx[r], 1.0f / 2048.0f, dv[r]); }
+            }
+        }
+        // the tile's dK / dV rows: lane = key, registers = d rows (r & 3) + 8 (r >> 2) + 4 h -> four 16-B runs per lane
+        const long key = (long)tile * KT + l32;
+        if (key < p.K) {
+            float *ko = p.dk + ((long)b * p.K + key) * p.C + hd * 32 + 4 * h, *vo = p.dv + ((long)b * p.K + key) * p.C + hd * 32 + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 a, c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = dk[4 * g4 + e] * LN2;                            // the staged q carries log2(e): back to natural scale
+                    c[e] = dv[4 * g4 + e];
+                }
+                *reinterpret_cast<f32x4 *>(ko + 8 * g4) = a;
+                *reinterpret_cast<f32x4 *>(vo + 8 * g4) = c;
+            }
+        }
+    }
+    // ---- dQ: the 4 waves' partials added in wave order, one [128][32] partial per split
+    __syncthreads();                                          // every wave is done with the staged queries: their LDS becomes the exchange area
+    float (*red)[128][33] = reinterpret_cast<float (*)[128][33]>(attn_bwd_smem);      // [4][128][33] floats = 67.6 KB <= the Q / dO images
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[wv][32 * j + l32][d] = dq[j][r];
+        }
+    __syncthreads();
+    float *o = p.dq_part + (((long)b * p.H + hd) * p.S + split) * 128 * 32;
+    for (int i = tid; i < 128 * 32; i += 256) {
+        const int qq = i >> 5, d = i & 31;
+        o[i] = ((red[0][qq][d] + red[1][qq][d]) + red[2][qq][d]) + red[3][qq][d];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -658,8 +956,23 @@ int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v,
     p.tiles_per_split = (tiles + p.S - 1) / p.S;
     p.qscale = 0.17677669529663687f * 1.4426950408889634f;
     p.dk = dk; p.dv = dv; p.dq_part = workspace;
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(tiles, H, B), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(p.S, H, B), dim3(256), 0, stream, p);
+    static int mfma = -1;                                    // S2D_ATTN_BWD_MFMA=0: the two scalar fp32 kernels (A/B runs, tests)
+    if (mfma < 0) { const char *e = getenv("S2D_ATTN_BWD_MFMA"); mfma = e ? atoi(e) : 1; }
+    if (mfma) {
+        static S2dDevOnce attr;
+        if (!attr.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(AttnBwdLds)) != hipSuccess)
+                return S2D_ERR_LAUNCH;
+            attr.mark();
+        }
+        const int tiles32 = (K + KT - 1) / KT;
+        p.tiles_per_split = (tiles32 + p.S - 1) / p.S;
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(p.S, H, B), dim3(256), sizeof(AttnBwdLds), stream, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(tiles, H, B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(p.S, H, B), dim3(256), 0, stream, p);
+    }
     const long total = (long)B * Q * C;
     hipLaunchKernelGGL(attn_bwd_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, workspace, B, Q, C, H, p.S,
                        0.17677669529663687f, dq);      // dS carries natural-scale probabilities; dQ = dS K / sqrt(d)
