@@ -55,6 +55,16 @@ class ConvBN(nn.Module):
             self._packed = (key, ops.mark_static(w), scale.float(), shift.float())
         return self._packed[1:]
 
+    def packed_scaled(self):
+        """the packed weight with the folded BatchNorm scale multiplied into its output channels (diag(scale) . W): the dgrad operand
+        when the arriving gradient is d(pre-activation sum), not yet multiplied by the scale"""
+        w, scale, _ = self.packed()
+        key = self._packed[0]
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws[0] != key:
+            self._ws = ws = (key, ops.mark_static(w * scale.view(-1, 1, 1, 1)))
+        return ws[1]
+
     def forward(self, x, res=None, relu=True):
         w, scale, shift = self.packed()
         if self.k == 1 and self.stride == 1:
@@ -64,15 +74,23 @@ class ConvBN(nn.Module):
             return y.view(N, H, W, -1)
         return ops.conv2d_nhwc(x, w, self.stride, self.pad, scale, shift, res, relu)
 
-    def backward(self, x, y, dy, relu=True, has_res=False, need_dx=True, dx_res=None, pre_gated=False, in_scale=None):
+    def backward(self, x, y, dy, relu=True, has_res=False, need_dx=True, dx_res=None, pre_gated=False, in_scale=None, out_gated=False,
+                 gate_x=False):
         """gradients of y = act(conv(x) * scale + shift [+ res]): accumulates into self.weight.grad and returns
         (dx [+ dx_res: a gradient arriving at x over another path, added in the dgrad epilogue for 1x1 kernels], dres).
         pre_gated: dy is already d(conv output) (the consumer's dgrad applied this layer's ReLU gate and scale in its epilogue).
         in_scale: x is the ReLU output of a ConvBN with that folded scale; the returned dx is then d(that convolution's output),
-        gated by x > 0 and scaled in the dgrad epilogue (one pass over the activation gradient less)."""
+        gated by x > 0 and scaled in the dgrad epilogue (one pass over the activation gradient less).
+        gate_x: x is a ReLU output (a block output): the returned dx is gated by x > 0 in the dgrad epilogue, not scaled.
+        out_gated: dy is d(pre-ReLU sum) already (the consumer of y gated it, gate_x there) but NOT multiplied by this layer's folded
+        scale: the scale goes into the dgrad's weight (packed_scaled) and onto the rows of the weight gradient, so the three-pass
+        gate / scale kernel over the block output's gradient disappears."""
         from .. import backward as B
         w, scale, _ = self.packed()
-        if pre_gated:
+        if out_gated:
+            dz, dres = dy, (dy if has_res else None)
+            w = self.packed_scaled()
+        elif pre_gated:
             dz, dres = dy, None
         elif has_res and relu:
             dz, dres = B.relu_scale_backward(dy, y, scale, want_res=True)       # d(conv output), d(residual): one pass
@@ -80,6 +98,8 @@ class ConvBN(nn.Module):
             dres = dy if has_res else None
             dz = B.relu_scale_backward(dy, y if relu else None, scale)
         dw = B.conv_weight_grad(dz, x, self.k, self.k, self.stride, self.pad)  # [O,kh,kw,C(4)]
+        if out_gated:
+            dw = dw * scale.view(-1, 1, 1, 1)                                  # dz = dy * scale enters the weight gradient linearly
         dw = dw[..., :self.weight.shape[1]].permute(0, 3, 1, 2)
         if self.weight.grad is None:
             self.weight.grad = dw.contiguous()
@@ -87,7 +107,7 @@ class ConvBN(nn.Module):
             self.weight.grad += dw
         dx = None
         if need_dx:
-            gate = x if in_scale is not None else None
+            gate = x if (in_scale is not None or gate_x) else None
             if self.k == 1 and self.stride == 1:
                 N, H, W, C = x.shape
                 dx = B.input_grad(dz.view(-1, dz.shape[-1]), w.view(w.shape[0], -1), None if dx_res is None else dx_res.view(-1, C),
@@ -134,16 +154,18 @@ class BottleneckBlock(nn.Module):
             tape.append((self, x, sc, y1, y2, out))
         return out
 
-    def backward(self, saved, dout):
-        """d(block input) from d(block output); parameter gradients accumulate in the ConvBN weights"""
+    def backward(self, saved, dout, gated=False, gate_in=False):
+        """d(block input) from d(block output); parameter gradients accumulate in the ConvBN weights.
+        gated: dout is already multiplied by (out > 0) (the consuming block's conv1 dgrad did it, gate_in there).
+        gate_in: x is the previous block's ReLU output: return dx * (x > 0) (in conv1's dgrad epilogue)."""
         _, x, sc, y1, y2, out = saved
         # conv3's and conv2's dgrads gate by the ReLU output they differentiate through and apply that layer's folded scale in
         # their epilogues: d2 / d1 arrive as d(conv2 output) / d(conv1 output)
-        d2, dsc = self.conv3.backward(y2, out, dout, relu=True, has_res=True, in_scale=self.conv2.packed()[1])
+        d2, dsc = self.conv3.backward(y2, out, dout, relu=True, has_res=True, in_scale=self.conv2.packed()[1], out_gated=gated)
         d1, _ = self.conv2.backward(y1, y2, d2, pre_gated=True, in_scale=self.conv1.packed()[1])
         if self.shortcut is not None:
-            dsc, _ = self.shortcut.backward(x, sc, dsc, relu=False)
-        dx, _ = self.conv1.backward(x, y1, d1, pre_gated=True, dx_res=dsc)             # both paths meet at x
+            dsc, _ = self.shortcut.backward(x, sc, dsc, relu=False, out_gated=True)        # no activation: only the folded scale, taken into the weights
+        dx, _ = self.conv1.backward(x, y1, d1, pre_gated=True, dx_res=dsc, gate_x=gate_in)   # both paths meet at x
         return dx
 
 
@@ -183,8 +205,10 @@ class ResNet50(nn.Module):
     def backward(self, tape, grads):
         """grads: {"res2".."res5": d(loss)/d(output)} (missing = zero).  Walks the tape backwards, accumulating the weight
         gradients of all 53 convolutions (FREEZE_AT 0: the whole trunk trains, Base-YouTubeVIS...yaml:3)."""
+        from .. import backward as B
         last = {getattr(self, name)[-1]: name for name, *_ in R50_STAGES}
-        d = None
+        first_block = getattr(self, R50_STAGES[0][0])[0]
+        d, gated = None, False
         for saved in reversed(tape):
             mod = saved[0]
             if isinstance(mod, BasicStem):
@@ -192,8 +216,17 @@ class ResNet50(nn.Module):
                 continue
             g = grads.get(last.get(mod))
             if g is not None:
-                d = g if d is None else d + g
-            d = mod.backward(saved, d)
+                if d is None:
+                    d, gated = g, False
+                elif gated:
+                    d = d + B.relu_scale_backward(g, saved[5])       # d arrives gated by this block's output: gate the stage output's own gradient too
+                else:
+                    d = d + g
+            # every block but the first hands its input gradient back gated by that input (the previous block's ReLU output), in its conv1
+            # dgrad's epilogue: the previous block then needs no gate / scale pass over its 0.2-1 GB output gradient
+            gate_in = mod is not first_block
+            d = mod.backward(saved, d, gated=gated, gate_in=gate_in)
+            gated = gate_in
 
 
 def build_resnet_backbone(cfg=None, input_shape=None):
