@@ -417,6 +417,11 @@ int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int
 /* out[c][r] = in[r][c]; in [R][ldi], out [C][ldo].  dW = dY^T . X runs as an NT GEMM on the transposed operands. */
 int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream);
 
+/* dst_t[i] += src_t[i] for a list of tensors in one launch (the "param.grad += g" glue of a training iteration): table [n][3] =
+ * (src pointer, dst pointer, element count) as 64-bit words in DEVICE memory; block b adds elements [chunk_off[b], chunk_off[b] +
+ * chunk) of tensor chunk_tensor[b].  No two entries may share a destination. */
+int s2d_multi_add_f32(const long *table, const int *chunk_tensor, const long *chunk_off, int nchunks, int chunk, hipStream_t stream);
+
 /* out[i] = beta * out[i] + sum_{s < S} part[s * stride + i], s ascending (fixed order: reproducible split-K) */
 int s2d_reduce_slices_f32(const float *part, int S, long n, long stride, float beta, float *out, hipStream_t stream);
 

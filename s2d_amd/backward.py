@@ -18,13 +18,54 @@ def _st():
     return ops._stream()
 
 
+_PENDING = None        # deferred "param.grad += g" pairs (begin_deferred_acc .. flush_acc): one multi-tensor launch instead of ~350
+_ACC_CHUNK = 1 << 16
+
+
+def begin_deferred_acc():
+    """from here to flush_acc(), acc() on an existing contiguous float32 gradient only records the pair"""
+    global _PENDING
+    if _PENDING is None:
+        _PENDING = ([], set())
+
+
+def flush_acc(end=False):
+    """apply the recorded pairs in one launch (s2d_multi_add_f32); end=True also leaves the deferred mode"""
+    global _PENDING
+    if _PENDING is None:
+        return
+    pairs, _ = _PENDING
+    _PENDING = None if end else ([], set())
+    if not pairs:
+        return
+    table, ct, co = [], [], []
+    for i, (dst, src) in enumerate(pairs):
+        n = dst.numel()
+        table += [src.data_ptr(), dst.data_ptr(), n]
+        for off in range(0, n, _ACC_CHUNK):
+            ct.append(i); co.append(off)
+    dev = pairs[0][0].device
+    t_table = torch.tensor(table, dtype=torch.int64).to(dev, non_blocking=True)
+    t_ct = torch.tensor(ct, dtype=torch.int32).to(dev, non_blocking=True)
+    t_co = torch.tensor(co, dtype=torch.int64).to(dev, non_blocking=True)
+    lib().call("s2d_multi_add_f32", t_table, t_ct, t_co, len(ct), _ACC_CHUNK, _st())
+    # `pairs` (and with it every src) stays referenced until here: later allocations on this stream are ordered behind the launch
+
+
 def acc(param, g):
     """accumulate a gradient into param.grad (allocating it on first use), as autograd's AccumulateGrad does"""
     g = g.reshape(param.shape)
     if param.grad is None:
         param.grad = g.contiguous().clone() if g.data_ptr() == param.data_ptr() else g.contiguous()
-    else:
-        param.grad += g
+        return
+    gr = param.grad
+    if _PENDING is not None and gr.is_contiguous() and gr.dtype == torch.float32 and g.dtype == torch.float32 and g.device == gr.device:
+        if id(param) in _PENDING[1]:
+            flush_acc()                                  # a second contribution to the same gradient: keep one destination per launch
+        _PENDING[0].append((gr, g.contiguous()))
+        _PENDING[1].add(id(param))
+        return
+    param.grad += g
 
 
 def acc_wgrad(param, dy, x):

@@ -363,9 +363,42 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
     *reinterpret_cast<f32x4 *>(col + i * 4) = v;
 }
 
+// dst_i += src_i for a list of tensors in ONE launch: table [n][3] = (src pointer, dst pointer, element count) as 64-bit words, a block
+// takes one chunk of one tensor (chunk_tensor / chunk_off name it).  The ~350 "param.grad += g" of a training iteration's glue.
+__global__ __launch_bounds__(256) void multi_add_kernel(const long *__restrict__ table, const int *__restrict__ chunk_tensor,
+                                                        const long *__restrict__ chunk_off, int chunk)
+{
+    const int t = chunk_tensor[blockIdx.x];
+    const float *src = reinterpret_cast<const float *>(table[3 * t]);
+    float *dst = reinterpret_cast<float *>(table[3 * t + 1]);
+    const long n = table[3 * t + 2], off = chunk_off[blockIdx.x];
+    const long end = off + chunk < n ? off + chunk : n;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (off & 3) == 0) {
+        const long e4 = off + ((end - off) & ~3L);
+        for (long i = off + 4L * threadIdx.x; i < e4; i += 1024) {
+            f32x4 a = *reinterpret_cast<const f32x4 *>(src + i), b = *reinterpret_cast<const f32x4 *>(dst + i);
+            *reinterpret_cast<f32x4 *>(dst + i) = b + a;
+        }
+        for (long i = e4 + threadIdx.x; i < end; i += 256) dst[i] += src[i];
+    } else {
+        for (long i = off + threadIdx.x; i < end; i += 256) dst[i] += src[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int s2d_multi_add_f32(const long *table, const int *chunk_tensor, const long *chunk_off, int nchunks, int chunk, hipStream_t stream)
+{
+    if (nchunks < 0 || chunk <= 0 || (chunk & 3)) return S2D_ERR_ARG;
+    if (nchunks == 0) return S2D_OK;
+    if (!table || !chunk_tensor || !chunk_off) return S2D_ERR_ARG;
+    hipLaunchKernelGGL(multi_add_kernel, dim3(nchunks), dim3(256), 0, stream, table, chunk_tensor, chunk_off, chunk);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
 
 int s2d_im2col_nhwc_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, float *col, hipStream_t stream)
 {

@@ -359,13 +359,20 @@ class KDVideoMaskFormer(nn.Module):
             if w_ce != 0.0:
                 d_cls[NL - 1] += ops.class_loss_backward(student.class_logits[NL - 1], ctx["idx_q"][(NL - 1) * B:].contiguous(),
                                                          ctx["n_match"][(NL - 1) * B:].contiguous(), w_ce * loss_scale, self.criterion.eos_coef)
-        d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
-        if grad_ready is not None:
-            grad_ready("predictor")
-        grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
-        if grad_ready is not None:
-            grad_ready("pixel_decoder")
-        backbone.backward(tb, grads)
+        from .. import backward as Bk
+        Bk.begin_deferred_acc()          # the ~350 "param.grad += g" of the walk below: one multi-tensor launch per part
+        try:
+            d_mf, d_mem = head.predictor.backward(td[0], d_cls, sources)
+            Bk.flush_acc()
+            if grad_ready is not None:
+                grad_ready("predictor")
+            grads = head.pixel_decoder.backward_features(tp[0], d_mf, d_mem)
+            Bk.flush_acc()
+            if grad_ready is not None:
+                grad_ready("pixel_decoder")
+            backbone.backward(tb, grads)
+        finally:
+            Bk.flush_acc(end=True)
         if grad_ready is not None:
             grad_ready("backbone")
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
