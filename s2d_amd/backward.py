@@ -219,14 +219,14 @@ def _transposed_weight(w, Np):
     if ent is None or ent[2] is not base:
         wt = ops.mark_static(transpose(w.contiguous(), Np if Np != w.shape[0] else None))
         wt._s2d_version = 0
-        ent = _WT[key] = [wt, base._version, base]
-    elif ent[1] != base._version:
+        ent = _WT[key] = [wt, ops.version_of(base), base]
+    elif ent[1] != ops.version_of(base):
         # the weight changed (an optimizer step): transpose into the SAME buffer and bump its version -- a fresh tensor per
         # iteration would enter ops._SPLIT under a new address every time and never leave it (0.5 GB per iteration at c4)
         wc = w.contiguous()
         lib().call("s2d_transpose_f32", wc, wc.shape[0], wc.shape[1], wc.shape[1], ent[0], ent[0].shape[1], _st())
         ent[0]._s2d_version += 1
-        ent[1] = base._version
+        ent[1] = ops.version_of(base)
     return ent[0]
 
 
@@ -244,11 +244,11 @@ def _flipped_weight(w):
     if ent is None or ent[2] is not base:
         wf = ops.mark_static(w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
         wf._s2d_version = 0
-        ent = _WF[key] = [wf, base._version, base]
-    elif ent[1] != base._version:                          # same buffer, new contents (see _transposed_weight)
+        ent = _WF[key] = [wf, ops.version_of(base), base]
+    elif ent[1] != ops.version_of(base):                          # same buffer, new contents (see _transposed_weight)
         ent[0].copy_(w.flip(1, 2).permute(3, 1, 2, 0))
         ent[0]._s2d_version += 1
-        ent[1] = base._version
+        ent[1] = ops.version_of(base)
     return ent[0]
 
 

@@ -42,8 +42,8 @@ class ConvBN(nn.Module):
         self._packed = None
 
     def packed(self):
-        key = (self.weight._version, self.weight.device, self.norm.weight._version, self.norm.running_var._version,
-               self.norm.bias._version, self.norm.running_mean._version)
+        v = ops.version_of
+        key = (v(self.weight), self.weight.device, v(self.norm.weight), v(self.norm.running_var), v(self.norm.bias), v(self.norm.running_mean))
         if self._packed is None or self._packed[0] != key:
             w = self.weight.detach().permute(0, 2, 3, 1)             # [O,kh,kw,C]
             if w.shape[-1] % 4:

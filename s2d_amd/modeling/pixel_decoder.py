@@ -52,7 +52,7 @@ class MSDeformAttn(nn.Module):
         bias [0 | b_value]: the offsets/logits bias travels in the row-periodic pos term of forward_fused."""
         ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight, self.attention_weights.bias,
               self.value_proj.weight, self.value_proj.bias)
-        key = tuple(p._version for p in ps) + (ps[0].device,)
+        key = tuple(ops.version_of(p) for p in ps) + (ps[0].device,)
         if self._packed is None or self._packed[0] != key:
             w_oa = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
             b_oa = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
@@ -243,7 +243,7 @@ class _ConvGN(nn.Module):
         self._packed = None
 
     def packed(self):
-        key = (self.weight._version, self.weight.device)
+        key = (ops.version_of(self.weight), self.weight.device)
         if self._packed is None or self._packed[0] != key:
             w = self.weight.detach().permute(0, 2, 3, 1).contiguous()
             self._packed = (key, ops.mark_static(w.clone() if w._base is not None else w))
@@ -282,7 +282,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def _pos(self, shapes, device):
         le = self.transformer.level_embed
-        key = (tuple(shapes), le._version, device)
+        key = (tuple(shapes), ops.version_of(le), device)
         if self._pos_cache.get("key") != key:
             pos = [ops.pe_sine(0, h, w, self.conv_dim // 2, add_c=le[i].detach().contiguous(), device=device)
                    for i, (h, w) in enumerate(shapes)]

@@ -230,7 +230,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
     def _pos(self, T, sizes, device):
         """per level: pos3d + level_embed (for keys) and level_embed alone (for values), token-major [T*h*w, C]"""
         le = self.level_embed.weight
-        key = (T, tuple(sizes), le._version, device)
+        key = (T, tuple(sizes), ops.version_of(le), device)
         if self._pos_cache.get("key") != key:
             self._pos_cache = {"key": key, "posl": [
                 ops.pe_sine(T, h, w, self.hidden_dim // 2, add_c=le[i].detach().contiguous(), device=device)
@@ -242,7 +242,7 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         stacked to [n*C, C] so that the memory of a level is read once for all of them instead of once per layer"""
         C = self.hidden_dim
         mh = [l.multihead_attn for l in self.transformer_cross_attention_layers]
-        key = tuple(m.in_proj_weight._version for m in mh) + tuple(m.in_proj_bias._version for m in mh) + (mh[0].in_proj_weight.device,)
+        key = tuple(ops.version_of(m.in_proj_weight) for m in mh) + tuple(ops.version_of(m.in_proj_bias) for m in mh) + (mh[0].in_proj_weight.device,)
         if self._kv_cache is None or self._kv_cache[0] != key:
             packs = []
             for lvl in range(3):

@@ -68,6 +68,19 @@ _MODE = "f16x3"
 _SPLIT = {}      # (data_ptr, shape, row stride) -> (split image, version of the owning tensor, the owning tensor)
 
 
+def version_of(t):
+    """content version of a tensor for this library's caches: torch's in-place counter of the owning tensor + the count of rewrites
+    torch cannot see (the multi-tensor optimizer kernel updates parameters and EMA copies through raw pointers: bump_version)"""
+    base = t._base if t._base is not None else t
+    return base._version + getattr(base, "_s2d_version", 0)
+
+
+def bump_version(t):
+    """declare that t's storage was rewritten behind torch's back (a kernel of this library wrote through its raw pointer)"""
+    base = t._base if t._base is not None else t
+    base._s2d_version = getattr(base, "_s2d_version", 0) + 1
+
+
 def mark_static(t):
     """Declare a tensor a static weight (a packed / concatenated copy of parameters that its module caches): dense launches
     reading it as the B operand may then use a cached pre-split fp16 image instead of splitting it in every launch."""

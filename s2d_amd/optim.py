@@ -142,6 +142,13 @@ class FullModelGradientClippingAdamW:
         lib().call("s2d_optim_adamw_ema_f32", self._t_ptrs, self._t_numel, self._t_hyper, self._t_ct, self._t_co, self._nchunks,
                    CHUNK, 1.0, float(beta1), float(beta2), float(g0["eps"]), float(bc1), float(bc2_sqrt), float(inv_scale), ema,
                    self.normbuf if need_norm else None, st)
+        # the kernel wrote the parameters (and the EMA copies) through raw pointers: torch's version counters did not move, so tell the
+        # library's weight caches (packed / pre-split / transposed copies keyed by ops.version_of) that their sources changed
+        for p in self._params:
+            ops.bump_version(p)
+        if ema >= 0.0:
+            for e in self._ema:
+                ops.bump_version(e)
 
     def grad_norm(self):
         return float(self.normbuf[0])
