@@ -48,11 +48,15 @@ class ConvBN(nn.Module):
             w = self.weight.detach().permute(0, 2, 3, 1)             # [O,kh,kw,C]
             if w.shape[-1] % 4:
                 w = torch.nn.functional.pad(w, (0, 4 - w.shape[-1] % 4))  # stem: Cin 3 -> 4 (input is NHWC4)
-            scale, shift = self.norm.fold()
+            nkey = key[1:]                                                # the frozen statistics do not change with the weight:
+            if getattr(self, "_fold", None) is None or self._fold[0] != nkey:   # fold them once, not after every optimizer step
+                scale, shift = self.norm.fold()
+                self._fold = (nkey, scale.float(), shift.float())
+            scale, shift = self._fold[1], self._fold[2]
             w = w.contiguous().float()
             if w._base is not None:          # 1x1 kernels: permute + contiguous is still a view of the parameter; own the
                 w = w.clone()                # storage so that views of the packed weight resolve to this (marked) tensor
-            self._packed = (key, ops.mark_static(w), scale.float(), shift.float())
+            self._packed = (key, ops.mark_static(w), scale, shift)
         return self._packed[1:]
 
     def packed_scaled(self):
