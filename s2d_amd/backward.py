@@ -59,13 +59,21 @@ def acc(param, g):
         param.grad = g.contiguous().clone() if g.data_ptr() == param.data_ptr() else g.contiguous()
         return
     gr = param.grad
-    if _PENDING is not None and gr.is_contiguous() and gr.dtype == torch.float32 and g.dtype == torch.float32 and g.device == gr.device:
-        if id(param) in _PENDING[1]:
-            flush_acc()                                  # a second contribution to the same gradient: keep one destination per launch
-        _PENDING[0].append((gr, g.contiguous()))
-        _PENDING[1].add(id(param))
-        return
-    param.grad += g
+    if not _defer_add(gr, g):
+        param.grad += g
+
+
+def _defer_add(dst, src):
+    """dst += src through the pending multi-tensor launch when the deferred mode is on and the pair qualifies -> True"""
+    if _PENDING is None or not (dst.is_contiguous() and dst.dtype == torch.float32 and src.dtype == torch.float32 and src.device == dst.device
+                                and src.numel() == dst.numel()):
+        return False
+    key = dst.data_ptr()
+    if key in _PENDING[1]:
+        flush_acc()                                      # a second contribution to the same gradient: keep one destination per launch
+    _PENDING[0].append((dst, src.contiguous()))
+    _PENDING[1].add(key)
+    return True
 
 
 def acc_wgrad(param, dy, x):
@@ -150,12 +158,18 @@ def weight_grad(dy, x, out=None, beta=0.0, bias_out=None, bias_beta=0.0):
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
         bpart = torch.empty((S, N), device=dy.device, dtype=torch.float32) if bias_out is not None else None
         lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, bpart, _st())
+        # one slice (short contractions: the video decoder's 200 query rows): nothing to reduce -- the slice IS the result, and an
+        # accumulation into an existing gradient joins the pending multi-tensor add instead of taking a launch of its own
+        if bias_out is not None and not (S == 1 and bias_beta == 1.0 and _defer_add(bias_out, bpart.view(-1))):
+            lib().call("s2d_reduce_slices_f32", bpart, S, N, N, float(bias_beta), bias_out, _st())
         if out is None:
+            if S == 1:
+                return part.view(N, K)
             out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
             beta = 0.0
+        elif S == 1 and beta == 1.0 and _defer_add(out, part.view(N, K)):
+            return out
         lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
-        if bias_out is not None:
-            lib().call("s2d_reduce_slices_f32", bpart, S, N, N, float(bias_beta), bias_out, _st())
         return out
     if bias_out is not None:
         bias_grad(dy, out=bias_out, beta=bias_beta)
