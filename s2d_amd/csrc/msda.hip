@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // are co-resident on one CU by construction, so the corner rows neighbouring queries share (their sampling offsets differ by
 // less than the patch when the offsets field is smooth) are fetched into that CU's L1 once; with 256-thread workgroups of 4
 // consecutive queries the dispatcher deals a CU workgroups that lie 128 queries apart.
+// timing experiments only (scripts/build_msda_dbg.sh; results wrong by construction): 1 no value gathers, 2 one corner line per sample instead of
+// four (profiles/r4_experiments/msda_dbg.txt)
+#ifndef S2D_MSDA_DBG
+#define S2D_MSDA_DBG 0
+#endif
 template <int LP_, bool HM = false, bool SHARE = false, bool TILED = false>
 __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const float *__restrict__ value, int ldv, Levels lv,
                                                          const float *__restrict__ oa, int ldoa, int S, int M, int L,
@@ -318,6 +323,12 @@ __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const fl
                                     : value + ((long)n * S + lv.start[l]) * rowstride + m * D + c * V;
             const float *p1 = vbase + (long)pix * rowstride;
             f32x4 v1 = f32x4(0.f), v2 = f32x4(0.f), v3 = f32x4(0.f), v4 = f32x4(0.f);
+            if (S2D_MSDA_DBG & 1) {                                // timing experiment: no gathers
+                v1 = f32x4(c1); v2 = f32x4(c2); v3 = f32x4(aw); v4 = f32x4((float)pix);
+            } else if (S2D_MSDA_DBG & 2) {                         // timing experiment: one corner line instead of four
+                v1 = *reinterpret_cast<const f32x4 *>(p1 + ((mask & 1) ? 0 : (long)(W + 1) * rowstride));
+                v2 = v1 * c2; v3 = v1 * c3; v4 = v1 * c4;
+            } else
             if (__builtin_amdgcn_readfirstlane(mask) == 15 && __all(mask == 15)) {
                 // interior sample in every head of the wave (the common case): four loads, no per-corner exec juggling
                 v1 = *reinterpret_cast<const f32x4 *>(p1);
