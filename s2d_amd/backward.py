@@ -7,6 +7,7 @@ dx is an NT GEMM against W^T.  dW contracts over the M rows (3e5..4e6): the cont
 in a fixed order, so the result is reproducible (shapes the TN kernel cannot take are transposed once and run as the batch
 of one NT-GEMM launch).  Same split-fp16 x3 arithmetic as the forward (fp32-class accuracy)."""
 import os
+import weakref
 
 import torch
 
@@ -220,7 +221,13 @@ def bias_grad(dy, out=None, beta=0.0):
     return out
 
 
-_WT = {}     # (data_ptr, shape) -> (W^T, version of the owning tensor, the owning tensor)
+_WT = {}     # (data_ptr, shape) -> [W^T, version of the owning tensor, weak reference to the owning tensor]
+
+
+def _sweep(cache):
+    """drop the copies whose owning tensor is gone (called when a new key enters)"""
+    for k in [k for k, e in cache.items() if e[2]() is None]:
+        del cache[k]
 
 
 def _transposed_weight(w, Np):
@@ -230,10 +237,11 @@ def _transposed_weight(w, Np):
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), tuple(w.shape), Np)
     ent = _WT.get(key)
-    if ent is None or ent[2] is not base:
+    if ent is None or ent[2]() is not base:
         wt = ops.mark_static(transpose(w.contiguous(), Np if Np != w.shape[0] else None))
         wt._s2d_version = 0
-        ent = _WT[key] = [wt, ops.version_of(base), base]
+        _sweep(_WT)
+        ent = _WT[key] = [wt, ops.version_of(base), weakref.ref(base)]     # a WEAK reference: the copy must not keep a replaced weight alive
     elif ent[1] != ops.version_of(base):
         # the weight changed (an optimizer step): transpose into the SAME buffer and bump its version -- a fresh tensor per
         # iteration would enter ops._SPLIT under a new address every time and never leave it (0.5 GB per iteration at c4)
@@ -255,10 +263,11 @@ def _flipped_weight(w):
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
     ent = _WF.get(key)
-    if ent is None or ent[2] is not base:
+    if ent is None or ent[2]() is not base:
         wf = ops.mark_static(w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
         wf._s2d_version = 0
-        ent = _WF[key] = [wf, ops.version_of(base), base]
+        _sweep(_WF)
+        ent = _WF[key] = [wf, ops.version_of(base), weakref.ref(base)]
     elif ent[1] != ops.version_of(base):                          # same buffer, new contents (see _transposed_weight)
         ent[0].copy_(w.flip(1, 2).permute(3, 1, 2, 0))
         ent[0]._s2d_version += 1

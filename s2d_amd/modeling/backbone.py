@@ -53,10 +53,8 @@ class ConvBN(nn.Module):
                 scale, shift = self.norm.fold()
                 self._fold = (nkey, scale.float(), shift.float())
             scale, shift = self._fold[1], self._fold[2]
-            w = w.contiguous().float()
-            if w._base is not None:          # 1x1 kernels: permute + contiguous is still a view of the parameter; own the
-                w = w.clone()                # storage so that views of the packed weight resolve to this (marked) tensor
-            self._packed = (key, ops.mark_static(w), scale, shift)
+            # own storage (1x1 kernels: permute + contiguous is still a view of the parameter), refreshed in place after an optimizer step
+            self._packed = (key, ops.repack(None if self._packed is None else self._packed[1], w.float()), scale, shift)
         return self._packed[1:]
 
     def packed_scaled(self):
@@ -66,7 +64,7 @@ class ConvBN(nn.Module):
         key = self._packed[0]
         ws = getattr(self, "_ws", None)
         if ws is None or ws[0] != key:
-            self._ws = ws = (key, ops.mark_static(w * scale.view(-1, 1, 1, 1)))
+            self._ws = ws = (key, ops.repack(None if ws is None else ws[1], w * scale.view(-1, 1, 1, 1)))
         return ws[1]
 
     def forward(self, x, res=None, relu=True):

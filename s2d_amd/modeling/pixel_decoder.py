@@ -54,11 +54,12 @@ class MSDeformAttn(nn.Module):
               self.value_proj.weight, self.value_proj.bias)
         key = tuple(ops.version_of(p) for p in ps) + (ps[0].device,)
         if self._packed is None or self._packed[0] != key:
-            w_oa = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
-            b_oa = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
-            w_all = torch.cat([w_oa, ps[4].detach()], 0).contiguous()
-            b_all = torch.cat([torch.zeros_like(b_oa), ps[5].detach()], 0).contiguous()
-            self._packed = (key, ops.mark_static(w_all), b_all, ops.mark_static(w_oa), b_oa)
+            w_oa = torch.cat([ps[0].detach(), ps[2].detach()], 0)
+            b_oa = torch.cat([ps[1].detach(), ps[3].detach()], 0)
+            w_all = torch.cat([w_oa, ps[4].detach()], 0)
+            b_all = torch.cat([torch.zeros_like(b_oa), ps[5].detach()], 0)
+            prev = (None,) * 5 if self._packed is None else self._packed            # refreshed in place after an optimizer step (ops.repack)
+            self._packed = (key, ops.repack(prev[1], w_all), ops.repack(prev[2], b_all), ops.repack(prev[3], w_oa), ops.repack(prev[4], b_oa))
         return self._packed[1:]
 
     def projection(self, pos):
@@ -245,8 +246,8 @@ class _ConvGN(nn.Module):
     def packed(self):
         key = (ops.version_of(self.weight), self.weight.device)
         if self._packed is None or self._packed[0] != key:
-            w = self.weight.detach().permute(0, 2, 3, 1).contiguous()
-            self._packed = (key, ops.mark_static(w.clone() if w._base is not None else w))
+            w = self.weight.detach().permute(0, 2, 3, 1)
+            self._packed = (key, ops.repack(None if self._packed is None else self._packed[1], w))
         return self._packed[1]
 
 

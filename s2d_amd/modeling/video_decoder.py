@@ -245,16 +245,18 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         key = tuple(ops.version_of(m.in_proj_weight) for m in mh) + tuple(ops.version_of(m.in_proj_bias) for m in mh) + (mh[0].in_proj_weight.device,)
         if self._kv_cache is None or self._kv_cache[0] != key:
             packs = []
+            prevs = [None] * 3 if self._kv_cache is None else self._kv_cache[1]
             for lvl in range(3):
                 ms = [mh[i] for i in range(self.num_layers) if i % 3 == lvl]
                 if not ms:                         # fewer than three layers: nobody reads this level
                     packs.append(None)
                     continue
-                wk = torch.cat([m.in_proj_weight.detach()[C:2 * C] for m in ms], 0).contiguous()
-                bk = torch.cat([m.in_proj_bias.detach()[C:2 * C] for m in ms], 0).contiguous()
-                wv = torch.cat([m.in_proj_weight.detach()[2 * C:] for m in ms], 0).contiguous()
-                bv = torch.cat([m.in_proj_bias.detach()[2 * C:] for m in ms], 0).contiguous()
-                packs.append((ops.mark_static(wk), bk, ops.mark_static(wv), bv))
+                wk = torch.cat([m.in_proj_weight.detach()[C:2 * C] for m in ms], 0)
+                bk = torch.cat([m.in_proj_bias.detach()[C:2 * C] for m in ms], 0)
+                wv = torch.cat([m.in_proj_weight.detach()[2 * C:] for m in ms], 0)
+                bv = torch.cat([m.in_proj_bias.detach()[2 * C:] for m in ms], 0)
+                pv = prevs[lvl] if prevs[lvl] is not None else (None,) * 4                    # refreshed in place after an optimizer step
+                packs.append((ops.repack(pv[0], wk), ops.repack(pv[1], bk), ops.repack(pv[2], wv), ops.repack(pv[3], bv)))
             self._kv_cache = (key, packs)
         return self._kv_cache[1]
 

@@ -81,6 +81,20 @@ def bump_version(t):
     base._s2d_version = getattr(base, "_s2d_version", 0) + 1
 
 
+def repack(old, new):
+    """A module's cached packed weight copy after its sources changed: when the previous copy has the same shape it is overwritten
+    IN PLACE (torch's counter moves, so the caches hanging off its address -- split images, transposed / flipped copies -- refresh
+    into their existing buffers); otherwise `new` becomes the copy.  A fresh tensor per optimizer step would leave a dead generation of
+    every such cache behind per step."""
+    if old is not None and old.shape == new.shape and old.device == new.device and old.dtype == new.dtype:
+        old.copy_(new)
+        return old
+    new = new.contiguous()
+    if new._base is not None:
+        new = new.clone()
+    return mark_static(new)
+
+
 def mark_static(t):
     """Declare a tensor a static weight (a packed / concatenated copy of parameters that its module caches): dense launches
     reading it as the B operand may then use a cached pre-split fp16 image instead of splitting it in every launch."""

@@ -91,12 +91,17 @@ def test_weight_caches_follow_the_multi_tensor_optimizer_step():
         f = F.layer_norm(s1 + F.linear(torch.relu(F.linear(s1, lin.weight, lin.bias)), lin2.weight, lin2.bias), (256,))
         return y, c, f, y @ lin.weight, F.linear(x, ema[0], ema[1])
 
-    for it in range(3):
+    sizes = []
+    for it in range(6):
         for a, b in zip(device_side(), torch_side()):
             assert float((a - b.detach()).abs().max()) < 2e-4 * float(b.abs().max()) + 1e-5, it
         for p in params:
             p.grad.copy_(torch.randn_like(p))
         opt.step(ema_momentum=0.9)
+        sizes.append((len(ops._SPLIT), len(ops._FFN_PACK), len(B._WT), len(B._WF), id(conv.packed()[0])))
+    # ... and the refresh happens IN PLACE: no cache gains an entry per step, the packed ConvBN weight keeps its buffer (a copy that
+    # kept a replaced weight alive, or a fresh packed tensor per step, leaks a generation of every cache per iteration)
+    assert sizes[2] == sizes[5], sizes
 
 
 def test_transpose_odd_shapes():
