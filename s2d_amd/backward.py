@@ -233,8 +233,10 @@ def _sweep(cache):
 def _transposed_weight(w, Np):
     """W^T [K,Np] of a weight [N,K] (zero columns beyond N), cached per weight version and marked static so that the dense
     kernels also cache its pre-split image: the dgrad GEMMs then run on the same kernels as the forward's"""
-    w = w.detach()
+    # the owner is identified BEFORE detaching: a detached alias is a fresh object on every call (and does not carry the library's
+    # version attribute), so keying on it would rebuild the copy at every call
     base = w._base if w._base is not None else w
+    w = w.detach()
     key = (w.data_ptr(), tuple(w.shape), Np)
     ent = _WT.get(key)
     if ent is None or ent[2]() is not base:
@@ -259,8 +261,8 @@ def _flipped_weight(w):
     """the dgrad kernel of a convolution weight [Cout,KH,KW,Cin]: taps flipped, channels swapped -> [Cin,KH,KW,Cout]; cached per
     weight version and marked static (like _transposed_weight), so that the dgrad convolutions run on the forward's kernels with
     a pre-split image"""
+    base = w._base if w._base is not None else w          # (see _transposed_weight)
     w = w.detach()
-    base = w._base if w._base is not None else w
     key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
     ent = _WF.get(key)
     if ent is None or ent[2]() is not base:

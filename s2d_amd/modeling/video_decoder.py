@@ -92,8 +92,8 @@ class SelfAttentionLayer(nn.Module):
         dW = torch.cat([Bk.weight_grad(d_qk, qk_in.view(-1, C)), Bk.weight_grad(dv.view(-1, C), tgt.view(-1, C))], 0)
         Bk.acc(m.in_proj_weight, dW)
         Bk.acc(m.in_proj_bias, torch.cat([Bk.bias_grad(d_qk), Bk.bias_grad(dv.view(-1, C))], 0))
-        d_in = Bk.input_grad(d_qk, W[:2 * C].detach().contiguous()).view(B, Q, C)                 # d(tgt + query_pos)
-        d_tgt = Bk.input_grad(dv.view(-1, C), W[2 * C:].detach().contiguous(), res=d2).view(B, Q, C) + d_in
+        d_in = Bk.input_grad(d_qk, W[:2 * C]).view(B, Q, C)                 # d(tgt + query_pos)
+        d_tgt = Bk.input_grad(dv.view(-1, C), W[2 * C:], res=d2).view(B, Q, C) + d_in
         return d_tgt, Bk.sum_slices(d_in)
 
 
@@ -135,7 +135,7 @@ class CrossAttentionLayer(nn.Module):
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
         dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead)
         dq2 = dq.view(-1, C)
-        Wq = m.in_proj_weight[:C].detach().contiguous()
+        Wq = m.in_proj_weight[:C]
         self._dWq, self._dbq = Bk.weight_grad(dq2, q_in.view(-1, C)), Bk.bias_grad(dq2)            # merged with the k / v rows later
         d_in = Bk.input_grad(dq2, Wq).view(B, Q, C)
         return d_in + d_x, Bk.sum_slices(d_in), dk, dv
