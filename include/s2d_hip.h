@@ -424,6 +424,9 @@ int s2d_multi_add_f32(const long *table, const int *chunk_tensor, const long *ch
 
 /* out[i] = beta * out[i] + sum_{s < S} part[s * stride + i], s ascending (fixed order: reproducible split-K) */
 int s2d_reduce_slices_f32(const float *part, int S, long n, long stride, float beta, float *out, hipStream_t stream);
+/* two such reductions with the same slice count in one launch (a weight gradient and its bias gradient): same bits as two calls */
+int s2d_reduce_slices_pair_f32(const float *partA, long nA, long strideA, float betaA, float *outA, const float *partB, long nB, long strideB,
+                               float betaB, float *outB, int S, hipStream_t stream);
 
 /* part[s][c] = sum of in[r][c] over the rows of slice s (rows_per_slice rows each, ceil(R / rows_per_slice) slices):
  * bias gradients, finished by s2d_reduce_slices_f32 */

@@ -161,16 +161,18 @@ def weight_grad(dy, x, out=None, beta=0.0, bias_out=None, bias_beta=0.0):
         lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, bpart, _st())
         # one slice (short contractions: the video decoder's 200 query rows): nothing to reduce -- the slice IS the result, and an
         # accumulation into an existing gradient joins the pending multi-tensor add instead of taking a launch of its own
-        if bias_out is not None and not (S == 1 and bias_beta == 1.0 and _defer_add(bias_out, bpart.view(-1))):
-            lib().call("s2d_reduce_slices_f32", bpart, S, N, N, float(bias_beta), bias_out, _st())
+        bias_pending = bias_out is not None and not (S == 1 and bias_beta == 1.0 and _defer_add(bias_out, bpart.view(-1)))
         if out is None:
-            if S == 1:
+            if S == 1 and not bias_pending:
                 return part.view(N, K)
             out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
             beta = 0.0
-        elif S == 1 and beta == 1.0 and _defer_add(out, part.view(N, K)):
+        elif S == 1 and beta == 1.0 and not bias_pending and _defer_add(out, part.view(N, K)):
             return out
-        lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
+        if bias_pending:                                  # both reductions in one launch
+            lib().call("s2d_reduce_slices_pair_f32", part, N * K, N * K, float(beta), out, bpart, N, N, float(bias_beta), bias_out, S, _st())
+        else:
+            lib().call("s2d_reduce_slices_f32", part, S, N * K, N * K, float(beta), out, _st())
         return out
     if bias_out is not None:
         bias_grad(dy, out=bias_out, beta=bias_beta)

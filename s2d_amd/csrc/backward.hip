@@ -363,6 +363,33 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
     *reinterpret_cast<f32x4 *>(col + i * 4) = v;
 }
 
+// two slice reductions of the same slice count in one launch (a weight gradient and the bias gradient that left the TN kernel with it)
+__global__ __launch_bounds__(256) void reduce_slices_pair_kernel(const float *__restrict__ partA, long nA, long strideA, float betaA, float *__restrict__ outA,
+                                                                 const float *__restrict__ partB, long nB, long strideB, float betaB, float *__restrict__ outB,
+                                                                 int S)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool second = i >= nA;
+    if (second) i -= nA;
+    if (second && i >= nB) return;
+    const float *p = (second ? partB : partA) + i;
+    const long stride = second ? strideB : strideA;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                   // the same eight chains and the same final tree as reduce_slices_kernel: same bits
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    for (int j = 0; s < S; ++s, ++j) a[j] += p[(long)s * stride];
+    const float sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    float *o = (second ? outB : outA) + i;
+    const float beta = second ? betaB : betaA;
+    *o = beta == 0.f ? sum : beta * *o + sum;
+}
+
 // dst_i += src_i for a list of tensors in ONE launch: table [n][3] = (src pointer, dst pointer, element count) as 64-bit words, a block
 // takes one chunk of one tensor (chunk_tensor / chunk_off name it).  The ~350 "param.grad += g" of a training iteration's glue.
 __global__ __launch_bounds__(256) void multi_add_kernel(const long *__restrict__ table, const int *__restrict__ chunk_tensor,
@@ -473,6 +500,17 @@ int s2d_reduce_slices_f32(const float *part, int S, long n, long stride, float b
     if (S < 0 || n < 0 || stride < n) return S2D_ERR_ARG;
     if (n == 0) return S2D_OK;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, part, S, n, stride, beta, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_reduce_slices_pair_f32(const float *partA, long nA, long strideA, float betaA, float *outA, const float *partB, long nB, long strideB,
+                               float betaB, float *outB, int S, hipStream_t stream)
+{
+    if (S < 0 || nA < 0 || nB < 0 || strideA < nA || strideB < nB) return S2D_ERR_ARG;
+    if (nA + nB == 0) return S2D_OK;
+    hipLaunchKernelGGL(reduce_slices_pair_kernel, dim3(cdiv(nA + nB, 256)), dim3(256), 0, stream, partA, nA, strideA, betaA, outA, partB, nB, strideB,
+                       betaB, outB, S);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
