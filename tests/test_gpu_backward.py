@@ -104,6 +104,44 @@ def test_weight_caches_follow_the_multi_tensor_optimizer_step():
     assert sizes[2] == sizes[5], sizes
 
 
+def test_deferred_gradient_accumulation_and_paired_slice_reduction():
+    """backward.acc in the deferred mode (one multi-tensor launch per flush, a second contribution to the same gradient forces a flush)
+    against immediate `param.grad += g`, on odd sizes and unaligned views; s2d_reduce_slices_pair_f32 against two single reductions"""
+    from s2d_amd import backward as B
+    from s2d_amd._lib import lib
+    g = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(7,), (256, 256), (1024, 256), (3, 5, 7), (1,), (70001,), (33, 3)]
+    arena = torch.randn((sum(int(np.prod(sh)) for sh in shapes) + 64,), device=DEV, generator=g)
+    params, ref, o = [], [], 3                                       # gradients are views of one arena at odd offsets, like the optimizer's
+    for sh in shapes:
+        n = int(np.prod(sh))
+        p = torch.nn.Parameter(torch.zeros(sh, device=DEV))
+        p.grad = arena[o:o + n].view(sh)
+        params.append(p); ref.append(p.grad.clone()); o += n
+    adds = [[torch.randn(sh, device=DEV, generator=g) for sh in shapes] for _ in range(3)]
+    B.begin_deferred_acc()
+    try:
+        for rnd in adds:                                             # rounds 2 and 3 hit pending destinations: flushes in between
+            for p, a in zip(params, rnd):
+                B.acc(p, a)
+    finally:
+        B.flush_acc(end=True)
+    for r, rnd in zip(ref, zip(*adds)):
+        for a in rnd:
+            r += a
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r)
+    S, N, K = 5, 132, 64
+    pa, pb = torch.randn((S, N, K), device=DEV, generator=g), torch.randn((S, N), device=DEV, generator=g)
+    oa, ob = torch.randn((N, K), device=DEV, generator=g), torch.randn((N,), device=DEV, generator=g)
+    ea, eb = oa.clone(), ob.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    lib().call("s2d_reduce_slices_f32", pa, S, N * K, N * K, 1.0, ea, st)
+    lib().call("s2d_reduce_slices_f32", pb, S, N, N, 0.0, eb, st)
+    lib().call("s2d_reduce_slices_pair_f32", pa, N * K, N * K, 1.0, oa, pb, N, N, 0.0, ob, S, st)
+    assert torch.equal(oa, ea) and torch.equal(ob, eb)
+
+
 def test_transpose_odd_shapes():
     from s2d_amd import backward
     for R, C, pad in ((1, 1, None), (65, 130, None), (1000, 37, 1024), (129, 64, 160)):
