@@ -198,6 +198,16 @@ int s2d_msda_backward_dev_f32(const float *value, const int64_t *shapes_dev, con
  * into it (system scope, never cleared by the library): the caller tests the word with a plain host read before / after its calls and
  * raises -- at the latest one call after the offending one has executed -- instead of training on zeros.  The drop-in module
  * (s2d_amd/compat/MultiScaleDeformableAttention.py) does exactly that. */
+/* float64 instantiation of the drop-in op (the reference extension dispatches on floating types, ms_deform_attn_cuda.cu:69, :137; its
+ * ops/test.py gradchecks in double): same argument kinds as the *_dev_f32 entries, no workspace.  Not a hot path -- one thread per
+ * output channel, grad_value / grad_sampling_loc / grad_attn_weight accumulated with double atomics (as the reference's col2im kernels
+ * do), so the gradients are reproducible to rounding, not bitwise.  A level that does not lie inside S contributes nothing. */
+int s2d_msda_forward_dev_f64(const double *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const double *loc,
+                             const double *attn_w, int N, int S, int M, int D, int L, int Lq, int P, double *out, hipStream_t stream);
+int s2d_msda_backward_dev_f64(const double *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const double *loc,
+                              const double *attn_w, const double *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                              double *grad_value, double *grad_loc, double *grad_attn_w, hipStream_t stream);
+
 int s2d_msda_dev_error_word(int *word);
 /* *err_host = the error flag of the *_dev call that used `workspace` (0 = shapes accepted).  Synchronises `stream`. */
 int s2d_msda_dev_status(const void *workspace, int *err_host, hipStream_t stream);

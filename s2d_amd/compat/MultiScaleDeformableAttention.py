@@ -8,7 +8,8 @@ clips with different pyramids (MIN_SIZE_TRAIN (360, 480) + random crop) cannot m
 
 Conventions kept from the CUDA extension (ops/src/cuda/ms_deform_attn_cuda.cu:33-57, :93-116): every tensor must be
 contiguous and on the GPU, else RuntimeError; `batch % min(batch, im2col_step) == 0`; outputs are freshly allocated; work is
-enqueued on the current stream.  Differences: float32 only (the path's dtype; the extension also instantiates float64), and
+enqueued on the current stream.  float32 is the path's dtype (the atomic-free kernels); float64 tensors take the extension's other
+instantiation (s2d_msda_*_dev_f64: simple kernels for gradient checks in double, ops/test.py).  Difference:
 `im2col_step` only takes part in that check -- the kernels need no batch chunking.  There is no torch fallback: a missing
 library raises at import."""
 import os
@@ -70,7 +71,8 @@ def _check(name, t, dtype=torch.float32):
 
 
 def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
-    _check("value", value); _check("sampling_loc", sampling_loc); _check("attn_weight", attn_weight)
+    dt = value.dtype if isinstance(value, torch.Tensor) and value.dtype == torch.float64 else torch.float32
+    _check("value", value, dt); _check("sampling_loc", sampling_loc, dt); _check("attn_weight", attn_weight, dt)
     _check("spatial_shapes", spatial_shapes, torch.int64); _check("level_start_index", level_start_index, torch.int64)
     _raise_if_flagged()
     batch = value.shape[0]
@@ -89,6 +91,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     """value [N,S,M,D], spatial_shapes [L,2] (H,W), level_start_index [L], sampling_loc [N,Lq,M,L,P,2], attn_weight
     [N,Lq,M,L,P] -> [N,Lq,M*D]"""
     _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    if value.dtype == torch.float64:                     # the extension's other instantiation (ops/test.py gradchecks in double)
+        N, S, M, D = value.shape
+        Lq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+        out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float64)
+        lib().call("s2d_msda_forward_dev_f64", value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out,
+                   torch.cuda.current_stream().cuda_stream)
+        return out
     out, ws = ops.msda_forward_dev(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, want_ws=True)
     _status(ws)
     return out
@@ -97,7 +106,14 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]"""
     _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
-    _check("grad_output", grad_output)
+    _check("grad_output", grad_output, value.dtype)
+    if value.dtype == torch.float64:
+        N, S, M, D = value.shape
+        Lq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+        gv, gl, gw = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+        lib().call("s2d_msda_backward_dev_f64", value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, N, S, M, D, L,
+                   Lq, P, gv, gl, gw, torch.cuda.current_stream().cuda_stream)
+        return [gv, gl, gw]
     gv, gl, gw, ws = ops.msda_backward_dev(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, want_ws=True)
     _status(ws)
     return [gv, gl, gw]

@@ -1299,6 +1299,66 @@ static int launch_geom(const int64_t *shapes_dev, const int64_t *lsi_dev, int L,
 constexpr long GEOM_BYTES = 256;
 static_assert(sizeof(Geom) <= GEOM_BYTES, "Geom outgrew its workspace slot");
 
+// ---- float64 instantiation of the drop-in op (ops/src/cuda/ms_deform_attn_cuda.cu:69, :137: AT_DISPATCH_FLOATING_TYPES; the reference's
+// ops/test.py gradchecks the op in double).  Not a hot path: one thread per (n, q, m, channel), shapes read from the DEVICE tensors, a
+// level that does not lie inside S contributes nothing; the backward scatters grad_value with double atomics (like the reference's
+// col2im kernels) and adds the channel sums of grad_sampling_loc / grad_attn_weight with double atomics too.
+__device__ __forceinline__ bool level_ok_f64(const int64_t *shapes, const int64_t *lsi, int l, long S, int &H, int &W, long &st)
+{
+    const int64_t h = shapes[2 * l], w = shapes[2 * l + 1], s0 = lsi[l];
+    H = (int)h; W = (int)w; st = (long)s0;
+    return h > 0 && w > 0 && h < (1 << 20) && w < (1 << 20) && s0 >= 0 && s0 + h * w <= S;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void msda_f64_kernel(const double *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                       const int64_t *__restrict__ lsi, const double *__restrict__ loc,
+                                                       const double *__restrict__ aw, const double *__restrict__ gout, long S, int M, int D,
+                                                       int L, long Lq, int P, long total, double *__restrict__ out,
+                                                       double *__restrict__ gvalue, double *__restrict__ gloc, double *__restrict__ gaw)
+{
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= total) return;
+    const int d = (int)(item % D);
+    const int m = (int)((item / D) % M);
+    const long q = (item / ((long)D * M)) % Lq;
+    const long n = item / ((long)D * M * Lq);
+    const long qm = (n * Lq + q) * M + m;
+    const double go = BWD ? gout[qm * D + d] : 0.0;
+    double acc = 0.0;
+    for (int l = 0; l < L; ++l) {
+        int H, W; long st;
+        if (!level_ok_f64(shapes, lsi, l, S, H, W, st)) continue;
+        const double *vb = value + ((n * S + st) * M + m) * D + d;
+        double *gb = BWD ? gvalue + ((n * S + st) * M + m) * D + d : nullptr;
+        const long rs = (long)M * D;
+        for (int p = 0; p < P; ++p) {
+            const long wi = (qm * L + l) * P + p;
+            const double lx = loc[2 * wi], ly = loc[2 * wi + 1], a = aw[wi];
+            const double h_im = ly * H - 0.5, w_im = lx * W - 0.5;                    // cuh:262-263
+            if (!(h_im > -1 && w_im > -1 && h_im < H && w_im < W)) continue;           // cuh:265
+            const int h0 = (int)floor(h_im), w0 = (int)floor(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const double lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+            const bool o1 = h0 >= 0 && w0 >= 0, o2 = h0 >= 0 && w1 <= W - 1, o3 = h1 <= H - 1 && w0 >= 0, o4 = h1 <= H - 1 && w1 <= W - 1;
+            const double v1 = o1 ? vb[((long)h0 * W + w0) * rs] : 0.0, v2 = o2 ? vb[((long)h0 * W + w1) * rs] : 0.0;
+            const double v3 = o3 ? vb[((long)h1 * W + w0) * rs] : 0.0, v4 = o4 ? vb[((long)h1 * W + w1) * rs] : 0.0;
+            const double w1_ = hh * hw, w2_ = hh * lw, w3_ = lh * hw, w4_ = lh * lw;
+            const double val = w1_ * v1 + w2_ * v2 + w3_ * v3 + w4_ * v4;             // cuh:19-63
+            if (!BWD) { acc += val * a; continue; }
+            const double tg = go * a;                                                  // cuh:66-137
+            if (o1) atomicAdd(gb + ((long)h0 * W + w0) * rs, w1_ * tg);
+            if (o2) atomicAdd(gb + ((long)h0 * W + w1) * rs, w2_ * tg);
+            if (o3) atomicAdd(gb + ((long)h1 * W + w0) * rs, w3_ * tg);
+            if (o4) atomicAdd(gb + ((long)h1 * W + w1) * rs, w4_ * tg);
+            const double gh = -hw * v1 - lw * v2 + hw * v3 + lw * v4, gw = -hh * v1 + hh * v2 - lh * v3 + lh * v4;
+            atomicAdd(gaw + wi, go * val);
+            atomicAdd(gloc + 2 * wi, W * gw * tg);
+            atomicAdd(gloc + 2 * wi + 1, H * gh * tg);
+        }
+    }
+    if (!BWD) out[qm * D + d] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1357,6 +1417,35 @@ int s2d_msda_backward_sorted_strided_f32(const float *value, long ldv, const int
     if (N <= 0 || Lq <= 0) return S2D_OK;
     return launch_backward_sorted(gv, (long)gv.g.kmax, value, loc, attn_w, grad_out, N, S, M, L, Lq, P, grad_value, grad_loc, grad_attn_w,
                                   reinterpret_cast<char *>(workspace), workspace_bytes, stream, ldv, ldg);
+}
+
+int s2d_msda_forward_dev_f64(const double *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const double *loc,
+                             const double *attn_w, int N, int S, int M, int D, int L, int Lq, int P, double *out, hipStream_t stream)
+{
+    if (N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return S2D_ERR_ARG;
+    const long total = (long)N * Lq * M * D;
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL((msda_f64_kernel<false>), dim3(cdiv(total, 256)), dim3(256), 0, stream, value, shapes_dev, level_start_dev, loc, attn_w,
+                       (const double *)nullptr, (long)S, M, D, L, (long)Lq, P, total, out, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_msda_backward_dev_f64(const double *value, const int64_t *shapes_dev, const int64_t *level_start_dev, const double *loc,
+                              const double *attn_w, const double *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                              double *grad_value, double *grad_loc, double *grad_attn_w, hipStream_t stream)
+{
+    if (N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return S2D_ERR_ARG;
+    if (s2d_zero_async(grad_value, sizeof(double) * (size_t)N * S * M * D, stream) != S2D_OK ||
+        s2d_zero_async(grad_loc, sizeof(double) * (size_t)N * Lq * M * L * P * 2, stream) != S2D_OK ||
+        s2d_zero_async(grad_attn_w, sizeof(double) * (size_t)N * Lq * M * L * P, stream) != S2D_OK)
+        return S2D_ERR_LAUNCH;
+    const long total = (long)N * Lq * M * D;
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL((msda_f64_kernel<true>), dim3(cdiv(total, 256)), dim3(256), 0, stream, value, shapes_dev, level_start_dev, loc, attn_w,
+                       grad_out, (long)S, M, D, L, (long)Lq, P, total, (double *)nullptr, grad_value, grad_loc, grad_attn_w);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
 }
 
 long s2d_msda_dev_forward_workspace_bytes(void) { return GEOM_BYTES; }

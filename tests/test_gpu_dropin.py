@@ -134,6 +134,40 @@ def test_msda_compat_module_and_function(oracle):
         MSDA.ms_deform_attn_forward(torch.cat([v, v[:1]]), shapes, lsi, torch.cat([loc, loc[:1]]), torch.cat([w, w[:1]]), 2)   # 3 % 2
 
 
+def test_msda_compat_float64_instantiation_forward_and_gradcheck():
+    """the extension's float64 instantiation (ms_deform_attn_cuda.cu:69, :137), as the reference's ops/test.py exercises it: forward
+    against a float64 grid_sample evaluation of the same sum (ms_deform_attn_func.py:52-72) and torch.autograd.gradcheck of
+    MSDeformAttnFunction in double, channels not a multiple of 32, a level with out-of-map samples"""
+    import s2d_amd.compat as compat
+    compat.install()
+    import MultiScaleDeformableAttention as MSDA
+    from s2d_amd.compat.ms_deform_attn_func import MSDeformAttnFunction
+    dev = torch.device(DEV)
+    g = torch.Generator(device=dev).manual_seed(11)
+    N, M, D, Lq, L, P = 2, 3, 10, 5, 2, 3
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = torch.rand((N, S, M, D), device=dev, dtype=torch.float64, generator=g) * 0.01
+    loc = torch.rand((N, Lq, M, L, P, 2), device=dev, dtype=torch.float64, generator=g) * 1.2 - 0.1       # some samples outside the maps
+    w = torch.rand((N, Lq, M, L, P), device=dev, dtype=torch.float64, generator=g) + 1e-5
+    w = w / w.sum((-1, -2), keepdim=True)
+    out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, w, 2)
+    assert out.dtype == torch.float64 and out.shape == (N, Lq, M * D)
+    ref = torch.zeros((N, Lq, M, D), device=dev, dtype=torch.float64)
+    for l, (H, W) in enumerate(shapes.tolist()):
+        vl = value[:, int(lsi[l]):int(lsi[l]) + H * W].permute(0, 2, 3, 1).reshape(N * M, D, H, W)
+        grid = (2 * loc[:, :, :, l] - 1).permute(0, 2, 1, 3, 4).reshape(N * M, Lq, P, 2)
+        smp = torch.nn.functional.grid_sample(vl, grid, mode="bilinear", padding_mode="zeros", align_corners=False)      # [N*M, D, Lq, P]
+        ref += (smp.view(N, M, D, Lq, P) * w[:, :, :, l].permute(0, 2, 1, 3)[:, :, None]).sum(-1).permute(0, 3, 1, 2)
+    assert float((out.view(N, Lq, M, D) - ref).abs().max()) < 1e-14
+    vr, lr, wr = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b, c: MSDeformAttnFunction.apply(a, shapes, lsi, b, c, 2), (vr, lr, wr), eps=1e-6, atol=1e-7,
+                                    rtol=1e-5, nondet_tol=1e-12)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(value, shapes, lsi, loc.float(), w, 2)                 # mixed precisions
+
+
 def test_msda_compat_fresh_shape_tensors_of_different_pyramids(oracle):
     """The reference builds `spatial_shapes` / `level_start_index` fresh on every forward (msdeformattn.py:82-83:
     torch.as_tensor(list) -> cat / cumsum) and frees them afterwards, so the caching allocator hands the same small blocks to the
