@@ -72,39 +72,73 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
     teach = dict(zip((id(p) for p in model.student.parameters()), model.teacher.parameters()))
     opt = FullModelGradientClippingAdamW(groups, lr=1e-4, clip_norm=0.01, ema_params=[teach[id(g["params"][0])] for g in groups])
     from s2d_amd.optim import OverlappedAllReduce, student_parts
+    # The gradient exchange: ONE SUM all-reduce of the arena behind the backward is the default (optim.allreduce_grads); the
+    # per-part exchange started while the backward still runs (OverlappedAllReduce) is opt-in (S2D_OVERLAP_ALLREDUCE=1) until it has
+    # run on real multi-GPU hardware -- at N > 1 this report times it too and compares its reduced arena with the one-shot exchange's.
+    overlap_default = os.environ.get("S2D_OVERLAP_ALLREDUCE", "0") == "1"
     exchange = OverlappedAllReduce(opt, student_parts(model))
     losses, times, t_ar = [], [], []
     WARM = 4                                            # the caching allocator settles over the first iterations (0 hipMalloc from the fifth on)
     st0 = torch.cuda.memory_stats()
-    for i in range(iters + WARM):
-        if i == WARM:
-            st0 = torch.cuda.memory_stats()
+
+    def iteration(overlap, step=True):
         _fence(world)
         t0 = time.perf_counter()
         images = ops.normalize_pad(frames, 32, mean, std)
         targets = TargetSet.from_list(masks, device=dev)
         opt.zero_grad()
-        out = model.forward_backward(images, targets, grad_ready=exchange.ready)     # buckets go out while the backward still runs
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        inv = exchange.finish()
+        if overlap:
+            out = model.forward_backward(images, targets, grad_ready=exchange.ready)     # buckets go out while the backward still runs
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            inv = exchange.finish()
+        else:
+            out = model.forward_backward(images, targets)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            inv = opt.allreduce_grads()
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        opt.step(inv_scale=inv, ema_momentum=0.999)
+        if step:
+            opt.step(inv_scale=inv, ema_momentum=0.999)
         tot = float(sum(out.values()))
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0); t_ar.append(t2 - t1); losses.append(round(tot, 4))
+        return time.perf_counter() - t0, t2 - t1, round(tot, 4)
+
+    for i in range(iters + WARM):
+        if i == WARM:
+            st0 = torch.cuda.memory_stats()
+        dt, dar, tot = iteration(overlap_default)
+        times.append(dt); t_ar.append(dar); losses.append(tot)
+    st1 = torch.cuda.memory_stats()
+    other = None
+    if world > 1:
+        # the other exchange mode, timed the same way, and both modes on the SAME batch and seeds without stepping: the reduced
+        # arenas must agree (bitwise at 2 ranks; to summation order beyond, since a ring reduces a sub-range in another rank order)
+        t_o = [iteration(not overlap_default)[0] for _ in range(iters)]
+        arenas = []
+        for ov in (False, True):
+            model.criterion.seed = 0; model.criterion.matcher.seed = 0
+            torch.manual_seed(5); ops._DROP_CALLS[0] = 0
+            iteration(ov, step=False)
+            arenas.append(opt.grad_arena.clone())
+        d = float((arenas[0] - arenas[1]).abs().max() / (arenas[0].abs().max() + 1e-30))
+        other = {"mode": "overlapped per part" if not overlap_default else "one all-reduce behind the backward",
+                 "ms_per_iteration": round(1000 * _max_over_ranks(sum(t_o) / iters, world, cdev or dev), 1),
+                 "reduced_arena_max_rel_diff_between_modes": d, "bitwise_equal": bool(torch.equal(arenas[0], arenas[1]))}
+        del arenas
     assert all(map(lambda v: v == v and abs(v) != float("inf"), losses)) and not opt.found_inf()
     ms = 1000 * _max_over_ranks(sum(times[WARM:]) / iters, world, cdev or dev)
     ar = 1000 * _max_over_ranks(sum(t_ar[WARM:]) / iters, world, cdev or dev)
     return {"what": "one full training iteration per rank on its batch: fwd + loss (student + teacher, GT + KD) + backward of the student "
-                    "(HIP gradient kernels, no autograd graph) + gradient all-reduce (per part of the student, started while the backward of the remaining parts "
-                    "runs; allreduce_ms = what is left to wait for after the backward) + full-model clip + AdamW + EMA teacher update; fp32, "
+                    "(HIP gradient kernels, no autograd graph) + gradient all-reduce ("
+                    + ("per part of the student, started while the backward of the remaining parts runs; allreduce_ms = what is left to wait for after the backward"
+                       if overlap_default else "one SUM all-reduce of the arena behind the backward") + ") + full-model clip + AdamW + EMA teacher update; fp32, "
                     + ("teacher forward and GT criterion on a second stream" if model.overlap_teacher else "one stream"),
             "ms_per_iteration": round(ms, 1), "clip_frames_per_s": round(world * frames.shape[0] / (ms / 1000), 2),
             "allreduce_ms": round(ar, 2), "allreduce_bytes": int(opt.grad_arena.numel() * 4), "n_gpus": world,
             "iterations": iters, "warmup_iterations": WARM, "loss_per_iteration_rank0": losses,
             "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "ms_each_rank0": [round(1000 * t, 1) for t in times],
-            "allocator_in_timed_iterations": {k: torch.cuda.memory_stats().get(k, 0) - st0.get(k, 0) for k in
-                                              ("num_alloc_retries", "num_device_alloc", "num_device_free")}}
+            "allocator_in_timed_iterations": {k: st1.get(k, 0) - st0.get(k, 0) for k in
+                                              ("num_alloc_retries", "num_device_alloc", "num_device_free")},
+            "other_exchange_mode": other}
 
 
 def synth_batch(rank, B, T, H0, W0, N, device):
@@ -245,13 +279,16 @@ def cpu_baseline(cfg_name):
             return _oracle_sample(cfg_name, Ts), omp
 
     _warm_oracle(cores, threadpool_limits)      # thread-pool start-up and library loads are not part of any stage
-    Ts = 2
+    # one REAL clip of the workload (all T frames: the cross-frame attention over T * hw keys and the T-frame matcher / point loss are
+    # timed, not extrapolated from a shorter clip); S2D_CPU_BASELINE_FRAMES shortens it for quick runs
+    Ts = max(1, min(T, int(os.environ.get("S2D_CPU_BASELINE_FRAMES", T))))
     st, omp = run(cores, Ts)
     dt = sum(st.values())
     out = {"value": round(Ts / (2.0 * dt), 5), "unit": "clip-frames/s", "cores": cores, "kind": "port",
-           "sample": f"oracle port, extrapolated x2: one {Ts}-frame clip {H0}x{W0} (Q={Q}, P={P}, N={N}): student fwd + 10-layer GT criterion + KD "
+           "sample": f"oracle port: one {Ts}-frame clip {H0}x{W0} of the workload (Q={Q}, P={P}, N={N}): student fwd + 10-layer GT criterion + KD "
                      f"target prep took {dt:.1f}s on {cores} threads (BLAS and OpenMP {omp}; usable cores of {os.cpu_count()} host threads; python "
-                     f"loops between the kernels single-threaded); KD step = 2x (teacher fwd + KD criterion) -> frames/s = {Ts}/(2*{dt:.1f})",
+                     f"loops between the kernels single-threaded); the KD step runs the same network and criterion twice (teacher fwd + KD "
+                     f"criterion: same code, same shapes) -> frames/s = {Ts}/(2*{dt:.1f})",
            "stage_seconds": {k: round(v, 3) for k, v in st.items()}}
     if cores > 1:
         st1, _ = run(1, 1)
@@ -636,6 +673,23 @@ def main():
         if args.config == "c4":
             res["hbm_roofline"] = {"algorithmic_GB_per_frame": 19.0, "peak_TBps": 8.0,
                                    "frac": round(res["value"] / world * 19.0 / 8000.0, 4), "target_frac": 0.4}
+            if not model.teacher_aux_masks:
+                # The 19.0 GB/frame of SURVEY 8d counts ten FULL mask-logit einsums + attention-mask resizes for the teacher too.  The
+                # step evaluates the teacher's intermediate heads only at the pixels its attention masks read (1/32 and 1/16 levels:
+                # 4 bilinear taps per key; outputs bit-identical): those bytes are not moved, so the fraction is also given against
+                # the bytes net of them.
+                Hp, Wp = (H0 + 31) // 32 * 32, (W0 + 31) // 32 * 32
+                hm, wm = Hp // 4, Wp // 4
+                npx = T * hm * wm
+                saved = 0.0
+                for div in (32, 16):                        # three intermediate heads feed each level (heads 0,3,6 / 1,4,7)
+                    ntap = min(4 * T * (Hp // div) * (Wp // div), npx)
+                    saved += 3 * B * (4.0 * (npx - ntap) * (256 + Q)            # einsum: feature rows read + logits written
+                                      + 4.0 * Q * (npx - ntap))                 # attention-mask builder: logits read
+                net = 19.0 - saved / 1e9 / (B * T)
+                res["hbm_roofline"].update({"skipped_teacher_mask_GB_per_step": round(saved / 1e9, 2),
+                                            "algorithmic_GB_per_frame_net": round(net, 3),
+                                            "frac_net_of_skipped_teacher_masks": round(res["value"] / world * net / 8000.0, 4)})
         if amp_res is not None:
             res["amp"] = amp_res
         if prof and args.dense_breakdown:

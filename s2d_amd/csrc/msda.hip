@@ -358,6 +358,145 @@ __global__ __launch_bounds__(TILED ? 1024 : 256) void msda_fused_kernel(const fl
     *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + c * V) = acc;
 }
 
+// Record form of the fused kernel (round 5; the default for the S2D geometry L = 3, P = 4, M = 8, D = 32).
+// The TILED form above spends half its time outside the gathers (profiles/r4_experiments/msda_dbg.txt: 0.32 of 0.67 ms with no gather
+// at all), and its ISA shows why: per sample 7 ds_bpermute + a wait, two scalar loads of the level's geometry (the level index is i / P
+// with a runtime P) + a wait, ~25 scalar instructions of exec juggling around the border cases, then four loads and `s_waitcnt vmcnt(0)`
+// before the next sample starts -- ~600 scalar instructions per query on the CU's one scalar unit and twelve serialised
+// shuffle -> load -> use chains per wave.  Here the set-up is split off completely:
+//   phase 1  lane (head m, j) prepares samples j and j + 8 of its head as in the SHARE form (same formulas, same order) and writes one
+//            RECORD per sample into the wave's own LDS area: the four corners' BYTE OFFSETS into the frame's value slice (0x80000000 for a
+//            corner outside the map: the buffer load's bounds check then returns zeros, which is the value the reference gives a missing
+//            corner, cuh:61-83), the four bilinear weights and the attention weight;
+//   phase 2  twelve branch-free steps: the 8 lanes of a head read their record (two ds_read_b128 + one ds_read_b32, broadcast within the
+//            head, conflict-free across heads), issue four buffer_load_dwordx4 with 32-bit offsets (no 64-bit address arithmetic) and
+//            accumulate; nothing in a step depends on the previous one but the accumulator, so the compiler keeps several samples' loads
+//            in flight.
+// L and P are template constants (level of sample i known at compile time; H, W, start live in SGPRs for the whole kernel).
+// Arithmetic and accumulation order are those of msda_fused_kernel: results are bit-identical (tests/test_gpu_msda_glue.py).
+// Record row of sample i: 8 heads x 48 B + 16 B of skew (400 B: the 8 lanes of a head WRITE samples j = 0..7, 400 B apart = 4 banks
+// apart: conflict-free ds_write_b128; the heads of one sample READ 48 B apart: 12 banks).
+constexpr int REC_HEAD = 48;
+constexpr int REC_ROW = 8 * REC_HEAD + 16;
+constexpr unsigned int REC_OOB = 0x80000000u;
+
+template <int L_, int P_, int WAVES_EU>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WAVES_EU, WAVES_EU)))
+void msda_fused_rec_kernel(const float *__restrict__ value, int ldv, Levels lv, const float *__restrict__ oa, int ldoa, int S,
+                           int blk_per_n, float *__restrict__ out, unsigned int frame_bytes)
+{
+    constexpr int LP = L_ * P_, M = 8, D = 32;
+    constexpr int REC_WAVE = LP * REC_ROW;
+    static_assert(LP <= 16 && LP > 8, "two samples per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char rec_lds[];
+    const int n = blockIdx.y;
+    int tb = xcd_band(blockIdx.x, blk_per_n), lq = 0, ntx = 1;
+#pragma unroll
+    for (; lq < L_; ++lq) {
+        ntx = (lv.W[lq] + 3) >> 2;
+        const int nt = ntx * ((lv.H[lq] + 3) >> 2);
+        if (tb < nt) break;
+        tb -= nt;
+    }
+    if (lq >= L_) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qy = (tb / ntx) * 4 + (w >> 2), qx = (tb % ntx) * 4 + (w & 3);
+    if (qy >= lv.H[lq] || qx >= lv.W[lq]) return;             // whole waves leave (patches overhanging the level's border); no workgroup barrier below
+    const int q = (int)lv.start[lq] + qy * lv.W[lq] + qx;
+    const int m = lane >> 3, j = lane & 7;
+    const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
+    const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
+    unsigned char *rec = rec_lds + w * REC_WAVE;
+
+    // ---- phase 1: softmax over the head's L * P logits, bilinear set-up of this lane's two samples, records -> LDS ----
+    const float *row = oa + ((long)n * S + q) * ldoa;
+    const float *offp_g = row + m * (LP * 2);
+    const float *lgp = row + M * LP * 2 + m * LP;
+    float own_ox[2], own_oy[2], own_lg[2], own_e[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = j + 8 * r;
+        const bool live = i < LP;
+        const int ic = live ? i : LP - 1;
+        const float2 o = *reinterpret_cast<const float2 *>(offp_g + 2 * ic);
+        own_ox[r] = o.x; own_oy[r] = o.y;
+        own_lg[r] = live ? lgp[ic] : -INFINITY;
+        mx = fmaxf(mx, own_lg[r]);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) own_e[r] = expf(own_lg[r] - mx);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) den += __shfl(own_e[i >> 3], i & 7, 8);      // index order in every lane, as the other forms
+    const float inv = 1.f / den;
+    const unsigned int ldv4 = (unsigned int)ldv * 4u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = j + 8 * r;
+        if (i < LP) {
+            const int l = i / P_;                                             // lane-dependent: selects over the (scalar) level table
+            int H = lv.H[0], W = lv.W[0], st = (int)lv.start[0];
+#pragma unroll
+            for (int k = 1; k < L_; ++k)
+                if (l == k) { H = lv.H[k]; W = lv.W[k]; st = (int)lv.start[k]; }
+            const float lx = ref_x + own_ox[r] / (float)W, ly = ref_y + own_oy[r] / (float)H;      // ms_deform_attn.py:106-109
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;   // cuh:293
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+            const f32x4 cw = {hh * hw, hh * lw, lh * hw, lh * lw};
+            const bool t = in && h0 >= 0, b = in && h1 <= H - 1, lft = w0 >= 0, rgt = w1 <= W - 1;
+            const unsigned int p00 = (unsigned int)(st + h0 * W + w0) * ldv4;  // wraps for h0 / w0 = -1; only used where the corner exists
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t off = {t && lft ? p00 : REC_OOB, t && rgt ? p00 + ldv4 : REC_OOB,
+                                 b && lft ? p00 + (unsigned int)W * ldv4 : REC_OOB, b && rgt ? p00 + (unsigned int)(W + 1) * ldv4 : REC_OOB};
+            unsigned char *d = rec + i * REC_ROW + m * REC_HEAD;
+            *reinterpret_cast<u32x4_t *>(d) = off;
+            *reinterpret_cast<f32x4 *>(d + 16) = cw;
+            *reinterpret_cast<float *>(d + 32) = own_e[r] * inv;
+        }
+    }
+    // the records cross lanes inside the wave only: LDS instructions of one wave execute in order; keep the compiler from moving the
+    // reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 2: 12 x (record, four 128-B corner rows of the head, accumulate) ----
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value + (long)n * S * ldv), 0, (int)frame_bytes, 0x00020000);
+    const unsigned int lanecol = (unsigned int)(m * D + j * 4) * 4u;
+    const unsigned char *rd = rec + m * REC_HEAD;
+    f32x4 acc = f32x4(0.f);
+    // explicit software pipeline, DEPTH samples' loads (4 x 16 B per lane each) in flight: the slot a step has just consumed is
+    // refilled with the sample DEPTH steps ahead; the scheduling fence after every step keeps the compiler from hoisting more
+    // loads than the register budget of WAVES_EU waves per SIMD holds
+    constexpr int DEPTH = WAVES_EU >= 8 ? 2 : 4;
+    f32x4 pv[DEPTH][4], pc[DEPTH];
+    float pa[DEPTH];
+    auto issue = [&](int i, int sl) {
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t off = *reinterpret_cast<const u32x4_t *>(rd + i * REC_ROW);
+        pc[sl] = *reinterpret_cast<const f32x4 *>(rd + i * REC_ROW + 16);
+        pa[sl] = *reinterpret_cast<const float *>(rd + i * REC_ROW + 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            pv[sl][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)(off[k] + lanecol), 0, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(i, i);
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const int sl = i % DEPTH;
+        acc += (pc[sl][0] * pv[sl][0] + pc[sl][1] * pv[sl][1] + pc[sl][2] * pv[sl][2] + pc[sl][3] * pv[sl][3]) * pa[sl];     // cuh:85-88, :299
+        if (i + DEPTH < LP) issue(i + DEPTH, sl);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + j * 4) = acc;
+}
+
 // One HEAD per workgroup, the coarsest level of that head in LDS.  The gather is bound by the line rate of the vector L1: every bilinear
 // tap of a (query, head) is one 128-B line, 48 per (query, head) at L x P = 12.  A head's 32 channels of the coarsest level are
 // H x W x 128 B -- 115 KB at the S2D geometry (23 x 40) -- so a workgroup that works on ONE head copies that plane into LDS once and
@@ -1619,6 +1758,23 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
         } else if (tiled && M == 8) {
             int ntile = 0;
             for (int l = 0; l < L; ++l) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);
+            // record form (default; S2D_MSDA_REC=0: the TILED form, 2: the record form at 4 waves per SIMD / 128 registers), read per call
+            int recmode = 1;
+            if (const char *e = getenv("S2D_MSDA_REC")) recmode = atoi(e);
+            const long fb = ((long)(S - 1) * ldv + (long)M * D) * 4;           // bytes of one frame's value slice as the kernel addresses it
+            if (recmode && L == 3 && P == 4 && fb < 0x7fffffffL && (long)lv.start[L - 1] * ldv * 4 < 0x7fffffffL) {
+                static S2dDevOnce attr;
+                if (!attr.done()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_rec_kernel<3, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 12 * REC_ROW) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_rec_kernel<3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 12 * REC_ROW) != hipSuccess)
+                        return S2D_ERR_LAUNCH;
+                    attr.mark();
+                }
+                if (recmode == 2)
+                    hipLaunchKernelGGL((msda_fused_rec_kernel<3, 4, 4>), dim3(ntile, N), dim3(1024), 16 * 12 * REC_ROW, stream, value, ldv, lv, offs_logits, ldoa, S, ntile, out, (unsigned int)fb);
+                else
+                    hipLaunchKernelGGL((msda_fused_rec_kernel<3, 4, 8>), dim3(ntile, N), dim3(1024), 16 * 12 * REC_ROW, stream, value, ldv, lv, offs_logits, ldoa, S, ntile, out, (unsigned int)fb);
+            } else
             hipLaunchKernelGGL((msda_fused_kernel<12, false, true, true>), dim3(ntile, N), dim3(1024), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, ntile, out);
         } else if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
         else hipLaunchKernelGGL((msda_fused_kernel<12, false, false>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);

@@ -3,6 +3,7 @@ s2d_amd.modeling: forward + loss + backward, gradient exchange, optimizer step, 
 statements `loss_dict = self.model(data)`, `self.grad_scaler.scale(losses).backward()`, `self.grad_scaler.step(self.optimizer)`
 and the EMA loop, with the data loading, copy-paste, logging and scheduling left to the trainer."""
 import math
+import os
 
 from .modeling.criterion import TargetSet
 from .modeling.meta_arch import _gt_target_list
@@ -21,9 +22,11 @@ def run_step(model, optimizer, data, iteration=0, ema_momentum=None):
     if iteration % accum == 0:
         optimizer.zero_grad()
     last = (iteration + 1) % accum == 0
-    if last and hasattr(model, "student"):
-        # the exchange starts part by part while the backward still runs (DDP's bucketed overlap, engine/defaults.py:76-85);
-        # under accumulation only the last micro-step exchanges, as DDP's no_sync() iterations do
+    if last and hasattr(model, "student") and os.environ.get("S2D_OVERLAP_ALLREDUCE", "0") == "1":
+        # opt-in: the exchange starts part by part while the backward still runs (DDP's bucketed overlap, engine/defaults.py:76-85);
+        # under accumulation only the last micro-step exchanges, as DDP's no_sync() iterations do.  The default below is ONE all-reduce
+        # of the arena behind the backward: the overlapped form has only ever run over gloo (no multi-GPU node was available to
+        # this pipeline; tests/test_gpu_multi.py runs it over RCCL wherever two GPUs are visible).
         from .optim import OverlappedAllReduce, student_parts
         ex = getattr(optimizer, "_exchange", None)
         if ex is None:

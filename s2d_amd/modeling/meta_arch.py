@@ -187,6 +187,7 @@ class KDVideoMaskFormer(nn.Module):
         # they are evaluated at the attention masks' source pixels only; True computes the full maps like the reference.
         self.teacher_aux_masks = False
         self.overlap_teacher, self._side = False, None
+        self._side_delay_cycles = 0                 # tests only: spin the side stream this many cycles before the GT criterion
 
     @classmethod
     def from_config(cls, cfg):  # kd_video_maskformer_model.py:130-231
@@ -332,13 +333,14 @@ class KDVideoMaskFormer(nn.Module):
             side.wait_stream(main)        # student outputs ready
         main.wait_stream(side)            # pseudo targets ready
         with torch.cuda.stream(crit_side):
+            if crit_side is not main and self._side_delay_cycles:      # tests: hold the side stream back (schedule-independence check)
+                torch.cuda._sleep(int(self._side_delay_cycles))
             losses = self.criterion(student, gt_targets, False, coords_gt, keep_ctx=True)
             ctx_gt = self.criterion.last_ctx
         kd = self.criterion(student, TargetSet(tgt, cnt, ne), True, coords_kd, keep_ctx=True)
         ctx_kd = self.criterion.last_ctx
         for k, v in kd.items():
             losses[k.replace("loss_", "kd_loss_")] = v
-        out = {k: v * wd[k] for k, v in losses.items() if k in wd}
         # ---- backward
         NL, B = student.class_logits.shape[:2]
         Q, T, hm, wm = student.dims
@@ -354,6 +356,9 @@ class KDVideoMaskFormer(nn.Module):
                     rows = ops.point_loss_backward(ctx["point_loss"], w_mask * loss_scale, w_dice * loss_scale).view(NL, B, ctx["maxm"], T * hm * wm)
                 sources.append((rows, ctx["idx_q"]))
         main.wait_stream(crit_side)
+        # the weighted dict is formed on the main stream: only here, behind the wait, are the GT criterion's loss tensors (written on
+        # the side stream) ordered before their reader
+        out = {k: v * wd[k] for k, v in losses.items() if k in wd}
         for ctx, pre in ((ctx_gt, ""), (ctx_kd, "kd_")):
             w_ce = wd.get(pre + "loss_ce", 0.0)
             if w_ce != 0.0:

@@ -153,10 +153,16 @@ def test_train_step_at_config4_gradients_finite_and_reproducible(setup):
     # beside the KD pass's, on a second stream) gives the same losses and the same 345 gradients, bit for bit
     model.overlap_teacher = model.overlap_criteria = True
     l3, g3 = once()
+    # ... also when the side stream is held back ~0.1 s in front of the GT criterion (the weighted loss dict is formed on
+    # the main stream and must be ordered behind the side stream's loss kernels, whichever stream finishes first)
+    model._side_delay_cycles = 200_000_000
+    l4, g4 = once()
+    model._side_delay_cycles = 0
     model.overlap_teacher = model.overlap_criteria = False
     model.last_tapes = None
     assert l3 == l1 and all(torch.equal(a, b) for a, b in zip(g1, g3))
-    del g3
+    assert l4 == l1 and all(torch.equal(a, b) for a, b in zip(g1, g4))
+    del g3, g4
     assert len(g1) == 345 and l1 == l2
     assert all(bool(torch.isfinite(g).all()) for g in g1)
     spread = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(g1, g2))

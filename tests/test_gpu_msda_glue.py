@@ -41,12 +41,14 @@ def test_msda_forward_backward_golden(oracle):
     close(gw.cpu().numpy(), g["grad_w"], 1e-4)
 
 
-def test_msda_fused_vs_oracle_720p_shapes(oracle):
-    """fused softmax+loc+gather at a mid-size pyramid, against the oracle's module arithmetic"""
+@pytest.mark.parametrize("shapes,N", [([(6, 10), (12, 20), (23, 40)], 2), ([(23, 40), (46, 80), (92, 160)], 1)],
+                         ids=["quarter_size_pyramid", "720p_pyramid"])
+def test_msda_fused_vs_oracle_720p_shapes(oracle, shapes, N):
+    """fused softmax+loc+gather against the oracle's module arithmetic: a quarter-size pyramid (two frames) and the real pyramid of
+    a 736 x 1280 frame -- (23,40), (46,80), (92,160), S = 19 320 queries per frame, the benched geometry"""
     from s2d_amd import ops
-    shapes = [(6, 10), (12, 20), (23, 40)]
     S = sum(h * w for h, w in shapes)
-    N, M, D, L, P = 2, 8, 32, 3, 4
+    M, D, L, P = 8, 32, 3, 4
     value = synth.randn(7, 1, (N, S, M * D))
     off = synth.randn(7, 2, (N, S, M, L, P, 2), 2.0)
     lg = synth.randn(7, 3, (N, S, M, L * P))
