@@ -286,26 +286,35 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
 
 
+def dropout_thresh(p):
+    """T = round(p * 256) clamped to [0, 255]: an element is dropped iff its 8 random bits < T (s2d_amd/csrc/dropout.h)"""
+    return max(0, min(int(np.float32(p) * np.float32(256.0) + np.float32(0.5)), 255))
+
+
+def dropout_scale(p):
+    """256 / (256 - T) = 1 / P(keep): the multiplier of a kept element (float32, as the kernels form it)"""
+    return np.float32(256.0) / np.float32(256 - dropout_thresh(p))
+
+
 def dropout_multipliers(M, N, p, seed, site):
-    """the [M, N] float32 multipliers (0 or 1 / (1 - p)) of the library's counter-based dropout (s2d_amd/csrc/dropout.h):
-    block (row, col // 8) draws Philox4x32-10(counter = (row, col // 8, site, 0), key = seed); element col % 8 = e takes
-    half (e & 1) of word (e >> 1) and is kept iff those 16 bits >= round(p * 65536).  Semantics of the sites: nn.Dropout
-    at mask2former/modeling/pixel_decoder/msdeformattn.py:101-125 (x * mask / (1 - p)); the mask stream itself is this
-    library's own definition (torch's is an implementation detail of its CUDA kernels), so dropout parity is
-    distributional plus exact agreement with this restatement."""
+    """the [M, N] float32 multipliers (0 or 256 / (256 - T)) of the library's counter-based dropout (s2d_amd/csrc/dropout.h):
+    block (row, col // 16) draws Philox4x32-10(counter = (row, col // 16, site, 0), key = seed); element col % 16 = e takes
+    byte (e & 3) of word (e >> 2) and is kept iff those 8 bits >= T = round(p * 256).  Semantics of the sites: nn.Dropout
+    at mask2former/modeling/pixel_decoder/msdeformattn.py:101-125 (x * mask / P(keep)) with p quantised to T / 256; the mask
+    stream itself is this library's own definition (torch's is an implementation detail of its CUDA kernels), so dropout
+    parity is distributional plus exact agreement with this restatement."""
     assert N % 8 == 0
-    thresh = min(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)), 65535)
+    thresh = dropout_thresh(p)
     if thresh == 0:
         return np.ones((M, N), np.float32)
+    nb = (N + 15) // 16
     rows = np.arange(M, dtype=np.uint32)[:, None]
-    cb = np.arange(N // 8, dtype=np.uint32)[None, :]
+    cb = np.arange(nb, dtype=np.uint32)[None, :]
     r = philox4x32_10(rows, cb, np.uint32(site), np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    bits = np.empty((M, N // 8, 8), np.uint32)
-    for e in range(8):
-        w = r[e >> 1]
-        bits[..., e] = (w >> np.uint32(16)) if (e & 1) else (w & np.uint32(0xFFFF))
-    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
-    return np.where(bits.reshape(M, N) >= thresh, scale, np.float32(0.0)).astype(np.float32)
+    bits = np.empty((M, nb, 16), np.uint32)
+    for e in range(16):
+        bits[..., e] = (r[e >> 2] >> np.uint32(8 * (e & 3))) & np.uint32(0xFF)
+    return np.where(bits.reshape(M, nb * 16)[:, :N] >= thresh, dropout_scale(p), np.float32(0.0)).astype(np.float32)
 
 
 def pixel_decoder(p, feats, pre="", n_layers=6):

@@ -30,9 +30,8 @@ extern "C" int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t 
 {
     if (!(p >= 0.f) || p >= 1.f || M < 0 || N <= 0 || (N & 7) || M >= (1L << 32)) return S2D_ERR_ARG;
     if (M == 0) return S2D_OK;
-    unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
-    if (thresh > 65535u) thresh = 65535u;
-    const float scale = thresh ? 1.0f / (1.0f - p) : 1.0f;
+    const unsigned thresh = s2d_dropout_thresh(p);
+    const float scale = thresh ? s2d_dropout_scale(thresh) : 1.0f;
     const long n = M * (N >> 3);
     hipLaunchKernelGGL(dropout_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, M, N, thresh, scale,
                        (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32), site, row0, y);

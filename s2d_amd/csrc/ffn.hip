@@ -16,7 +16,7 @@
 //   * the epilogue (dropout3, residual, LayerNorm over the 256 outputs of a row = 128 values on the lane + 128 on lane ^ 32) runs on
 //     the accumulators and stores 64 contiguous bytes per lane and tile.
 // The row -> hidden-unit / output-column permutation inside a 32-row MFMA tile is chosen so that a lane's 16 accumulator registers are
-// 16 CONSECUTIVE units / columns (two whole 8-column Philox blocks, 64 contiguous bytes): MFMA row 8g + 4h + i <-> 16h + 4g + i.
+// 16 CONSECUTIVE units / columns (one whole 16-column Philox block, 64 contiguous bytes): MFMA row 8g + 4h + i <-> 16h + 4g + i.
 //
 // Weights: s2d_ffn_pack_f16 writes both matrices once as an image of MFMA A-fragments in the order the kernel consumes them
 // (per chunk: 16 k-steps x (hi, lo) of W1 | k-step 0: 8 tiles x (hi, lo) of W2 | k-step 1: the same; 1 KB = 64 lanes x 16 B per
@@ -33,6 +33,17 @@
 
 #ifndef S2D_FFN_DBG
 #define S2D_FFN_DBG 0
+#endif
+
+#if S2D_FFN_DBG & 16
+// diagnostic build only (scripts/mb_ffn_clock.py): s_memtime / s_memrealtime around the chunk loop of wave 0 of every workgroup, into
+// a buffer of their own that nothing else reads -- the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back (6))
+__device__ unsigned long long g_ffn_stamps[8 * 4096];      // per workgroup: entry, loop start (time, realtime), loop end (time, realtime), epilogue end, kernel end
+extern "C" int s2d_ffn_dbg_stamps(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ffn_stamps), sizeof(g_ffn_stamps)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace {
@@ -144,7 +155,7 @@ struct FfnParams {
     const float *g1, *be1;      // LayerNorm on the input (NULL: none)
     const float *g2, *be2;      // LayerNorm on the output (NULL: none)
     float eps;
-    unsigned int thresh;        // dropout: element kept iff its 16 bits >= thresh; 0 = no dropout
+    unsigned int thresh;        // dropout: element kept iff its 8 bits >= thresh (csrc/dropout.h); 0 = no dropout
     float dscale;
     unsigned int k0, k1, site_h, site_o, row0;
     // POST: the next encoder layer's merged projection of the output row, out_post[row][n] = y . Wpost[n]^T + post_bias[n]
@@ -161,6 +172,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [W1 buf 0 | W1 buf 1 | W2 buf 0 | W2 buf 1 | b1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if S2D_FFN_DBG & 16
+    const unsigned long long st_te = __builtin_amdgcn_s_memtime();
+#endif
     const int tok = lane & 31, h = lane >> 5;
     const long row = (long)blockIdx.x * 128 + wave * 32 + tok;
     const bool rowok = row < p.M;
@@ -180,26 +194,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // ---- helpers shared by the phases of the launch ----
-    uint32_t rb[2][4], rt[2];           // Philox state / result of the chunk's two 8-unit mask blocks; rt: the c0 a half-done round holds back
+    uint32_t rb[4], rt = 0u;            // Philox state / result of the chunk's 16-unit mask block (one byte per unit); rt: the c0 a half-done round holds back
     f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
                                         // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
     const unsigned char *lane_lds = lds + lane * 16;
-    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any bit set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads
+    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any of bits 1-8 set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads; 16: clock stamps (results unchanged)
 
-    // Philox4x32-10 of mask block e, round r, in two halves (idx = 4 r + 2 e + half):
+    // Philox4x32-10 of the lane's mask block, round r, in two halves (idx = 2 r + half):
     //   half 0: M1 * c2 -> rt = hi ^ c1 ^ k0, c1 = lo;   half 1: M0 * c0 -> c2 = hi ^ c3 ^ k1, c3 = lo, c0 = rt
     auto philox_half = [&](int idx) {
-        const int r = idx >> 2, e = (idx >> 1) & 1;
+        const int r = idx >> 1;
         if (!(idx & 1)) {
-            const uint64_t pr = (uint64_t)0xCD9E8D57u * rb[e][2];
-            rt[e] = (uint32_t)(pr >> 32) ^ rb[e][1] ^ (p.k0 + 0x9E3779B9u * (uint32_t)r);
-            rb[e][1] = (uint32_t)pr;
+            const uint64_t pr = (uint64_t)0xCD9E8D57u * rb[2];
+            rt = (uint32_t)(pr >> 32) ^ rb[1] ^ (p.k0 + 0x9E3779B9u * (uint32_t)r);
+            rb[1] = (uint32_t)pr;
         } else {
-            const uint64_t pr = (uint64_t)0xD2511F53u * rb[e][0];
-            rb[e][2] = (uint32_t)(pr >> 32) ^ rb[e][3] ^ (p.k1 + 0xBB67AE85u * (uint32_t)r);
-            rb[e][3] = (uint32_t)pr;
-            rb[e][0] = rt[e];
+            const uint64_t pr = (uint64_t)0xD2511F53u * rb[0];
+            rb[2] = (uint32_t)(pr >> 32) ^ rb[3] ^ (p.k1 + 0xBB67AE85u * (uint32_t)r);
+            rb[3] = (uint32_t)pr;
+            rb[0] = rt;
         }
+    };
+    // the 20 half-rounds of a part / chunk go into every other MFMA gap of its first 40 (gap g = 3 ks + 0..2)
+    auto philox_gap = [&](int g) {
+        if (g < 40 && !(g & 1)) philox_half(g >> 1);
     };
     auto dma_piece = [&](int src_byte, int dst_byte) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
             f32x4 res4[2][4];                                       // the residual's tile, loaded a whole part before its use (HBM latency:
                                                                     // nothing else runs on the SIMD to hide it)
-            uint32_t mk[2][4];                                      // the finished mask words of the previous tile
+            uint32_t mk[4];                                         // the finished mask words of the previous tile
             auto res_load = [&](int t, int b) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) res4[b][q] = *reinterpret_cast<const f32x4 *>(resr + 32 * t + 4 * q);
@@ -295,10 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = __builtin_fmaf(x[4 * q + e], 1.0f / 2048.0f, m[4 * q + e]);
-                    if (DROP) {
-                        const uint32_t w = mk[q >> 1][2 * (q & 1) + (e >> 1)];
-                        v *= ((e & 1) ? (w >> 16) : (w & 0xFFFFu)) >= p.thresh ? p.dscale : 0.f;
-                    }
+                    if (DROP) v *= ((mk[q] >> (8 * e)) & 0xFFu) >= p.thresh ? p.dscale : 0.f;     // element 4 q + e of the tile's 16: byte e of word q
                     ym[T][4 * q + e] = v + res4[T & 1][q][e];
                 }
             };
@@ -307,10 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const unsigned char *w = lane_lds + (J & 3) * PART, *wn = lane_lds + ((J + 1) & 3) * PART;
                 // two parts ahead; behind the last part come the chunk loop's first weights (W1 of chunks 0 and 1 live in ring buffers 0, 1)
                 const int src2 = J + 2 < 8 ? pre_base + (J + 2) * PART : (J == 6 || p.nchunks < 2 ? 0 : CHUNKB), dst2 = ((J + 2) & 3) * PART;
-                if (DROP) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) { rb[e][0] = mrow; rb[e][1] = (uint32_t)(4 * J + 2 * h + e); rb[e][2] = p.site_pre; rb[e][3] = 0u; }
-                }
+                if (DROP) { rb[0] = mrow; rb[1] = (uint32_t)(2 * J + h); rb[2] = p.site_pre; rb[3] = 0u; }      // columns 32 J + 16 h + 0..15
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
                     const int sl = ks & 3, sn = (ks + 2) & 3;
@@ -320,16 +332,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         __builtin_amdgcn_sched_barrier(0);
                         if (DROP) {
 #pragma unroll
-                            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) mk[e][c] = rb[e][c];
+                            for (int c = 0; c < 4; ++c) mk[c] = rb[c];
                         }
                         if (J < 7) bias_init(J + 1);
                     }
                     frag_read(sn, ks < 14 ? w + (2 * ks + 4) * FRAG : wn + (2 * (ks - 14)) * FRAG);
                     if (ks == 0) qm[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xh[ks], binit, 0, 0, 0); else mfma_a(qm[CUR], fr[sl][0], xh[ks]);
                     if (ks == 0) res_load(J, CUR);
-                    if (DROP && 3 * ks < 40) philox_half(3 * ks);
+                    if (DROP) philox_gap(3 * ks);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0) qx[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xl[ks], zero16, 0, 0, 0); else mfma_a(qx[CUR], fr[sl][0], xl[ks]);
                     if (ks < 8) {
@@ -341,11 +351,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         default: dma_piece4(s4, d4, std::integral_constant<int, 3>{}); break;
                         }
                     }
-                    if (DROP && 3 * ks + 1 < 40) philox_half(3 * ks + 1);
+                    if (DROP) philox_gap(3 * ks + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_a(qx[CUR], fr[sl][1], xh[ks]);
                     if (J > 0 && ks >= 6 && ks < 14 && !(ks & 1)) pre_out(qm[CUR ^ 1], qx[CUR ^ 1], std::integral_constant<int, (J > 0 ? J - 1 : 0)>{}, (ks - 6) >> 1);
-                    if (DROP && 3 * ks + 2 < 40) philox_half(3 * ks + 2);
+                    if (DROP) philox_gap(3 * ks + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -421,9 +431,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hv1 = fmaxf(__builtin_fmaf(ax[r0 + 1], 1.0f / 2048.0f, am[r0 + 1]), 0.f);
         } else if (part == 1) {
             if (DROP) {
-                const uint32_t w = rb[s][q];
-                hv0 *= (w & 0xFFFFu) >= p.thresh ? p.dscale : 0.f;      // a multiplier (select of two constants), not a select of the products:
-                hv1 *= (w >> 16) >= p.thresh ? p.dscale : 0.f;          // the latter compiles to exec-masked blocks that cut the schedule
+                const uint32_t w = rb[2 * s + (q >> 1)];                // units 8 s + 2 q, + 1 of the lane's 16: bytes 2 (q & 1), + 1 of word 2 s + (q >> 1)
+                hv0 *= ((w >> (16 * (q & 1))) & 0xFFu) >= p.thresh ? p.dscale : 0.f;      // a multiplier (select of two constants), not a select of the products:
+                hv1 *= ((w >> (16 * (q & 1) + 8)) & 0xFFu) >= p.thresh ? p.dscale : 0.f;  // the latter compiles to exec-masked blocks that cut the schedule
             }
         } else if (part == 2) {
             hhi = pk_hi(hv0, hv1);
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    // Chunk pc:  GEMM 1 k-steps 0..13 (42 MFMAs; the 40 Philox half-rounds of its mask in their gaps)  ->  vmcnt(0), BARRIER (the pieces
+    // Chunk pc:  GEMM 1 k-steps 0..13 (42 MFMAs; the 20 Philox half-rounds of its mask in every other gap)  ->  vmcnt(0), BARRIER (the pieces
     // issued a chunk ago are visible, the buffers of chunk pc - 1 and W1 of chunk pc are free)  ->  GEMM 1 k-steps 14, 15 (their fragments were
     // read before the barrier: 6 MFMAs that cover the latency of pass A's first fragment reads)  ->  pass A: GEMM 2 k-step 1 of chunk pc - 1 (24
     // MFMAs; chunk pc's first activation fragment formed in their gaps)  ->  pass B: GEMM 2 k-step 0 of chunk pc (24 MFMAs; its second
@@ -503,15 +513,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     frag_read(0, lane_lds);
     frag_read(1, lane_lds + 2 * FRAG);
     bias_read(0);
+#if S2D_FFN_DBG & 16
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int pc = 0; pc < p.nchunks; ++pc) {
         const int cur = pc & 1;
         const unsigned char *w1 = lane_lds + cur * PART;                          // W1 of chunk pc
         const unsigned char *w2a = lane_lds + 3 * PART + (cur ^ 1) * (PART / 2);   // W2 k-step 1 of chunk pc - 1
         const unsigned char *w2b = lane_lds + 2 * PART + cur * (PART / 2);         // W2 k-step 0 of chunk pc
-        if (DROP) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { rb[e][0] = mrow; rb[e][1] = (uint32_t)(4 * pc + 2 * h + e); rb[e][2] = p.site_h; rb[e][3] = 0u; }
-        }
+        if (DROP) { rb[0] = mrow; rb[1] = (uint32_t)(2 * pc + h); rb[2] = p.site_h; rb[3] = 0u; }      // hidden units 32 pc + 16 h + 0..15
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int sl = ks & 3, sn = (ks + 2) & 3;
@@ -525,21 +535,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             frag_read(sn, ks < 14 ? w1 + (2 * ks + 4) * FRAG : w2a + (2 * (ks - 14)) * FRAG);
             mfma_v(am, fr[sl][0], xh[ks], pv);
             if (ks >= 14) post_gap(3 * (ks - 14), pc);
-            if (DROP && 3 * ks < 40) philox_half(3 * ks);
+            if (DROP) philox_gap(3 * ks);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) mfma_v0(ax, fr[sl][0], xl[ks], pv); else mfma_v(ax, fr[sl][0], xl[ks], pv);
             if (ks >= 14) post_gap(3 * (ks - 14) + 1, pc);
-            if (DROP && 3 * ks + 1 < 40) philox_half(3 * ks + 1);
+            if (DROP) philox_gap(3 * ks + 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_v(ax, fr[sl][1], xh[ks], pv);
             if (ks >= 14) post_gap(3 * (ks - 14) + 2, pc);
-            if (DROP && 3 * ks + 2 < 40) philox_half(3 * ks + 2);
+            if (DROP) philox_gap(3 * ks + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ring slots 0, 1 hold pass A's first two fragment pairs (requested behind the barrier)
         gemm2_pass(std::integral_constant<int, 1>{}, w2a, w2b, 6, pc, 6, -1);
         gemm2_pass(std::integral_constant<int, 0>{}, w2b, lane_lds + (cur ^ 1) * PART, 30, pc, 2, pc + 1 < p.nchunks ? pc + 1 : pc);
     }
+#if S2D_FFN_DBG & 16
+    {
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 4096) {
+            g_ffn_stamps[8 * blockIdx.x] = st_te;
+            g_ffn_stamps[8 * blockIdx.x + 1] = st_t0; g_ffn_stamps[8 * blockIdx.x + 2] = st_r0;
+            g_ffn_stamps[8 * blockIdx.x + 3] = st_t1; g_ffn_stamps[8 * blockIdx.x + 4] = st_r1;
+        }
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                            // the last chunk's W2 k-step 1 pieces, copied by all four waves
     const int post_base = p.nchunks * CHUNKB;
@@ -561,11 +581,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        uint32_t m0[4], m1[4];
-        if (DROP) {
-            s2d_philox4x32_10(mrow, (uint32_t)(4 * t + 2 * h), p.site_o, 0u, p.k0, p.k1, m0);
-            s2d_philox4x32_10(mrow, (uint32_t)(4 * t + 2 * h + 1), p.site_o, 0u, p.k0, p.k1, m1);
-        }
+        uint32_t m0[4];
+        if (DROP) s2d_philox4x32_10(mrow, (uint32_t)(2 * t + h), p.site_o, 0u, p.k0, p.k1, m0);      // columns 32 t + 16 h + 0..15
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 x = *reinterpret_cast<const f32x4 *>((PRE ? p.Xn + rowc * FC + 16 * h : xr) + 32 * t + 4 * q);     // PRE: the normalised x1 this lane stored
@@ -577,11 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * q + e;
                 float v = ym[t][r] + yx[t][r] * (1.0f / 2048.0f);
-                if (DROP) {
-                    const uint32_t w = r < 8 ? m0[(r & 7) >> 1] : m1[(r & 7) >> 1];
-                    const uint32_t bits = (r & 1) ? (w >> 16) : (w & 0xFFFFu);
-                    v = bits >= p.thresh ? v * p.dscale : 0.f;
-                }
+                if (DROP) v = ((m0[q] >> (8 * e)) & 0xFFu) >= p.thresh ? v * p.dscale : 0.f;      // r = 4 q + e: byte e of word q
                 v += x[e];
                 ym[t][r] = v;
                 s += v;
@@ -616,6 +629,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#if S2D_FFN_DBG & 16
+    if (tid == 0 && blockIdx.x < 4096) g_ffn_stamps[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (POST) {
         // ---- the next layer's merged projection of the row just written: out_post[row][32 j + 16 h + reg] for the post_parts tiles j,
         // one weight part (32 KB, W1 buffers alternately) per tile, the row as the B fragments (same layout as the input tile's).
@@ -706,6 +722,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 4; ++q) { if (j & 1) tile_out(pm[1], px[1], j, q); else tile_out(pm[0], px[0], j, q); }
         }
     }
+#if S2D_FFN_DBG & 16
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have left: the kernel-end stamp counts them
+    if (tid == 0 && blockIdx.x < 4096) g_ffn_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 }  // namespace
@@ -748,8 +768,8 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     q.X = x; q.Y = y; q.Xn = xn; q.M = (int)M; q.nchunks = F / 32;
     q.pack = reinterpret_cast<const unsigned int *>(pack);
     q.b1 = b1; q.b2 = b2; q.g1 = ln1_gamma; q.be1 = ln1_beta; q.g2 = ln2_gamma; q.be2 = ln2_beta; q.eps = eps;
-    q.thresh = (unsigned int)lrintf(p * 65536.f);
-    q.dscale = 1.f / (1.f - p);
+    q.thresh = s2d_dropout_thresh(p);
+    q.dscale = q.thresh ? s2d_dropout_scale(q.thresh) : 1.f;
     q.k0 = (unsigned int)seed; q.k1 = (unsigned int)(seed >> 32); q.site_h = site_hidden; q.site_o = site_out; q.row0 = row0;
     q.post_bias = post_bias; q.post_pos = post_npos > 0 ? post_pos : post_bias; q.post_out = post_out; q.post_parts = Npost / 32;
     q.pre_bias = pre_bias; q.pre_res = pre_res; q.site_pre = site_pre;

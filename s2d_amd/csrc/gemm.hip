@@ -12,6 +12,7 @@
 // map, so every k is visited once).
 #include "common.h"
 #include "gemm_params.h"
+#include "dropout.h"
 
 namespace {
 
@@ -248,11 +249,11 @@ int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int
     q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K;
     q.lda = lda; q.ldb = ldb; q.ldc = ldc;
     q.bias = bias; q.res = res; q.ldr = res ? ldr : N; q.relu = relu; q.res_cols = N;
-    const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
+    const unsigned thresh = s2d_dropout_thresh(p);
     if (thresh == 0) return launch(q, false, 1, stream);        // p rounds to zero: the plain contraction
     if (g_dense_mode != 2) return S2D_ERR_ARG;
-    q.drop_thresh = thresh > 65535u ? 65535u : thresh;
-    q.drop_scale = 1.0f / (1.0f - p);
+    q.drop_thresh = thresh;
+    q.drop_scale = s2d_dropout_scale(thresh);
     q.drop_k0 = (unsigned)(seed & 0xFFFFFFFFull); q.drop_k1 = (unsigned)(seed >> 32); q.drop_stream = site; q.drop_row0 = row0;
     return launch(q, false, 1, stream);
 }

@@ -30,8 +30,8 @@ struct GemmParams {
     const unsigned int *Asplit;
     // fused dropout of the epilogue value (after scale / bias, before the residual; commutes with the ReLU): the three
     // nn.Dropout sites of the pixel decoder's encoder layers (msdeformattn.py:101-125).  drop_thresh 0 = off.
-    unsigned int drop_thresh;   // element kept iff its 16 random bits >= drop_thresh (= round(p * 65536))
-    float drop_scale;           // 1 / (1 - p)
+    unsigned int drop_thresh;   // element kept iff its 8 random bits >= drop_thresh (= round(p * 256), csrc/dropout.h)
+    float drop_scale;           // 256 / (256 - drop_thresh)
     unsigned int drop_k0, drop_k1, drop_stream;   // Philox key (the call's seed) and the stream id of this dropout site
     unsigned int drop_row0;     // mask row of output row 0 (a launch over rows [r0, r1) of a larger activation passes r0)
     // wave-specialised kernel: 16 K floats of 0 and of 1 that stand in for an absent bias / scale vector (branch-free epilogue)

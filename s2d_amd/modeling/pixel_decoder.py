@@ -201,9 +201,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         d2 = d_x2.view(-1, C)                                           # d(s1 + dropout3(linear2)): the residual takes it as is
         dm = ops.dropout(d2, p, seed, 2) if p > 0.0 else d2               # d(linear2 output)
         B.acc_wbgrad(self.linear2.weight, self.linear2.bias, dm, h)
-        # h = dropout2(relu(z)) = relu(z) * m / (1 - p): positive exactly where the unit is active AND kept, so the ReLU
+        # h = dropout2(relu(z)) = relu(z) * m / P(keep): positive exactly where the unit is active AND kept, so the ReLU
         # gate on h is the combined gate and the dropout factor is a constant per-channel scale
-        d_h = B.input_grad(dm, self.linear2.weight, gate=h, gate_scale=1.0 / (1.0 - p) if p > 0.0 else 1.0)
+        d_h = B.input_grad(dm, self.linear2.weight, gate=h, gate_scale=ops.dropout_scale(p) if p > 0.0 else 1.0)
         B.acc_wbgrad(self.linear1.weight, self.linear1.bias, d_h, s1.view(-1, C))
         d_s1 = B.input_grad(d_h, self.linear1.weight, res=d2).view(N, S, C)              # + the FFN residual
         d_x1, dg, db = B.layernorm_backward(x1, d_s1, self.norm1.weight)

@@ -361,8 +361,15 @@ def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, wan
     return res if len(res) > 1 else y
 
 
+def dropout_scale(p):
+    """the multiplier of a kept element: 256 / (256 - round(256 p)) = 1 / P(keep) with p quantised to 1 / 256 (csrc/dropout.h)"""
+    import numpy as np
+    t = max(0, min(int(np.float32(p) * np.float32(256.0) + np.float32(0.5)), 255))
+    return float(np.float32(256.0) / np.float32(256 - t)) if t else 1.0
+
+
 def dropout_apply(x, p, seed, site, row0=0, out=None):
-    """x [M, N] * mask / (1 - p): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
+    """x [M, N] * mask / P(keep): the mask gemm_nt(dropout=(p, seed, site)) applied (its gradient; the mask itself from ones)"""
     _chk(x)
     M, N = x.shape
     y = torch.empty_like(x) if out is None else out

@@ -29,6 +29,19 @@ in range.  Compiler-inserted counted waits are not concerned: the compiler count
 the same kernel ran 0 wrong words in > 500 two-stream launches, and every other kernel of the two-stream schedule is
 bitwise equal to its one-stream result.)
 
+Rule 3 (round 5): matrix-core hazards that INLINE-ASM MFMAs hide from the compiler.  On gfx950 an MFMA's result registers may not be
+read or written by a non-MFMA instruction (VALU, v_accvgpr_read / _mov, a store's data operand), nor read by a later MFMA as its A / B
+operand, before NumPasses + 3 wait states have gone by (v_mfma_*_32x32x16_{f16,bf16}: 8 passes -> 11; 16x16x32: 4 -> 7; the fp32-input
+32x32x2: 16 -> 19); and a VALU / v_accvgpr_write that writes a register an MFMA reads as SrcC needs 2 wait states in front of that MFMA.
+Nothing in the hardware interlocks these: the compiler's hazard recogniser pads them with s_nop -- for instructions it KNOWS to be MFMAs.
+An MFMA spelt in inline asm (csrc/ffn.hip: GEMM 1 on "+v" accumulators, so that the 256 output accumulators get the AGPR half) is an
+opaque string to it: a build of that kernel with GEMM 2 in asm too (`"+a"` accumulators; profiles/r5_experiments/ffn_asm_hazard.txt)
+has none of the 14 `s_nop 11` the builtin build carries between an MFMA and the v_accvgpr_read / v_accvgpr_mov_b32 of its
+accumulator, and none of the 8 `s_nop 1` between a v_accvgpr_mov_b32 and the MFMA that accumulates into it -- the deterministic
+1e-4 errors of round 4's asm form of GEMM 2 (a lost low-order product in whole output tiles) are what an accumulator read or moved
+one MFMA too early gives.  This rule recomputes the distances on the built ISA, whoever wrote the instruction: wait states are
+counted conservatively (every instruction 1, `s_nop N` N + 1) along straight-line code: a label or an unconditional branch ends a window.
+
     python scripts/isa_lint.py [file.s ...]          (no arguments: disassemble every csrc/*.hip for gfx950)
 """
 import glob
@@ -100,6 +113,95 @@ def lint_text(text, name):
     return bad
 
 
+AREG = re.compile(r"([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def xregs(tok):
+    """{('v', n) / ('a', n)} named by an operand token"""
+    out = set()
+    for k, a, b, k1, c in AREG.findall(tok):
+        if k1:
+            out.add((k1, int(c)))
+        else:
+            out.update((k, i) for i in range(int(a), int(b) + 1))
+    return out
+
+
+def mfma_passes(op):
+    if "32x32x2_f32" in op or "32x32x4" in op:
+        return 16
+    if "16x16x4_f32" in op or "32x32x16" in op or "32x32x8" in op:
+        return 8
+    if "16x16x32" in op or "16x16x16" in op:
+        return 4
+    return 16
+
+
+def lint_mfma(text, name):
+    """Rule 3: MFMA result -> non-MFMA reader / writer (or MFMA A / B reader) distance, VALU write -> MFMA SrcC distance"""
+    bad = []
+    kernel = None
+    pend = []        # [dst regs, wait states still required, wait states seen, line, text]
+    lastw = {}       # register -> wait states since a non-MFMA instruction wrote it
+    for ln, line in enumerate(text.split("\n"), 1):
+        s = line.split(";")[0].strip()
+        if not s or s.startswith("."):
+            continue
+        if s.endswith(":"):
+            if not s.startswith(".L") and not s.startswith("BB"):
+                kernel = s[:-1]
+            pend, lastw = [], {}          # a label: the code in front of it is not (only) what runs in front of it
+            continue
+        op = s.split()[0]
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pend, lastw = [], {}
+            continue
+        ops = s.split(None, 1)[1] if " " in s else ""
+        parts = [t.strip() for t in ops.split(",")]
+        step = 1
+        if op == "s_nop":
+            step = int(parts[0], 0) + 1 if parts and parts[0] else 1
+        is_mfma = op.startswith("v_mfma") or op.startswith("v_smfmac")
+        if op != "s_nop" and not op.startswith("s_") or op.startswith("s_") and False:
+            dst = xregs(parts[0]) if parts else set()
+            srcs = set()
+            for t in parts[1:]:
+                srcs |= xregs(t)
+            is_store = op.startswith(("global_store", "buffer_store", "flat_store", "ds_write", "ds_store", "scratch_store", "global_atomic", "buffer_atomic"))
+            if is_store:
+                srcs |= dst
+                dst = set()
+            for e in pend:
+                if is_mfma:
+                    ab = set()
+                    for t in parts[1:3]:
+                        ab |= xregs(t)
+                    hit = ab & e[0]
+                else:
+                    hit = (srcs | dst) & e[0]
+                if hit and e[2] < e[1]:
+                    bad.append(f"{name}:{ln}: {kernel}: `{s}` touches {sorted(hit)[:4]} {e[2]} wait states behind `{e[4]}` (line {e[3]}; needs {e[1]})")
+            if is_mfma and len(parts) >= 4:
+                srcc = xregs(parts[3])
+                for r in srcc:
+                    if lastw.get(r, 99) < 2:
+                        bad.append(f"{name}:{ln}: {kernel}: `{s}` reads SrcC {r} {lastw[r]} wait states behind a VALU write (needs 2)")
+                        break
+        for e in pend:
+            e[2] += step
+        pend = [e for e in pend if e[2] < e[1]]
+        for r in list(lastw):
+            lastw[r] += step
+            if lastw[r] > 4:
+                del lastw[r]
+        if is_mfma:
+            pend.append([xregs(parts[0]), mfma_passes(op) + 3, 0, ln, s])
+        elif op.startswith("v_") and parts:
+            for r in xregs(parts[0]):
+                lastw[r] = 0
+    return bad
+
+
 def lint_source(path):
     """Rule 2: hand-counted vmcnt(N > 0) and masked (OOB-dropped) buffer loads in one function"""
     bad = []
@@ -136,6 +238,7 @@ def main(argv):
     for f in files:
         text = open(f).read() if f.endswith(".s") else disassemble(f)
         bad += lint_text(text, os.path.basename(f))
+        bad += lint_mfma(text, os.path.basename(f))
         if not f.endswith(".s"):
             bad += lint_source(f)
     for b in bad:

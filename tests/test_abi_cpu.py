@@ -125,4 +125,13 @@ def test_isa_lint_no_packed_op_behind_a_dword_load_wait():
            " v_pk_mul_f32 v[28:29], v[12:13], v[20:21]\n s_endpgm\n")
     ok = bad.replace(" s_waitcnt vmcnt(0)\n", " s_waitcnt vmcnt(0)\n v_mov_b32_e32 v21, v21\n v_mov_b32_e32 v20, v20\n")
     assert len(lint.lint_text(bad, "t")) == 1 and lint.lint_text(ok, "t") == []
+    # rule 3 (round 5): the matrix-core hazards an inline-asm MFMA hides from the compiler (profiles/r5_experiments/ffn_asm_hazard.txt):
+    # an accumulator moved / written less than 2 wait states in front of the MFMA that reads it as SrcC, and an MFMA result read by a
+    # non-MFMA instruction less than NumPasses + 3 wait states behind it
+    h1 = "k:\n v_accvgpr_mov_b32 a241, a97\n v_accvgpr_mov_b32 a240, a96\n v_mfma_f32_32x32x16_f16 a[240:255], v[20:23], v[32:35], a[240:255]\n s_endpgm\n"
+    h1ok = h1.replace(" v_mfma", " s_nop 1\n v_mfma")
+    h2 = "k:\n v_mfma_f32_32x32x16_f16 a[0:15], v[20:23], v[32:35], a[0:15]\n s_nop 7\n v_accvgpr_read_b32 v1, a3\n s_endpgm\n"
+    h2ok = h2.replace("s_nop 7", "s_nop 11")
+    assert len(lint.lint_mfma(h1, "t")) == 1 and lint.lint_mfma(h1ok, "t") == []
+    assert len(lint.lint_mfma(h2, "t")) == 1 and lint.lint_mfma(h2ok, "t") == []
     assert lint.main([]) == 0

@@ -418,6 +418,6 @@ def test_philox4x32_10_known_answers(oracle):
         assert tuple(int(x) for x in got) == want
     m = oracle.dropout_multipliers(2000, 256, 0.3, 99, 1)
     keep = (m > 0).mean()
-    assert abs(keep - (1 - 19661 / 65536)) < 5 * (0.21 / m.size) ** 0.5
-    assert set(np.unique(m).tolist()) == {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))}
+    assert abs(keep - (1 - 77 / 256)) < 5 * (0.21 / m.size) ** 0.5
+    assert set(np.unique(m).tolist()) == {0.0, float(np.float32(256.0) / np.float32(256 - 77))}         # 1 / P(keep), p quantised to 77 / 256
     assert np.array_equal(oracle.dropout_multipliers(16, 64, 0.0, 1, 0), np.ones((16, 64), np.float32))
