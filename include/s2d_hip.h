@@ -54,16 +54,18 @@ int s2d_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int 
 /* The same contraction with nn.Dropout fused into the epilogue: C = act(dropout_p(A.B^T + bias) + res) -- the three dropout
  * sites of the pixel decoder's encoder layers in training mode (msdeformattn.py:101-125: dropout1 on the attention output,
  * dropout2 after the FFN activation (ReLU and a non-negative mask commute), dropout3 on the FFN output; each before its
- * residual add).  The mask is counter-based: element (row, col) of the [M,N] output is kept iff 16 bits of
- * Philox4x32-10(counter = (row0 + row, col / 8, site, 0), key = seed) are >= round(p * 65536) (row0: the mask row of output
- * row 0, for a launch over a row range of a larger activation), kept elements are multiplied by
- * 1 / (1 - p); the backward regenerates it (s2d_dropout_f32) instead of storing it.  Unbatched; N, ldc, ldr multiples of
- * 8; dense mode 2 only (S2D_ERR_ARG otherwise). */
+ * residual add).  The mask is counter-based (ABI 10: 8 bits per element, one generator call per 16 elements): element (row, col)
+ * of the [M,N] output is kept iff byte (col % 4) of word ((col % 16) / 4) of
+ * Philox4x32-10(counter = (row0 + row, col / 16, site, 0), key = seed) is >= T = round(p * 256) (row0: the mask row of output
+ * row 0, for a launch over a row range of a larger activation): P(drop) = T / 256, p quantised to 1 / 256; kept elements are
+ * multiplied by 256 / (256 - T) = 1 / P(keep) (inverted dropout, unbiased for the realised keep probability); the backward
+ * regenerates it (s2d_dropout_f32) instead of storing it.  Unbatched; N, ldc, ldr multiples of 8; dense mode 2 only
+ * (S2D_ERR_ARG otherwise). */
 int s2d_gemm_nt_dropout_f32(const float *A, const float *B, float *C, int M, int N, int K, long lda, long ldb, long ldc,
                             const float *bias, const float *res, long ldr, int relu, const void *B_split, float p,
                             uint64_t seed, unsigned site, unsigned row0, hipStream_t stream);
 
-/* y[M,N] = x * mask / (1 - p) with the mask of s2d_gemm_nt_dropout_f32 for the same (p, seed, site): the gradient of a
+/* y[M,N] = x * mask / P(keep) with the mask of s2d_gemm_nt_dropout_f32 for the same (p, seed, site): the gradient of a
  * dropout site (and the mask itself, from x = 1).  N multiple of 8; y may alias x. */
 int s2d_dropout_f32(const float *x, long M, int N, float p, uint64_t seed, unsigned site, unsigned row0, float *y, hipStream_t stream);
 

@@ -46,11 +46,38 @@ def flush_acc(end=False):
         for off in range(0, n, _ACC_CHUNK):
             ct.append(i); co.append(off)
     dev = pairs[0][0].device
-    t_table = torch.tensor(table, dtype=torch.int64).to(dev, non_blocking=True)
-    t_ct = torch.tensor(ct, dtype=torch.int32).to(dev, non_blocking=True)
-    t_co = torch.tensor(co, dtype=torch.int64).to(dev, non_blocking=True)
-    lib().call("s2d_multi_add_f32", t_table, t_ct, t_co, len(ct), _ACC_CHUNK, _st())
+    # ONE pinned staging buffer (int64: table | chunk offsets | chunk tensors) and one asynchronous copy per flush: a pageable source
+    # would be staged by the runtime and drain the host's launch-ahead in the middle of the backward.  A ring of buffers, each reused
+    # only after the copy that read it has completed (event), keeps the host from overwriting a table still in flight.
+    n_tab, n_ch = len(table), len(ct)
+    need = n_tab + n_ch + (n_ch + 1) // 2                 # the int32 chunk -> tensor table rides in the tail, two per word
+    slot = _staging(need)
+    host = slot["host"]
+    host[:n_tab] = torch.tensor(table, dtype=torch.int64)
+    host[n_tab:n_tab + n_ch] = torch.tensor(co, dtype=torch.int64)
+    host[n_tab + n_ch:need].view(torch.int32)[:n_ch] = torch.tensor(ct, dtype=torch.int32)
+    d = torch.empty((need,), dtype=torch.int64, device=dev)
+    d.copy_(host[:need], non_blocking=True)
+    slot["event"].record(torch.cuda.current_stream(dev))
+    lib().call("s2d_multi_add_f32", d[:n_tab], d[n_tab + n_ch:].view(torch.int32), d[n_tab:n_tab + n_ch], n_ch, _ACC_CHUNK, _st())
     # `pairs` (and with it every src) stays referenced until here: later allocations on this stream are ordered behind the launch
+
+
+_STAGE = {"ring": [], "next": 0}
+
+
+def _staging(n):
+    """next pinned int64 buffer of the ring with room for n words, free again (its last copy has completed)"""
+    ring = _STAGE["ring"]
+    if not ring:
+        for _ in range(4):
+            ring.append({"host": torch.empty((max(n, 1 << 14),), dtype=torch.int64).pin_memory(), "event": torch.cuda.Event()})
+    slot = ring[_STAGE["next"] % len(ring)]
+    _STAGE["next"] += 1
+    slot["event"].synchronize()                      # a no-op unless the host is four flushes ahead of the device
+    if slot["host"].numel() < n:
+        slot["host"] = torch.empty((2 * n,), dtype=torch.int64).pin_memory()
+    return slot
 
 
 def acc(param, g):
@@ -69,11 +96,14 @@ def _defer_add(dst, src):
     if _PENDING is None or not (dst.is_contiguous() and dst.dtype == torch.float32 and src.dtype == torch.float32 and src.device == dst.device
                                 and src.numel() == dst.numel()):
         return False
-    key = dst.data_ptr()
-    if key in _PENDING[1]:
-        flush_acc()                                      # a second contribution to the same gradient: keep one destination per launch
+    lo = dst.data_ptr()
+    hi = lo + 4 * dst.numel()
+    # one destination per launch: a second contribution to the same gradient -- or to ANY byte range that overlaps a pending one (a
+    # whole parameter and a row slice of it, say) -- would be a lost update between blocks of the multi-tensor kernel
+    if any(lo < b and a < hi for a, b in _PENDING[1]):
+        flush_acc()
     _PENDING[0].append((dst, src.contiguous()))
-    _PENDING[1].add(key)
+    _PENDING[1].add((lo, hi))
     return True
 
 

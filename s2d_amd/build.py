@@ -49,6 +49,13 @@ def build(force=False, verbose=True):
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+        # a shared library links with undefined symbols: load it once, so that a kernel whose host stub the compiler dropped (seen: a
+        # kernel-body lambda calling another lambda that returns a value) fails HERE, not on the GPU box
+        import ctypes
+        try:
+            ctypes.CDLL(LIB)
+        except OSError as e:
+            raise RuntimeError(f"{LIB} does not load: {e}")
         if verbose:
             print("built", LIB)
     return LIB

@@ -34,6 +34,15 @@
 #ifndef S2D_FFN_DBG
 #define S2D_FFN_DBG 0
 #endif
+// where the epilogue takes the residual x (the FFN's input) from: 0 = reloaded from memory tile by tile (round 4), 1 = rebuilt from the
+// resident fp16 hi / lo fragments (x = hi + lo / 2048, no memory traffic; the out_proj form then stores Xn only for callers that keep
+// it), 2 = all 32 loads issued before the trailing pass.  Measured in profiles/r5_experiments/ffn_phases.txt.
+#ifndef S2D_FFN_EPI
+#define S2D_FFN_EPI 1
+#endif
+#ifndef S2D_FFN_POSTV
+#define S2D_FFN_POSTV 0
+#endif
 
 #if S2D_FFN_DBG & 16
 // diagnostic build only (scripts/mb_ffn_clock.py): s_memtime / s_memrealtime around the chunk loop of wave 0 of every workgroup, into
@@ -60,6 +69,9 @@ constexpr int CHUNKB = 2 * PART;            // image bytes per chunk of 32 hidde
 constexpr int LDS_B1 = 2 * CHUNKB;          // byte offset of the bias copy (behind the two chunk buffers)
 constexpr int FMAX = 2048;                  // hidden width limit of the bias copy
 constexpr int LDS_PB = LDS_B1 + FMAX * 4;   // PRE: the output projection's bias (256 floats) behind it
+constexpr int LDS_LN = LDS_PB + FC * 4;     // LayerNorm parameters: gamma1 | beta1 | gamma2 | beta2 (256 floats each).  Read from global they
+                                            // were 16-B loads in the middle of the epilogue's store stream: every use waited `vmcnt(0)`, i.e.
+                                            // for every store issued before it too (in-order counter) -- from LDS they wait on lgkmcnt only
 
 // MFMA row rho of a 32-row tile <-> unit / column 16 h + 4 g + i   (rho = 8 g + 4 h + i): a lane half's 16 accumulator registers
 // (reg = 4 g + i at rows 8 g + 4 h + i) are then the 16 consecutive units 16 h + reg
@@ -88,6 +100,14 @@ __device__ __forceinline__ unsigned int pk_lo(float a, float b, unsigned int hi)
 //     MFMA has issued (the allocator otherwise hands a dead fragment's registers to the very next VALU instruction);
 //   * the VALU readers of am / ax (the activation quarters) sit >= 4 MFMAs behind GEMM 1's last MFMA.
 // tests/test_gpu_ffn.py checks every variant against a float64 oracle at 2e-5 of the output scale (a lost low-order product is 1e-4).
+// lane * 16 recomputed on the spot (volatile: never hoisted, no live range); a free __device__ function: an asm with a "v" constraint in a
+// lambda of the kernel body is checked by the HOST pass too, which then silently drops the kernel's host stub
+__device__ __forceinline__ int lane16_asm()
+{
+    int v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(v));
+    return v;
+}
 struct MfmaPrev { f16x8 a, b; };
 __device__ __forceinline__ void mfma_a(f32x16 &c, const f16x8 a, const f16x8 b) { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void mfma_v(f32x16 &c, const f16x8 a, const f16x8 b, MfmaPrev &pv)
@@ -183,14 +203,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                              // the projection phase are unconditional and must carry its values)
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(p.pack), 0, p.nchunks * CHUNKB + (p.post_parts + (PRE ? 8 : 0)) * PART, 0x00020000);
+    // The LDS-DMA's per-lane source offset, lane * 16.  Held in one register for the whole launch it is the value the allocator spills
+    // (the chunk loop fills all 512 registers), and a spilled operand of a DMA instruction is reloaded in front of EVERY piece with
+    // `scratch_load; s_waitcnt vmcnt(0)` -- vmcnt(0) drains all pieces in flight, one memory round trip per piece, in exactly the phases
+    // (out_proj, projection) that have no other work to hide it.  So outside the chunk loop it is recomputed where it is used (3 VALU,
+    // volatile: not hoisted, no live range; lane16_asm, a free __device__ function -- called through a lambda of the kernel body the host pass
+    // silently dropped the kernel's stub); the chunk loop keeps its own copy made just in front of it.
     // a wave copies pieces wave * n .. wave * n + n - 1 of a part of 4 n pieces (n = 8: 32 KB; n = 4: one k-step of W2, 16 KB)
     auto dma_part = [&](int src_byte, int dst_byte, auto n_) {
         constexpr int n = decltype(n_)::value;
+        const int voff = lane16_asm();
 #pragma unroll
         for (int i = 0; i < n; ++i) {
             const int piece = wave * n + i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte + piece * FRAG), 16,
-                                                     lane * 16, src_byte + piece * FRAG, 0, 0);
+                                                     voff, src_byte + piece * FRAG, 0, 0);
         }
     };
     // ---- helpers shared by the phases of the launch ----
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
                                         // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
     const unsigned char *lane_lds = lds + lane * 16;
-    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any of bits 1-8 set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads; 16: clock stamps (results unchanged)
+    constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any of bits 1-8 set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads; 16: clock stamps (results unchanged); 32 no projection-phase stores, 64 no residual loads in the epilogue, 128 no Y / Xn stores, 256 no residual loads in the out_proj phase, 512 no input tile loads
 
     // Philox4x32-10 of the lane's mask block, round r, in two halves (idx = 2 r + half):
     //   half 0: M1 * c2 -> rt = hi ^ c1 ^ k0, c1 = lo;   half 1: M0 * c0 -> c2 = hi ^ c3 ^ k1, c3 = lo, c0 = rt
@@ -220,13 +247,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (g < 40 && !(g & 1)) philox_half(g >> 1);
     };
     auto dma_piece = [&](int src_byte, int dst_byte) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane16_asm(), src_byte, 0, 0);
     };
     // piece `sub` (0..3) of a run of four consecutive 1-KB pieces: the instruction's immediate offset advances the source and the LDS
     // address alike, so the four share one M0 value and one scalar offset (two scalar instructions saved per piece)
-    auto dma_piece4 = [&](int src_byte, int dst_byte, auto sub_) {
+    int voff_loop = 0;                  // the chunk loop's copy of lane * 16 (set just in front of the loop)
+    auto dma_piece4 = [&](int src_byte, int dst_byte, auto sub_, bool in_loop = false) {
         constexpr int SUB = decltype(sub_)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, lane * 16, src_byte, SUB * FRAG, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(lds + dst_byte), 16, in_loop ? voff_loop : lane16_asm(), src_byte, SUB * FRAG, 0);
     };
     auto frag_read = [&](int slot, const unsigned char *at) {
         if (dbg & 8) return;
@@ -249,6 +277,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else chunk_loop_prologue(std::true_type{});
     for (int i = tid; i < p.nchunks * 32; i += 256) reinterpret_cast<float *>(lds + LDS_B1)[i] = p.b1[i];
     if (PRE) reinterpret_cast<float *>(lds + LDS_PB)[tid] = p.pre_bias[tid];
+    if (LN1) { reinterpret_cast<float *>(lds + LDS_LN)[tid] = p.g1[tid]; reinterpret_cast<float *>(lds + LDS_LN)[FC + tid] = p.be1[tid]; }
+    if (LN2) { reinterpret_cast<float *>(lds + LDS_LN)[2 * FC + tid] = p.g2[tid]; reinterpret_cast<float *>(lds + LDS_LN)[3 * FC + tid] = p.be2[tid]; }
 
     // ---- input tile -> fp16 hi / lo B fragments of GEMM 1.  The row is loaded in the accumulator layout (this lane: columns
     // 32 t + 16 h + 0..15 for t = 0..7, lane ^ 32 the other halves) and parked in the output accumulators, which are idle until the
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x16 ym[8], yx[8];
     f16x8 xh[16], xl[16];
     float mean1 = 0.f, rstd1 = 1.f;
-    auto tile_to_frags = [&]() {        // ym (fp32, accumulator layout) -> xh / xl
+    auto tile_to_frags = [&](const f32x16 (&src)[8]) {        // a row tile (fp32, accumulator layout) -> xh / xl
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 u32x4 hi, lo;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float a = ym[t][8 * s2 + 2 * q], b = ym[t][8 * s2 + 2 * q + 1];
+                    const float a = src[t][8 * s2 + 2 * q], b = src[t][8 * s2 + 2 * q + 1];
                     hi[q] = pk_hi(a, b);
                     lo[q] = pk_lo(a, b, hi[q]);
                 }
@@ -279,27 +309,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
-                ym[t][4 * q] = a[0]; ym[t][4 * q + 1] = a[1]; ym[t][4 * q + 2] = a[2]; ym[t][4 * q + 3] = a[3];
+                const f32x4 a = (dbg & 512) ? f32x4{(float)lane, 1.f, (float)t, (float)q} : *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
+                f32x16 &dst = PRE ? yx[t] : ym[t];      // PRE: the sampled values park in yx, the residual tile goes to ym, where x1 is formed in place
+                dst[4 * q] = a[0]; dst[4 * q + 1] = a[1]; dst[4 * q + 2] = a[2]; dst[4 * q + 3] = a[3];
             }
         if constexpr (PRE) {
             // ---- the attention's output projection in front of everything: x1 = res + dropout1( Wo . samp + bo ), tile by tile into the
             // parked row (ms_deform_attn.py:124 output_proj, msdeformattn.py:125 dropout1 + residual).  Same part machinery as the
             // projection phase at the end (four-buffer ring, pieces two parts ahead, builtin MFMAs on two accumulator pairs, the
             // previous tile's epilogue in the gaps), with the part index a compile-time constant: a tile's values go into ym[tile].
-            tile_to_frags();                                        // the sampled values as B fragments
+            // The residual's WHOLE row tile is loaded here, in flight together with the sampled values' tile (parked in the cross
+            // accumulators yx, dead once the fragments are formed), into ym, where tile T's x1 = res + drop(...) is then formed IN PLACE:
+            // one exposed memory round trip for both tiles instead of one per part -- loaded "a part ahead" each part still waited ~2 us for
+            // its tile, 16 of the phase's 56 us (profiles/r5_experiments/ffn_phases.txt; one wave per SIMD: nothing hides it)
             const float *resr = p.pre_res + rowc * FC + 16 * h;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = (dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(resr + 32 * t + 4 * q);
+                    ym[t][4 * q] = a[0]; ym[t][4 * q + 1] = a[1]; ym[t][4 * q + 2] = a[2]; ym[t][4 * q + 3] = a[3];
+                }
+            __builtin_amdgcn_sched_barrier(0);                      // both tiles' loads are issued before the first is waited for
+            tile_to_frags(yx);                                      // the sampled values as B fragments
             const unsigned char *pbo = lds + LDS_PB + 64 * h;      // the projection's bias, copied to LDS by the prologue
             f32x16 qm[2], qx[2], zero16, binit;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-            f32x4 res4[2][4];                                       // the residual's tile, loaded a whole part before its use (HBM latency:
-                                                                    // nothing else runs on the SIMD to hide it)
             uint32_t mk[4];                                         // the finished mask words of the previous tile
-            auto res_load = [&](int t, int b) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) res4[b][q] = *reinterpret_cast<const f32x4 *>(resr + 32 * t + 4 * q);
-            };
             auto bias_init = [&](int t) {                           // a lane's accumulator registers are 16 consecutive columns: C = bias
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -314,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int e = 0; e < 4; ++e) {
                     float v = __builtin_fmaf(x[4 * q + e], 1.0f / 2048.0f, m[4 * q + e]);
                     if (DROP) v *= ((mk[q] >> (8 * e)) & 0xFFu) >= p.thresh ? p.dscale : 0.f;     // element 4 q + e of the tile's 16: byte e of word q
-                    ym[T][4 * q + e] = v + res4[T & 1][q][e];
+                    ym[T][4 * q + e] += v;
                 }
             };
             auto pre_part = [&](auto j_) {
@@ -327,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int ks = 0; ks < 16; ++ks) {
                     const int sl = ks & 3, sn = (ks + 2) & 3;
                     if (ks == 14) {
-                        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");     // this part's 8 pieces + 4 loads may stay in flight
+                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // this part's 8 pieces may stay in flight
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                         if (DROP) {
@@ -338,7 +375,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                     frag_read(sn, ks < 14 ? w + (2 * ks + 4) * FRAG : wn + (2 * (ks - 14)) * FRAG);
                     if (ks == 0) qm[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xh[ks], binit, 0, 0, 0); else mfma_a(qm[CUR], fr[sl][0], xh[ks]);
-                    if (ks == 0) res_load(J, CUR);
                     if (DROP) philox_gap(3 * ks);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0) qx[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xl[ks], zero16, 0, 0, 0); else mfma_a(qx[CUR], fr[sl][0], xl[ks]);
@@ -375,6 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             chunk_loop_prologue(std::false_type{});
         }
         if (LN1) {
+            if (!PRE) __syncthreads();                              // the LayerNorm parameters' LDS copy (PRE: the phase's barriers are behind it)
             float s = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
@@ -393,14 +430,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.g1 + 32 * t + 16 * h + 4 * q), be = *reinterpret_cast<const f32x4 *>(p.be1 + 32 * t + 16 * h + 4 * q);
+                    const float *lnp = reinterpret_cast<const float *>(lds + LDS_LN) + 32 * t + 16 * h + 4 * q;
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(lnp), be = *reinterpret_cast<const f32x4 *>(lnp + FC);
                     f32x4 v = {ym[t][4 * q], ym[t][4 * q + 1], ym[t][4 * q + 2], ym[t][4 * q + 3]};
                     v = (v - mean1) * rstd1 * ga + be;
                     ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3];
-                    if (PRE || (p.Xn && rowok)) *reinterpret_cast<f32x4 *>(p.Xn + rowc * FC + 32 * t + 16 * h + 4 * q) = v;     // PRE: the epilogue's residual
+                    if (((PRE && S2D_FFN_EPI != 1) || (p.Xn && rowok)) && !(dbg & 128)) *reinterpret_cast<f32x4 *>(p.Xn + rowc * FC + 32 * t + 16 * h + 4 * q) = v;     // PRE, EPI != 1: the epilogue's residual
                 }
         }
-        tile_to_frags();
+        tile_to_frags(ym);
     }
 
     // ---- output accumulators: tile t, register reg <-> column 32 t + 16 h + reg of the wave's rows; bias b2 as the initial value ----
@@ -451,10 +489,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (dbg & 1) return;
         auto go = [&](int src, int dst) {
             switch (k & 3) {
-            case 0: dma_piece4(src, dst, std::integral_constant<int, 0>{}); break;
-            case 1: dma_piece4(src, dst, std::integral_constant<int, 1>{}); break;
-            case 2: dma_piece4(src, dst, std::integral_constant<int, 2>{}); break;
-            default: dma_piece4(src, dst, std::integral_constant<int, 3>{}); break;
+            case 0: dma_piece4(src, dst, std::integral_constant<int, 0>{}, true); break;
+            case 1: dma_piece4(src, dst, std::integral_constant<int, 1>{}, true); break;
+            case 2: dma_piece4(src, dst, std::integral_constant<int, 2>{}, true); break;
+            default: dma_piece4(src, dst, std::integral_constant<int, 3>{}, true); break;
             }
         };
         if (k < 8) go(min(pc + 2, last) * CHUNKB + (wave * 8 + (k & 4)) * FRAG, cur * PART + (wave * 8 + (k & 4)) * FRAG);
@@ -513,6 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     frag_read(0, lane_lds);
     frag_read(1, lane_lds + 2 * FRAG);
     bias_read(0);
+    voff_loop = lane16_asm();
 #if S2D_FFN_DBG & 16
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -570,14 +609,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int k = 0; k < 8; ++k) dma_piece(post_base + (p.post_parts > 1 ? PART : 0) + (wave * 8 + k) * FRAG, PART + (wave * 8 + k) * FRAG);
     }
+    // The epilogue's residual row tile (the FFN's input x: this lane's 128 values), ALL 32 loads issued here, into the registers the
+    // input fragments have just left: one memory round trip, covered by the trailing pass below.  Round 4 loaded it tile by tile inside
+    // the epilogue (register fear: the fragments are dead by then) -- eight dependent round trips with nothing to hide them at one wave
+    // per SIMD, and each wait also drained the stores issued before it (vmcnt is in order).
+    f32x4 resv[8][4];
+    const float *rsrc = (PRE ? p.Xn : p.X) + rowc * FC + 16 * h;        // PRE: the normalised x1 this lane stored behind the out_proj phase
+    if (S2D_FFN_EPI == 2) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) resv[t][q] = (dbg & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(rsrc + 32 * t + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     frag_read(0, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2));
     frag_read(1, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2) + 2 * FRAG);
     gemm2_pass(std::integral_constant<int, 1>{}, lane_lds + 3 * PART + ((p.nchunks - 1) & 1) * (PART / 2), lane_lds, 1000, 0, 1000, -1);   // no fillers
 
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are read by the VALU below (see mfma_a)
     // ---- epilogue: y = [LN2]( x + dropout3(acc) ),  this lane: columns 32 t + 16 h + 0..15 of its row ----
-    // (tile by tile, pinned: the 32 residual loads of a lane must not all be in flight beside the 256 accumulators)
-    const float *xr = p.X + rowc * FC + 16 * h;
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -585,9 +635,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (DROP) s2d_philox4x32_10(mrow, (uint32_t)(2 * t + h), p.site_o, 0u, p.k0, p.k1, m0);      // columns 32 t + 16 h + 0..15
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 x = *reinterpret_cast<const f32x4 *>((PRE ? p.Xn + rowc * FC + 16 * h : xr) + 32 * t + 4 * q);     // PRE: the normalised x1 this lane stored
-            if (LN1 && !PRE) {
-                const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.g1 + 32 * t + 16 * h + 4 * q), be = *reinterpret_cast<const f32x4 *>(p.be1 + 32 * t + 16 * h + 4 * q);
+            f32x4 x;
+            if (S2D_FFN_EPI == 2) x = resv[t][q];
+            else if (S2D_FFN_EPI == 0) x = (dbg & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(rsrc + 32 * t + 4 * q);
+            else {
+                // fragment (k-step 2 t + s, element j) IS column 32 t + 16 h + 8 s + j of the lane's row: the accumulator layout
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    x[e] = (dbg & 64) ? 0.f : __builtin_fmaf((float)xl[2 * t + (r >> 3)][r & 7], 1.0f / 2048.0f, (float)xh[2 * t + (r >> 3)][r & 7]);
+                }
+            }
+            if (LN1 && !PRE && S2D_FFN_EPI != 1) {
+                const float *lnp = reinterpret_cast<const float *>(lds + LDS_LN) + 32 * t + 16 * h + 4 * q;
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(lnp), be = *reinterpret_cast<const f32x4 *>(lnp + FC);
                 x = (x - mean1) * rstd1 * ga + be;
             }
 #pragma unroll
@@ -621,10 +682,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {ym[t][4 * q], ym[t][4 * q + 1], ym[t][4 * q + 2], ym[t][4 * q + 3]};
             if (LN2) {
-                const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.g2 + 32 * t + 16 * h + 4 * q), be = *reinterpret_cast<const f32x4 *>(p.be2 + 32 * t + 16 * h + 4 * q);
+                const float *lnp = reinterpret_cast<const float *>(lds + LDS_LN) + 2 * FC + 32 * t + 16 * h + 4 * q;
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(lnp), be = *reinterpret_cast<const f32x4 *>(lnp + FC);
                 v = (v - mean) * rstd * ga + be;
             }
-            if (rowok) *reinterpret_cast<f32x4 *>(yr + 32 * t + 4 * q) = v;
+            if (rowok && !(dbg & 128)) *reinterpret_cast<f32x4 *>(yr + 32 * t + 4 * q) = v;
             if (POST) { ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3]; }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -637,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // one weight part (32 KB, W1 buffers alternately) per tile, the row as the B fragments (same layout as the input tile's).
         // Accumulators: builtin MFMAs on two (main, cross) pairs, so that tile j - 1's epilogue -- 16 values per lane: combine, the
         // row-periodic pos term for the first post_npos columns, one 64-byte store -- runs in the gaps of tile j's MFMAs.
-        tile_to_frags();
+        tile_to_frags(ym);
         const long prow = rowc % p.post_S;
         const float *posr = p.post_pos + prow * p.post_ldpos + 16 * h;
         float *outr = p.post_out + rowc * p.post_ld + 16 * h;
@@ -657,7 +719,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4 v = {m[4 * q] + x[4 * q] * (1.0f / 2048.0f), m[4 * q + 1] + x[4 * q + 1] * (1.0f / 2048.0f),
                        m[4 * q + 2] + x[4 * q + 2] * (1.0f / 2048.0f), m[4 * q + 3] + x[4 * q + 3] * (1.0f / 2048.0f)};
             v += pos4[q];
-            *reinterpret_cast<f32x4 *>(outr + 32 * j + 4 * q) = v;        // unconditional (rows past M rewrite row M - 1 with its own values): the wait below counts it
+            if (!(dbg & 32)) *reinterpret_cast<f32x4 *>(outr + 32 * j + 4 * q) = v;        // unconditional (rows past M rewrite row M - 1 with its own values): the wait below counts it
         };
         // part j (accumulator pair CUR = j & 1; PREV: 0 = no previous tile, 1 = the previous tile takes the pos term, 2 = it does not) reads
         // buffer j & 3 of a ring of FOUR 32-KB buffers (the whole weight area: the chunk loop is over).  While it runs, the 8 pieces of
@@ -676,7 +738,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // part j + 1's pieces (issued during part j - 1) must have landed; what this part issued -- its 8 pieces, the previous
                     // tile's four additive-term loads and four stores -- are the youngest vector-memory operations and need not: vmcnt
                     // retires in order
-                    if (PREV) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                    // S2D_FFN_POSTV = 1: the part's pieces all go out in k-steps 0..3 (two per k-step), in front of every store of the part, so
+                    // that the previous part's four stores are younger than the pieces waited for here as well: vmcnt(20)
+                    if (PREV) { if (S2D_FFN_POSTV) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); }
                     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -686,17 +750,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (ks == 0 && PREV) add_load(j - 1, PREV == 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 0) px[CUR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[sl][0], xl[ks], zero16, 0, 0, 0); else mfma_a(px[CUR], fr[sl][0], xl[ks]);
-                if (ks < 8) {
-                    const int s4 = src2 + (wave * 8 + (ks & 4)) * FRAG, d4 = dst2 + (wave * 8 + (ks & 4)) * FRAG;
-                    switch (ks & 3) {
+                auto piece = [&](int k) {                                   // piece k (0..7) of part j + 2
+                    const int s4 = src2 + (wave * 8 + (k & 4)) * FRAG, d4 = dst2 + (wave * 8 + (k & 4)) * FRAG;
+                    switch (k & 3) {
                     case 0: dma_piece4(s4, d4, std::integral_constant<int, 0>{}); break;
                     case 1: dma_piece4(s4, d4, std::integral_constant<int, 1>{}); break;
                     case 2: dma_piece4(s4, d4, std::integral_constant<int, 2>{}); break;
                     default: dma_piece4(s4, d4, std::integral_constant<int, 3>{}); break;
                     }
-                }
+                };
+                if (S2D_FFN_POSTV) { if (ks < 4) piece(2 * ks); }
+                else if (ks < 8) piece(ks);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_a(px[CUR], fr[sl][1], xh[ks]);
+                if (S2D_FFN_POSTV && ks < 4) piece(2 * ks + 1);
                 if (PREV && ks >= 6 && ks < 14 && !(ks & 1)) tile_out(pm[CUR ^ 1], px[CUR ^ 1], j - 1, (ks - 6) >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -760,7 +827,7 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     if ((ln1_gamma == nullptr) != (ln1_beta == nullptr) || (ln2_gamma == nullptr) != (ln2_beta == nullptr)) return S2D_ERR_ARG;
     if (xn && !ln1_gamma) return S2D_ERR_ARG;
     if (!(p >= 0.f && p < 1.f)) return S2D_ERR_ARG;
-    if (pre_bias && (!pre_res || !xn || !ln1_gamma || !ln2_gamma)) return S2D_ERR_ARG;     // the out_proj phase exists for the encoder layer's form only
+    if (pre_bias && (!pre_res || (!xn && S2D_FFN_EPI != 1) || !ln1_gamma || !ln2_gamma)) return S2D_ERR_ARG;     // the out_proj phase exists for the encoder layer's form only
     if (Npost > 0 && (!post_bias || !post_out || post_ld < Npost || (post_ld & 3) || post_npos < 0 || post_npos > Npost || (post_npos & 31) ||
                       (post_npos > 0 && (!post_pos || post_S <= 0 || post_ldpos < post_npos || (post_ldpos & 3))) || M * post_ld > 0x7FFFFFFFL * 4))
         return S2D_ERR_ARG;
@@ -774,7 +841,7 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     q.post_bias = post_bias; q.post_pos = post_npos > 0 ? post_pos : post_bias; q.post_out = post_out; q.post_parts = Npost / 32;
     q.pre_bias = pre_bias; q.pre_res = pre_res; q.site_pre = site_pre;
     q.post_S = post_npos > 0 ? post_S : 1; q.post_npos = post_npos; q.post_ld = (int)post_ld; q.post_ldpos = (int)post_ldpos;
-    const int smem = LDS_PB + FC * 4;
+    const int smem = LDS_LN + 4 * FC * 4;
     const dim3 grid(cdiv(M, 128)), block(256);
     static S2dDevOnce attr[32];
     const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr, post = Npost > 0, pre = pre_bias != nullptr;

@@ -1454,10 +1454,17 @@ __global__ __launch_bounds__(256) void msda_f64_kernel(const double *__restrict_
                                                        const int64_t *__restrict__ lsi, const double *__restrict__ loc,
                                                        const double *__restrict__ aw, const double *__restrict__ gout, long S, int M, int D,
                                                        int L, long Lq, int P, long total, double *__restrict__ out,
-                                                       double *__restrict__ gvalue, double *__restrict__ gloc, double *__restrict__ gaw)
+                                                       double *__restrict__ gvalue, double *__restrict__ gloc, double *__restrict__ gaw,
+                                                       int *__restrict__ err_word)
 {
     const long item = (long)blockIdx.x * 256 + threadIdx.x;
     if (item >= total) return;
+    if (item == 0 && err_word) {                              // the same sticky process word the f32 geometry check sets (s2d_msda_dev_error_word):
+        for (int l = 0; l < L; ++l) {                          // a rejected level must not pass as zeros (a gradcheck in double would "pass")
+            int H, W; long st;
+            if (!level_ok_f64(shapes, lsi, l, S, H, W, st)) { *err_word = 1; break; }
+        }
+    }
     const int d = (int)(item % D);
     const int m = (int)((item / D) % M);
     const long q = (item / ((long)D * M)) % Lq;
@@ -1565,7 +1572,8 @@ int s2d_msda_forward_dev_f64(const double *value, const int64_t *shapes_dev, con
     const long total = (long)N * Lq * M * D;
     if (total == 0) return S2D_OK;
     hipLaunchKernelGGL((msda_f64_kernel<false>), dim3(cdiv(total, 256)), dim3(256), 0, stream, value, shapes_dev, level_start_dev, loc, attn_w,
-                       (const double *)nullptr, (long)S, M, D, L, (long)Lq, P, total, out, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+                       (const double *)nullptr, (long)S, M, D, L, (long)Lq, P, total, out, (double *)nullptr, (double *)nullptr, (double *)nullptr,
+                       g_error_word.load(std::memory_order_relaxed));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -1582,7 +1590,8 @@ int s2d_msda_backward_dev_f64(const double *value, const int64_t *shapes_dev, co
     const long total = (long)N * Lq * M * D;
     if (total == 0) return S2D_OK;
     hipLaunchKernelGGL((msda_f64_kernel<true>), dim3(cdiv(total, 256)), dim3(256), 0, stream, value, shapes_dev, level_start_dev, loc, attn_w,
-                       grad_out, (long)S, M, D, L, (long)Lq, P, total, (double *)nullptr, grad_value, grad_loc, grad_attn_w);
+                       grad_out, (long)S, M, D, L, (long)Lq, P, total, (double *)nullptr, grad_value, grad_loc, grad_attn_w,
+                       g_error_word.load(std::memory_order_relaxed));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

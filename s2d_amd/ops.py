@@ -308,6 +308,12 @@ def ffn_fusable(W1, W2):
             and lib().call("s2d_ffn_pack_words", 256, int(W1.shape[0]), 0, 0) > 0)
 
 
+_FFN_EPI = 1      # csrc/ffn.hip S2D_FFN_EPI of the loaded library (1: the out_proj form needs no Xn scratch); experiment builds set S2D_FFN_EPI in the environment
+import os as _os
+if _os.environ.get("S2D_FFN_EPI"):
+    _FFN_EPI = int(_os.environ["S2D_FFN_EPI"])
+
+
 def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, want_xn=False, post=None, pre=None):
     """y = LN2?( xn + drop( W2 . drop( relu( W1 . xn + b1 ) ) + b2 ) ),  xn = LN1?(x)   in one launch (csrc/ffn.hip).
     x [M, 256]; ln1 / ln2 = (gamma, beta) or None; dropout = (p, seed, site_hidden, site_out[, row0]) or None.
@@ -323,7 +329,7 @@ def ffn_fused(x, W1, b1, W2, b2, ln1=None, ln2=None, dropout=None, eps=1e-5, wan
     F = W1.shape[0]
     assert ffn_fusable(W1, W2) and C == 256 and (not want_xn or ln1 is not None)
     y = torch.empty_like(x)
-    xn = torch.empty_like(x) if (want_xn or pre is not None) else None
+    xn = torch.empty_like(x) if (want_xn or (pre is not None and _FFN_EPI != 1)) else None
     p, seed, site_h, site_o, row0 = 0.0, 0, 0, 0, 0
     if dropout is not None and dropout[0] > 0.0:
         p, seed, site_h, site_o = dropout[:4]

@@ -27,16 +27,19 @@ Wo = torch.nn.Parameter(torch.randn((256, 256), device=dev, generator=g) * 0.07)
 bo = torch.randn((256,), device=dev, generator=g) * 0.1
 samp = torch.randn((M, 256), device=dev, generator=g)
 NWG = (M + 127) // 128
+ONLY_FULL = os.environ.get("MB_ONLY_FULL", "") == "1"      # ablation builds: the encoder layer's launch at p = 0.3 only
 for name, mk in (("FFN only", lambda p: (lambda: ops.ffn_fused(x, W1, b1, W2, b2, dropout=(p, 7, 1, 2) if p > 0 else None))),
                  ("out_proj + LN1 + FFN + LN2 + next projection (the encoder layer's launch)",
                   lambda p: (lambda: ops.ffn_fused(samp, W1, b1, W2, b2, ln1=(g1, be1), ln2=(g2, be2), dropout=(p, 7, 1, 2) if p > 0 else None,
                                                    post=(Wp, bp, pos), pre=(Wo, bo, x, 0))))):
     for p in (0.0, 0.3):
+        if ONLY_FULL and (name == "FFN only" or p == 0.0):
+            continue
         fn = mk(p)
         for _ in range(3): fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 2.5:
+        while time.perf_counter() - t0 < (1.0 if ONLY_FULL else 2.5):
             for _ in range(50): fn()
             torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,7 +17,7 @@ print(f"# {len(ev)} dispatches, span {span / 1e6:.3f} ms, sum of durations {busy
 agg = collections.defaultdict(lambda: [0, 0, 0])
 prev_end = t0
 for s, e, n in ev:
-    short = n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+    short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
     gap = s - prev_end
     print(f"{(s - t0) / 1e3:10.1f} us  dur {(e - s) / 1e3:8.1f}  gap {gap / 1e3:7.1f}  {short}", file=out)
     a = agg[short]; a[0] += 1; a[1] += e - s; a[2] += max(gap, 0)

@@ -285,6 +285,18 @@ def test_msda_compat_module_fails_loudly_on_bad_shapes():
     MSDA.ms_deform_attn_backward(value, bad, lsi, loc, w, go, 64)
     with pytest.raises(RuntimeError):
         MSDA.check()
+    # the float64 instantiation (ops/test.py gradchecks in double) reports through the same word: a rejected level must not pass as zeros
+    v64, l64, w64 = value.double(), loc.double(), w.double()
+    MSDA.check()
+    assert MSDA.ms_deform_attn_forward(v64, good, lsi, l64, w64, 64).abs().sum() > 0
+    MSDA.check()
+    MSDA.ms_deform_attn_forward(v64, bad, lsi, l64, w64, 64)
+    with pytest.raises(RuntimeError):
+        MSDA.check()
+    MSDA.ms_deform_attn_backward(v64, bad, lsi, l64, w64, go.double(), 64)
+    with pytest.raises(RuntimeError):
+        MSDA.check()
+    MSDA.check()
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])

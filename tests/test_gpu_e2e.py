@@ -174,12 +174,15 @@ def test_amp_compute_mode_vs_oracle_with_fp16_operands(oracle):
             assert np.median(d) < 1e-3 and d.max() < 5e-2, (k, layer, float(np.median(d)), float(d.max()))
             for clip in range(B):
                 if not reached[layer, clip]:
-                    assert d[clip].max() < 1e-3, (k, layer, clip, float(d[clip].max()), "no attention-mask bit differs up to here")
+                    # three fp16 steps (3 x 4.9e-4 of an operand): the pixel decoder in front of the AMP layers is fp32-CLASS, not bitwise
+                    # the oracle's (1e-6: split-fp16 products; since round 5 the encoder FFN's residual is hi + lo / 2048 of its input too),
+                    # and an operand that differs in its last bits can round to the neighbouring fp16 number in either implementation
+                    assert d[clip].max() < 1.5e-3, (k, layer, clip, float(d[clip].max()), "no attention-mask bit differs up to here")
                 else:
                     rows = np.zeros(Q, bool)
                     for L in range(layer):
                         rows |= flipped[L][clip]
-                    big = d[clip].reshape(Q, -1) > 1e-3 if k == "s_masks" else d[clip] > 1e-3
+                    big = d[clip].reshape(Q, -1) > 1.5e-3 if k == "s_masks" else d[clip] > 1.5e-3
                     n_out += int(big.sum()); n_out_in_flipped_rows += int(big[rows].sum())
     print(f"AMP: heads with a flipped attention-mask row per clip: {[int(f.any(-1).sum()) for f in flipped]}; elements outside 1e-3: {n_out}, "
           f"of which in a query row whose own mask flipped: {n_out_in_flipped_rows}")
