@@ -374,10 +374,10 @@ def per_kernel_report(prof, steps, dims, args):
     profiles/r4_pmc_northstar.json (rocprofv3 --pmc passes of scripts/mb_northstar_kernels.py, stamped with their commit)."""
     B, T, Q = dims
     pmc = {}
-    pp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r4_pmc_northstar.json", "r3_pmc_northstar.json")) if os.path.exists(q)), "")
+    pp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_northstar.json", "r4_pmc_northstar.json", "r3_pmc_northstar.json")) if os.path.exists(q)), "")
     if pp and args.config == "c4" and args.dense == "f16x3":
         j = json.load(open(pp))
-        pmc = {k: dict(v, pmc_commit=j.get("commit")) for k, v in j.get("kernels", {}).items()}
+        pmc = {k: dict(v, pmc_commit=j.get("commit"), pmc_program=j.get("program")) for k, v in j.get("kernels", {}).items()}
 
     def agg(sel):
         rows = [r for r in prof if sel(r[3])]
@@ -397,7 +397,7 @@ def per_kernel_report(prof, steps, dims, args):
         if "hbm_bytes_per_launch_corrected" in p:
             e.update(GBps_measured=round(p["hbm_bytes_per_launch_corrected"] / (1000 * ms / n * 1e-6) / 1e9, 1),
                      hbm_bytes_per_launch_pmc=p["hbm_bytes_per_launch_corrected"], traffic_over_algorithmic=round(p["hbm_bytes_per_launch_corrected"] / (by / n), 3),
-                     pmc_commit=p.get("pmc_commit"))
+                     pmc_commit=p.get("pmc_commit"), pmc_program=p.get("pmc_program"))
         out["msda_gather"] = e
     for key, sel, desc in (("mask_einsum", lambda t: t[0] == "gemm" and t[1] == B and t[3] == Q and t[4] == 256 and t[2] > 4096, "bqc,btchw->bqthw as pixel-major GEMM"),
                            ("cross_attn", lambda t: t[0] == "xattn", "masked QK^T / softmax / AV, 3 levels")):
@@ -405,12 +405,18 @@ def per_kernel_report(prof, steps, dims, args):
         if a:
             n, ms, fl, by = a
             tf = fl / (ms * 1e-3) / 1e12
-            e = {"what": desc, "launches_per_step": n // steps, "avg_launch_us": round(1000 * ms / n, 1), "bound": "mfma",
+            gbps = by / (ms * 1e-3) / 1e9
+            # the einsum reads 482 MB of mask features and writes 188 MB of logits per clip for 24 GFLOP: 36 flop / byte, under the ridge of
+            # the split-fp16 matrix rate -- its roofline is HBM; the cross-attention's is the matrix pipe
+            hbm_bound = key == "mask_einsum"
+            e = {"what": desc, "launches_per_step": n // steps, "avg_launch_us": round(1000 * ms / n, 1), "bound": "hbm" if hbm_bound else "mfma",
                  "TFLOPs_algorithmic": round(tf, 1), "frac_of_f16_peak_2500": round(tf / 2500.0, 4), "mfma_flops_per_algorithmic_flop": 3,
-                 "GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1)}
+                 "GBps_algorithmic": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
             p = pmc.get(key, {})
             if "mfma_busy_frac" in p:
-                e.update(mfma_busy=p["mfma_busy_frac"], pmc_commit=p.get("pmc_commit"))
+                e.update(mfma_busy=p["mfma_busy_frac"], pmc_commit=p.get("pmc_commit"), pmc_program=p.get("pmc_program"))
+            if "hbm_bytes_per_launch_corrected" in p and hbm_bound:
+                e.update(hbm_bytes_per_launch_pmc=p["hbm_bytes_per_launch_corrected"], traffic_over_algorithmic=round(p["hbm_bytes_per_launch_corrected"] / (by / n), 3))
             out[key] = e
     return out
 
@@ -649,7 +655,7 @@ def main():
             # HBM bytes per dense launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (scripts/pmc_traffic.py; fetch corrected x2 as MI355X_MICROARCH.md prescribes), stamped with the commit it was taken at
             traffic, traffic_src = None, None
-            for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
                 if args.config == "c4" and args.dense == "f16x3" and os.path.exists(tp):
                     j = json.load(open(tp))
@@ -663,6 +669,11 @@ def main():
                                "algorithmic_bytes_per_launch": int(sum(t[-1] for *_, t in prof) / n),
                                "mfma_flops_per_algorithmic_flop": passes, "mfma_pipe_frac": round(passes * ach / peak, 4),
                                "achieved_vs_fp32_mfma_peak_157.3": round(ach / 157.3, 4),
+                               # the clock the chip HOLDS inside the family's largest kernel (the encoder FFN launch), from the diagnostic
+                               # build's s_memtime / s_memrealtime stamps (profiles/r5_experiments/ffn_phases.txt; not taken in this run):
+                               # `peak` above is the 2.4 GHz figure of MI355X_MICROARCH.md, the matrix pipe itself runs 1.58-1.72 GHz here
+                               "held_clock_MHz_in_ffn_kernel": 1661 if args.dense == "f16x3" else None,
+                               "mfma_pipe_frac_at_held_clock": round(passes * ach / (peak * 1661.0 / 2400.0), 4) if args.dense == "f16x3" else None,
                                "launches_per_step": n // prof_steps, "avg_launch_us": round(1000 * ms / n, 2),
                                "kernel_ms_per_step": round(ms / prof_steps, 2),
                                "algorithmic_gflop_per_step": round(fl / prof_steps / 1e9, 1), "measured": events_note,
