@@ -109,7 +109,9 @@ def train_step_report(model, frames, masks, mean, std, dev, world, cdev, iters=3
         times.append(dt); t_ar.append(dar); losses.append(tot)
     st1 = torch.cuda.memory_stats()
     other = None
-    if world > 1:
+    # opt-in (S2D_BENCH_EXCHANGE_CHECK=1): a collective that misbehaves would take the metric line down with it, and the overlapped
+    # exchange has never run over RCCL (tests/test_gpu_multi.py runs it wherever two GPUs are visible)
+    if world > 1 and os.environ.get("S2D_BENCH_EXCHANGE_CHECK", "0") == "1":
         # the other exchange mode, timed the same way, and both modes on the SAME batch and seeds without stepping: the reduced
         # arenas must agree (bitwise at 2 ranks; to summation order beyond, since a ring reduces a sub-range in another rank order)
         t_o = [iteration(not overlap_default)[0] for _ in range(iters)]
