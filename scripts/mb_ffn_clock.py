@@ -47,9 +47,9 @@ for name, mk in (("FFN only", lambda p: (lambda: ops.ffn_fused(x, W1, b1, W2, b2
         for _ in range(20): fn()
         e.record(); torch.cuda.synchronize()
         ms = s.elapsed_time(e) / 20
-        buf = np.zeros(8 * 4096, np.uint64)
+        buf = np.zeros(16 * 4096, np.uint64)
         assert raw.s2d_ffn_dbg_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-        st = buf.reshape(4096, 8)[: min(4096, NWG)].astype(np.int64)
+        st = buf.reshape(4096, 16)[: min(4096, NWG)].astype(np.int64)
         dt, dr = st[:, 3] - st[:, 1], st[:, 4] - st[:, 2]
         ok = dr > 0
         clk = np.median(dt[ok] / dr[ok]) * 100.0            # MHz
@@ -61,3 +61,8 @@ for name, mk in (("FFN only", lambda p: (lambda: ops.ffn_fused(x, W1, b1, W2, b2
               f"entry -> chunk loop {med(st[:, 1] - st[:, 0]):.1f} | chunk loop {cyc / clk:.1f} ({cyc:.0f} cycles, MFMA pipe busy {mfma_cyc / cyc:.3f}) | "
               f"trailing pass + epilogue {med(st[:, 5] - st[:, 3]):.1f} | projection phase + store drain {med(st[:, 6] - st[:, 5]):.1f} | "
               f"whole workgroup {med(st[:, 6] - st[:, 0]):.1f}; rounds of workgroups {-(-NWG // 256)} (x whole = {-(-NWG // 256) * med(st[:, 6] - st[:, 0]) / 1000:.3f} ms)", flush=True)
+        if name != "FFN only" and st[:, 7].any():
+            print(f"    fine (us): entry -> tiles landed + fragments {med(st[:, 7] - st[:, 0]):.1f} | out_proj phase {med(st[:, 8] - st[:, 7]):.1f} | LN1 + fragments "
+                  f"{med(st[:, 9] - st[:, 8]):.1f} | -> loop start {med(st[:, 1] - st[:, 9]):.1f} || loop end -> trailing pass done {med(st[:, 10] - st[:, 3]):.1f} | epilogue tile "
+                  f"loop {med(st[:, 11] - st[:, 10]):.1f} | LN2 + Y stores issued {med(st[:, 5] - st[:, 11]):.1f} || projection: -> part 4 {med(st[:, 13] - st[:, 5]):.1f} | 4..8 "
+                  f"{med(st[:, 14] - st[:, 13]):.1f} | 8..12 {med(st[:, 15] - st[:, 14]):.1f} | 12..end + drain {med(st[:, 6] - st[:, 15]):.1f}", flush=True)
