@@ -53,7 +53,7 @@
 // (MI355X_MICROARCH.md, DVFS give-back (6))
 __device__ unsigned long long g_ffn_stamps[16 * 4096];      // per workgroup: entry, loop start (time, realtime), loop end (time, realtime), epilogue end, kernel end
 // fine stamps (slots 7..15): 7 input + residual tiles landed (fragments formed), 8 out_proj phase done, 9 LN1 + fragments done (= just before the
-// loop's barrier), 10 trailing pass done, 11 epilogue tile loop done, 12 Y stores issued, 13 / 14 / 15 projection part 4 / 8 / 12 done
+// loop's barrier), 10 trailing pass done, 11 epilogue tile loop done, 13 / 14 / 15 projection part 4 / 8 / 12 done
 #define FFN_STAMP(slot) do { if (tid == 0 && blockIdx.x < 4096) g_ffn_stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int s2d_ffn_dbg_stamps(unsigned long long *host_out)
 {
@@ -75,7 +75,6 @@ constexpr int CHUNKB = 2 * PART;            // image bytes per chunk of 32 hidde
 constexpr int LDS_B1 = 2 * CHUNKB;          // byte offset of the bias copy (behind the two chunk buffers)
 constexpr int FMAX = 2048;                  // hidden width limit of the bias copy
 constexpr int LDS_PB = LDS_B1 + FMAX * 4;   // PRE: the output projection's bias (256 floats) behind it
-constexpr int LDS_STG = LDS_PB + FC * 4 + 4 * FC * 4;    // behind the LayerNorm parameters: the waves' row <-> lane staging tiles, 4 KB each (below)
 constexpr int LDS_LN = LDS_PB + FC * 4;     // LayerNorm parameters: gamma1 | beta1 | gamma2 | beta2 (256 floats each).  Read from global they
                                             // were 16-B loads in the middle of the epilogue's store stream: every use waited `vmcnt(0)`, i.e.
                                             // for every store issued before it too (in-order counter) -- from LDS they wait on lgkmcnt only
@@ -232,60 +231,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f16x8 fr[4][2];                     // weight fragment ring [slot][hi / lo]: a chunk is 32 MFMA groups (16 + 8 + 8), group g uses slot g & 3 and
                                         // requests group g + 2's pair first thing (one group of lead exposed ~30 cycles of LDS latency per group)
     const unsigned char *lane_lds = lds + lane * 16;
-    // ---- row <-> lane transposition of global traffic (round 5) ----
-    // The launch's layout has a ROW on the lane (16 consecutive columns of it per tile), so a plain 16-B global access of a wave touches 64
-    // different rows: 64 separate 16-B requests per instruction.  Measured (profiles/r5_experiments/ffn_phases.txt): ~256 cycles per such
-    // store instruction -- the 32 Y stores of a lane 19 us, the projection's 68 stores 42 us (= that whole phase), the two input tiles 23 us.
-    // Every row tile therefore crosses a wave-private 4-KB LDS tile [32 rows][8 slots of 16 B]: on the memory side an instruction moves 8 rows
-    // x 128 contiguous bytes (lane l: row 8 i + l / 8, slot l % 8), on the register side the lane reads / writes its own row.  Slot s of
-    // row r holds the row's piece s ^ ((r >> 1) & 7): with that XOR both sides are conflict-free ds_*_b128 (the swizzle is applied on the
-    // GLOBAL address, so the memory side's LDS access is linear).  In-order LDS execution inside one wave orders the two sides; no barrier.
-    unsigned char *stg = lds + LDS_STG + wave * 4096;
-    const int crow = lane >> 3;
-    auto cpiece = [&](int i) { return (lane & 7) ^ ((4 * i + (lane >> 4)) & 7); };            // (8 i + crow) >> 1 = 4 i + lane / 16
-    const long row0 = (long)blockIdx.x * 128 + wave * 32;
-    // memory side addressing: wave-uniform 64-bit base (tensor + row0 * ld, in the buffer resource) + a 32-bit per-lane offset of the local
-    // row (rows past M replicate row M - 1, as rowc does) and the piece; the tile's column offset is an immediate / scalar
-    const int lastrow = (int)((long)p.M - 1 - row0);               // >= 0: a workgroup's first row exists, a wave's may not (then every row clamps to M - 1 - row0 < 0 ... see below)
-    auto lrow = [&](int i) { const int r = 8 * i + crow; return r <= lastrow ? r : lastrow; };
-    // both sides' LDS addresses are rebuilt from a fresh lane id where they are used (see tile_voff): register side = this lane's row, piece
-    // 4 h + q at slot (4 h + q) ^ ((tok >> 1) & 7); memory side = instruction i's 1 KB, linear in the lane
-    auto stg_row = [&](int q) { const int l = lane16_asm() >> 4; return stg + (l & 31) * 128 + (((4 * (l >> 5) + q) ^ ((l >> 1) & 7)) * 16); };
-    auto stg_lin = [&](int i) { return stg + i * 1024 + lane16_asm(); };
-    // global [rows][ld floats] tile t (32 columns) -> 16 values of this lane (columns 32 t + 16 h + 0..15 of its row); v = the 4 pieces the
-    // caller loaded with tile_addr()
-    auto tile_rsrc = [&](const float *base, long ld) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + row0 * ld), 0, 0x7FFFFFFF, 0x00020000);
-    };
-    // bytes; ldw = row stride in floats.  Recomputed from a fresh lane id at every use (lane16_asm is volatile): as loop-invariant values
-    // the four offsets are exactly what the allocator spills, and a spilled store offset costs `scratch_load; s_waitcnt vmcnt(0)` per store
-    auto tile_voff = [&](int ldw, int i) {
-        const int l = lane16_asm() >> 4, r = 8 * i + (l >> 3);
-        return ((r <= lastrow ? r : lastrow) * ldw + 4 * ((l & 7) ^ ((4 * i + (l >> 4)) & 7))) * 4;
-    };
-    auto tile_load = [&](__amdgpu_buffer_rsrc_t rs, int ldw, int t, int i) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tile_voff(ldw, i), 128 * t, 0));
-    };
-    auto tile_in = [&](const f32x4 (&v)[4], f32x16 &dst) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(stg_lin(i)) = v[i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(stg_row(q));
-            dst[4 * q] = a[0]; dst[4 * q + 1] = a[1]; dst[4 * q + 2] = a[2]; dst[4 * q + 3] = a[3];
-        }
-    };
-    auto tile_stage = [&](const f32x4 &v, int q) {                  // quarter q (columns 4 q .. 4 q + 3 of the lane's 16) of an outgoing tile
-        *reinterpret_cast<f32x4 *>(stg_row(q)) = v;
-    };
-    auto tile_flush = [&](__amdgpu_buffer_rsrc_t rs, int ldw, int t) {            // the staged tile -> global, 8 rows x 128 B per instruction
-        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-        f32x4 w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const f32x4 *>(stg_lin(i));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, w[i]), rs, tile_voff(ldw, i), 128 * t, 0);     // unconditional (see lrow)
-    };
     constexpr int dbg = S2D_FFN_DBG;    // compile-time timing experiments (results are wrong with any of bits 1-8 set): 1 no DMA, 2 no barrier, 4 no activation work, 8 no fragment reads; 16: clock stamps (results unchanged); 32 no projection-phase stores, 64 no residual loads in the epilogue, 128 no Y / Xn stores, 256 no residual loads in the out_proj phase, 512 no input tile loads
 
     // Philox4x32-10 of the lane's mask block, round r, in two halves (idx = 2 r + half):
@@ -336,10 +281,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dma_part(pre_base, 0, std::integral_constant<int, 8>{});
         dma_part(pre_base + PART, PART, std::integral_constant<int, 8>{});
     } else chunk_loop_prologue(std::true_type{});
-    for (int i = tid; i < p.nchunks * 32; i += 256) reinterpret_cast<float *>(lds + LDS_B1)[i] = p.b1[i];
-    if (PRE) reinterpret_cast<float *>(lds + LDS_PB)[tid] = p.pre_bias[tid];
-    if (LN1) { reinterpret_cast<float *>(lds + LDS_LN)[tid] = p.g1[tid]; reinterpret_cast<float *>(lds + LDS_LN)[FC + tid] = p.be1[tid]; }
-    if (LN2) { reinterpret_cast<float *>(lds + LDS_LN)[2 * FC + tid] = p.g2[tid]; reinterpret_cast<float *>(lds + LDS_LN)[3 * FC + tid] = p.be2[tid]; }
+    // The small parameter vectors (b1, the out_proj bias, the LayerNorm parameters) go to LDS by LDS-DMA as well, 1 KB per instruction,
+    // spread over the waves: loaded through registers each needed its own wait in front of its ds_write -- memory round trips in series IN
+    // FRONT of the input tile's loads (the launch's longest wait).  They are visible behind the first `vmcnt(0)` + barrier, like the weights.
+    {
+        auto dma_vec = [&](const float *src, int nbytes, int dst_byte, int first) {          // piece k of the vector by wave (first + k) % 4
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, nbytes, 0x00020000);
+            for (int k = 0; k * 1024 < nbytes; ++k)
+                if (((first + k) & 3) == wave)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(lds + dst_byte + k * 1024), 16, lane16_asm(), k * 1024, 0, 0);
+        };
+        dma_vec(p.b1, p.nchunks * 32 * 4, LDS_B1, 0);
+        if (PRE) dma_vec(p.pre_bias, FC * 4, LDS_PB, 1);
+        if (LN1) { dma_vec(p.g1, FC * 4, LDS_LN, 2); dma_vec(p.be1, FC * 4, LDS_LN + FC * 4, 3); }
+        if (LN2) { dma_vec(p.g2, FC * 4, LDS_LN + 2 * FC * 4, 0); dma_vec(p.be2, FC * 4, LDS_LN + 3 * FC * 4, 1); }
+    }
 
     // ---- input tile -> fp16 hi / lo B fragments of GEMM 1.  The row is loaded in the accumulator layout (this lane: columns
     // 32 t + 16 h + 0..15 for t = 0..7, lane ^ 32 the other halves) and parked in the output accumulators, which are idle until the
@@ -365,19 +321,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
     };
     {
-        {
-            // all 32 pieces of the row tile in flight (8 rows x 128 B per instruction), then tile by tile through the staging tile
-            const __amdgpu_buffer_rsrc_t rsX = tile_rsrc(p.X, FC);
-            f32x4 xin[8][4];
+        const float *xr = p.X + rowc * FC + 16 * h;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xin[t][i] = (dbg & 512) ? f32x4{(float)lane, 1.f, (float)t, (float)i} : tile_load(rsX, FC, t, i);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) tile_in(xin[t], PRE ? yx[t] : ym[t]);      // PRE: the sampled values park in yx, the residual tile goes to ym, where x1 is formed in place
-        }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = (dbg & 512) ? f32x4{(float)lane, 1.f, (float)t, (float)q} : *reinterpret_cast<const f32x4 *>(xr + 32 * t + 4 * q);
+                f32x16 &dst = PRE ? yx[t] : ym[t];      // PRE: the sampled values park in yx, the residual tile goes to ym, where x1 is formed in place
+                dst[4 * q] = a[0]; dst[4 * q + 1] = a[1]; dst[4 * q + 2] = a[2]; dst[4 * q + 3] = a[3];
+            }
         if constexpr (PRE) {
             // ---- the attention's output projection in front of everything: x1 = res + dropout1( Wo . samp + bo ), tile by tile into the
             // parked row (ms_deform_attn.py:124 output_proj, msdeformattn.py:125 dropout1 + residual).  Same part machinery as the
@@ -387,18 +339,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // accumulators yx, dead once the fragments are formed), into ym, where tile T's x1 = res + drop(...) is then formed IN PLACE:
             // one exposed memory round trip for both tiles instead of one per part -- loaded "a part ahead" each part still waited ~2 us for
             // its tile, 16 of the phase's 56 us (profiles/r5_experiments/ffn_phases.txt; one wave per SIMD: nothing hides it)
-            {
-                const __amdgpu_buffer_rsrc_t rsR = tile_rsrc(p.pre_res, FC);
-                f32x4 rin[8][4];
+            const float *resr = p.pre_res + rowc * FC + 16 * h;
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < 8; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        rin[t][i] = (dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f} : tile_load(rsR, FC, t, i);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) tile_in(rin[t], ym[t]);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = (dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(resr + 32 * t + 4 * q);
+                    ym[t][4 * q] = a[0]; ym[t][4 * q + 1] = a[1]; ym[t][4 * q + 2] = a[2]; ym[t][4 * q + 3] = a[3];
+                }
+            __builtin_amdgcn_sched_barrier(0);                      // both tiles' loads are issued before the first is waited for
             tile_to_frags(yx);                                      // the sampled values as B fragments
             FFN_STAMP(7);
             const unsigned char *pbo = lds + LDS_PB + 64 * h;      // the projection's bias, copied to LDS by the prologue
@@ -481,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             chunk_loop_prologue(std::false_type{});
         }
         if (LN1) {
-            if (!PRE) __syncthreads();                              // the LayerNorm parameters' LDS copy (PRE: the phase's barriers are behind it)
+            if (!PRE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
             float s = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
@@ -736,7 +685,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_barrier(0);
     }
     FFN_STAMP(11);
-    const __amdgpu_buffer_rsrc_t rsY = tile_rsrc(p.Y, FC);
     float mean = 0.f, rstd = 1.f;
     if (LN2) {
         s += __shfl_xor(s, 32, 64);
@@ -749,6 +697,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ss += __shfl_xor(ss, 32, 64);
         rstd = 1.f / sqrtf(ss / (float)FC + p.eps);
     }
+    float *yr = p.Y + rowc * FC + 16 * h;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -759,10 +708,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const f32x4 ga = *reinterpret_cast<const f32x4 *>(lnp), be = *reinterpret_cast<const f32x4 *>(lnp + FC);
                 v = (v - mean) * rstd * ga + be;
             }
-            if (!(dbg & 128)) tile_stage(v, q);
+            if (rowok && !(dbg & 128)) *reinterpret_cast<f32x4 *>(yr + 32 * t + 4 * q) = v;
             if (POST) { ym[t][4 * q] = v[0]; ym[t][4 * q + 1] = v[1]; ym[t][4 * q + 2] = v[2]; ym[t][4 * q + 3] = v[3]; }
         }
-        if (!(dbg & 128)) tile_flush(rsY, FC, t);
         __builtin_amdgcn_sched_barrier(0);
     }
 #if S2D_FFN_DBG & 16
@@ -776,8 +724,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tile_to_frags(ym);
         const long prow = rowc % p.post_S;
         const float *posr = p.post_pos + prow * p.post_ldpos + 16 * h;
+        float *outr = p.post_out + rowc * p.post_ld + 16 * h;
         const float *pbr = p.post_bias + 16 * h;
-        const __amdgpu_buffer_rsrc_t rsO = tile_rsrc(p.post_out, p.post_ld);
         f32x16 pm[2], px[2], zero16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -793,8 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4 v = {m[4 * q] + x[4 * q] * (1.0f / 2048.0f), m[4 * q + 1] + x[4 * q + 1] * (1.0f / 2048.0f),
                        m[4 * q + 2] + x[4 * q + 2] * (1.0f / 2048.0f), m[4 * q + 3] + x[4 * q + 3] * (1.0f / 2048.0f)};
             v += pos4[q];
-            tile_stage(v, q);
-            if (q == 3 && !(dbg & 32)) tile_flush(rsO, p.post_ld, j);      // four unconditional stores (rows past M rewrite row M - 1 with its own values): the wait below counts them
+            if (!(dbg & 32)) *reinterpret_cast<f32x4 *>(outr + 32 * j + 4 * q) = v;        // unconditional (rows past M rewrite row M - 1 with its own values): the wait below counts it
         };
         // part j (accumulator pair CUR = j & 1; PREV: 0 = no previous tile, 1 = the previous tile takes the pos term, 2 = it does not) reads
         // buffer j & 3 of a ring of FOUR 32-KB buffers (the whole weight area: the chunk loop is over).  While it runs, the 8 pieces of
@@ -903,6 +850,8 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
 {
     if (s2d_ffn_pack_words(C, F, Npost, pre_bias != nullptr) < 0 || !x || !pack || !b1 || !b2 || !y || M <= 0 || M > 0x7FFFFF00L) return S2D_ERR_ARG;
     if ((ln1_gamma == nullptr) != (ln1_beta == nullptr) || (ln2_gamma == nullptr) != (ln2_beta == nullptr)) return S2D_ERR_ARG;
+    for (const void *q16 : {(const void *)b1, (const void *)ln1_gamma, (const void *)ln1_beta, (const void *)ln2_gamma, (const void *)ln2_beta, (const void *)pre_bias})
+        if (reinterpret_cast<uintptr_t>(q16) & 15) return S2D_ERR_ARG;      // the parameter vectors travel by 16-B LDS-DMA
     if (xn && !ln1_gamma) return S2D_ERR_ARG;
     if (!(p >= 0.f && p < 1.f)) return S2D_ERR_ARG;
     if (pre_bias && (!pre_res || (!xn && S2D_FFN_EPI != 1) || !ln1_gamma || !ln2_gamma)) return S2D_ERR_ARG;     // the out_proj phase exists for the encoder layer's form only
@@ -919,7 +868,7 @@ int s2d_ffn_fused_f32(const float *x, long M, int C, int F, const void *pack, co
     q.post_bias = post_bias; q.post_pos = post_npos > 0 ? post_pos : post_bias; q.post_out = post_out; q.post_parts = Npost / 32;
     q.pre_bias = pre_bias; q.pre_res = pre_res; q.site_pre = site_pre;
     q.post_S = post_npos > 0 ? post_S : 1; q.post_npos = post_npos; q.post_ld = (int)post_ld; q.post_ldpos = (int)post_ldpos;
-    const int smem = LDS_STG + 4 * 4096;
+    const int smem = LDS_LN + 4 * FC * 4;
     const dim3 grid(cdiv(M, 128)), block(256);
     static S2dDevOnce attr[32];
     const bool drop = q.thresh != 0, ln1 = ln1_gamma != nullptr, ln2 = ln2_gamma != nullptr, post = Npost > 0, pre = pre_bias != nullptr;
