@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmParams p)
 //   <8, 2>: 8 x 16 patch x 128 channels (Cout > 64);  <16, 1>: 16 x 16 patch x 64 channels (Cout <= 64: the res2 bottlenecks'
 //   3 x 3 convolutions, which the implicit-GEMM 128 x 64 kernel ran at 234 TFLOP/s with 9 x the input traffic through L2).
 constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2;
-template <int PH, int WNW>
+template <int PH, int WNW, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p)
 {
     constexpr int HALO_ROWS = (PH + 2) * HALO_W, BNT = 64 * WNW, WROWS = BNT / 32;      // WROWS: weight rows a thread copies per step
@@ -977,22 +977,79 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(GemmParams p
             }
         }
     };
+    // Round 5 (S2D_CONV_HALO_PIPE=1, opt-in: measured, no net gain): the same 24 MFMAs of a tap with their fragment reads ONE GROUP AHEAD.  In the form above every
+    // tap opens with its reads and the first MFMAs wait for them one by one (the schedule of its ISA: r..rrrrr|M|Mrrrrrr.|M|MMMrr|MM..: four to
+    // six exposed LDS round trips per 768 MFMA cycles).  Here a group = one (k-step, pixel tile) = 6 MFMAs; while it runs, the A pair of the next
+    // group is read, the B fragments of the tap's second k-step during its first group, and the A pair of the NEXT TAP's first group during the
+    // tap's last group (the halo does not change inside a channel block; a new block's halo is read behind its barrier).  Only the next tap's
+    // four B fragments are read behind the tap's barrier (the weights become visible there).  Same products, same order: same bits.
+    f16x8 pa[2][2];                     // [buffer][hi / lo] A pair of a group
+    f16x8 pb[2][2][2];                  // [k-step][n tile][hi / lo]
+    auto read_a = [&](int bufi, int tap, int s, int i) {
+        const int toff = ((tap / 3) * HALO_W + (tap % 3)) * ROWW;
+        pa[bufi][0] = *reinterpret_cast<const f16x8 *>(Ah + a_row[i] + toff + 8 * s);
+        pa[bufi][1] = *reinterpret_cast<const f16x8 *>(Ah + a_row[i] + toff + 16 + 8 * s);
+    };
+    auto read_b = [&](int buf, int s) {
+        const unsigned int *bs = Bs + (buf * BNT + wn * 64 + l32) * ROWW + 4 * h;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            pb[s][t2][0] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 8 * s);
+            pb[s][t2][1] = *reinterpret_cast<const f16x8 *>(bs + t2 * 32 * ROWW + 16 + 8 * s);
+        }
+    };
+    auto group = [&](int bufi, int s, int i) {
+        accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][1], pb[s][0][0], accx[i][0], 0, 0, 0);
+        accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][1], pb[s][1][0], accx[i][1], 0, 0, 0);
+        accx[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][0], pb[s][0][1], accx[i][0], 0, 0, 0);
+        accx[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][0], pb[s][1][1], accx[i][1], 0, 0, 0);
+        accm[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][0], pb[s][0][0], accm[i][0], 0, 0, 0);
+        accm[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[bufi][0], pb[s][1][0], accm[i][1], 0, 0, 0);
+    };
+    // tap `tap` on weight buffer `buf`; its first A pair (buffer 0) and its k-step-0 B fragments are already in registers.  nexta: the next
+    // tap reads the same halo (prefetch its first A pair during the last group)
+    auto compute_pipe = [&](int tap, int buf, int ntap, bool nexta) {
+        read_a(1, tap, 0, 1); read_b(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(0, tap, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        group(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(1, tap, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nexta) read_a(0, ntap, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        group(1, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // (channel block, tap) stream: q = cb * 9 + tap.  Weights of step q+1 are loaded during step q and stored into the other
     // buffer before the barrier; the halo of block cb+1 is loaded during tap 6 of block cb and stored after the barrier that
     // ends tap 8 (when nobody reads the old halo any more), followed by one more barrier.
+    constexpr bool pipe = PIPE;
     load_halo(0); load_w(0, 0);
     store_halo(); store_w(0);
     __syncthreads();
     const int Q = cblocks * 9;
     int tap = 0, cb = 0;
+    if (pipe) { read_a(0, 0, 0, 0); read_b(0, 0); }
     for (int q = 0; q < Q; ++q) {
         const int ntap = tap == 8 ? 0 : tap + 1, ncb = tap == 8 ? cb + 1 : cb;
         if (q + 1 < Q) load_w(ntap, ncb);
         if (tap == 6 && cb + 1 < cblocks) load_halo(cb + 1);
-        compute(tap, q & 1);
+        const bool newhalo = tap == 8 && cb + 1 < cblocks;
+        if (pipe) compute_pipe(tap, q & 1, ntap, q + 1 < Q && !newhalo);
+        else compute(tap, q & 1);
         if (q + 1 < Q) store_w((q + 1) & 1);
         __syncthreads();
-        if (tap == 8 && cb + 1 < cblocks) { store_halo(); __syncthreads(); }
+        if (newhalo) { store_halo(); __syncthreads(); }
+        if (pipe && q + 1 < Q) {
+            if (newhalo) read_a(0, ntap, 0, 0);
+            read_b((q + 1) & 1, 0);
+        }
         tap = ntap; cb = ncb;
     }
 
@@ -1890,23 +1947,31 @@ int launch_conv7x7s2_stem(const GemmParams &p, hipStream_t st)
     return S2D_OK;
 }
 
-int launch_conv3x3_halo(const GemmParams &p, hipStream_t st)
+int launch_conv3x3_halo(const GemmParams &pin, hipStream_t st)
 {
+    const GemmParams &p = pin;
+    // opt-in (S2D_CONV_HALO_PIPE=1, read per call): measured +2.6 % on 942 080 x 256 x 2 304, -1..-2 % on the smaller 3 x 3 shapes, -9 % on the
+    // 64-channel form (scripts/mb_conv3_pipe.py, profiles/r5_experiments/not_adopted.txt): at two waves per SIMD the fragment latency the
+    // round-4 form exposes is already covered by the other wave
+    int pipe = 0;
+    if (const char *e = getenv("S2D_CONV_HALO_PIPE")) pipe = atoi(e);
     const size_t lds = sizeof(float) * 4 * 64 * 68;           // epilogue staging (69.6 KB) >= halo + two weight buffers (62.8 / 65.1 KB)
     static S2dDevOnce attr_set;
     if (!attr_set.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return S2D_ERR_LAUNCH;
+        for (const void *fn : {reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<8, 2, true>), reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<16, 1, true>),
+                               reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<8, 2, false>), reinterpret_cast<const void *>(conv3x3_f16x3_halo_kernel<16, 1, false>)})
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return S2D_ERR_LAUNCH;
         attr_set.mark();
     }
     const int imgs = p.M / (p.Hin * p.Win);
     if (p.N <= 64) {
         const int nwg = imgs * cdiv(p.Hin, 16) * cdiv(p.Win, HT_W);
-        hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<16, 1>), dim3(nwg), dim3(256), lds, st, p);
+        if (pipe) hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<16, 1, true>), dim3(nwg), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<16, 1, false>), dim3(nwg), dim3(256), lds, st, p);
     } else {
         const int nwg = imgs * cdiv(p.Hin, HT_H) * cdiv(p.Win, HT_W) * cdiv(p.N, BN);
-        hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<8, 2>), dim3(nwg), dim3(256), lds, st, p);
+        if (pipe) hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<8, 2, true>), dim3(nwg), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv3x3_f16x3_halo_kernel<8, 2, false>), dim3(nwg), dim3(256), lds, st, p);
     }
     S2D_CHECK_LAUNCH();
     return S2D_OK;

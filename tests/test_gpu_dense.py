@@ -259,3 +259,20 @@ def test_forced_kernel_subprocess(dense_mode, switch, select):
                         os.path.join(root, "tests", "test_gpu_dense.py"), os.path.join(root, "tests", "test_gpu_dropin.py"),
                         "-k", select], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_conv3x3_halo_fragment_pipeline_opt_in_is_bitwise_equal(monkeypatch):
+    """S2D_CONV_HALO_PIPE=1 (fragment reads one MFMA group ahead; measured and not adopted, round 5) computes the same products in the
+    same order: bit-identical outputs on both halo geometries (Cout > 64 and Cout <= 64), two channel blocks and more"""
+    import torch
+    from s2d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (n, H, W, Ci, Co) in [(2, 24, 40, 64, 128), (1, 33, 47, 96, 64), (2, 16, 16, 256, 256)]:
+        x = torch.randn((n, H, W, Ci), generator=g).cuda()
+        w = torch.nn.Parameter(torch.randn((Co, 3, 3, Ci), generator=g).mul_((9 * Ci) ** -0.5).cuda(), requires_grad=False)
+        b = torch.randn((Co,), generator=g).cuda()
+        monkeypatch.setenv("S2D_CONV_HALO_PIPE", "0")
+        y0 = ops.conv2d_nhwc(x, w, stride=1, pad=1, bias=b, relu=True)
+        monkeypatch.setenv("S2D_CONV_HALO_PIPE", "1")
+        y1 = ops.conv2d_nhwc(x, w, stride=1, pad=1, bias=b, relu=True)
+        assert torch.equal(y0, y1)
