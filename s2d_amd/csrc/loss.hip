@@ -33,12 +33,24 @@ __device__ __forceinline__ uint32_t rand_key(uint64_t seed, uint64_t stream)
 {
     return (uint32_t)mix64(seed ^ mix64(stream * 0xD1342543DE82EF95ull));
 }
-// two uniforms in [0,1) with 24 random bits each (torch.rand's float construction) for counter i
+// Two uniforms in [0,1) with 24 random bits each (torch.rand's float construction) for counter i.  Round 5: u from hash32(key + i), v from ONE
+// more multiply-xorshift round of that hash (3 quarter-rate integer multiplies per point instead of the 4 of two independent hashes: the
+// point generator is 70 % of hist_kernel<0>).  Statistics of the pair stream over i (480 000 points, three keys; profiles/r5_experiments/
+// not_adopted.txt item 6 has the method): KS of u and of v, corr(u, v), serial correlations, 2-D chi-square of (u, v) and of the serial pairs
+// (u_i, u_i+1), (v_i, v_i+1) on 128 x 128 cells -- all |z| < 2.2; the two-hash generator it replaces scored z = 2.5-4.5 on the serial pairs
+// (its counters key + 2 i and key + 2 i + 1 are neighbours).
+__device__ __forceinline__ uint32_t rand_u_bits(uint32_t key, uint32_t i) { return hash32(key + i); }
+__device__ __forceinline__ uint32_t rand_v_bits(uint32_t a)
+{
+    uint32_t b = a * 0x9E3779B1u;
+    b ^= b >> 15;
+    return b ^ 0x85ebca6bu;
+}
 __device__ __forceinline__ void rand2(uint32_t key, uint32_t i, float &u, float &v)
 {
-    const uint32_t a = hash32(key + 2u * i), b = hash32(key + 2u * i + 1u);
+    const uint32_t a = rand_u_bits(key, i);
     u = (float)(a >> 8) * (1.0f / 16777216.0f);
-    v = (float)(b >> 8) * (1.0f / 16777216.0f);
+    v = (float)(rand_v_bits(a) >> 8) * (1.0f / 16777216.0f);
 }
 
 // bilinear sample (grid_sample, zeros padding, align_corners=False) of a [H,W] plane at (u,v) in [0,1]
@@ -465,8 +477,9 @@ __device__ __forceinline__ void over_point_rng(uint32_t key0, int i, const int *
 {
     int j = 0;
     while (j + 1 < nparts && i >= pb[j + 1]) ++j;
-    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
-    v = fmaf((float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f), dv[j], v0[j]);
+    const uint32_t ra_ = rand_u_bits(key0, (uint32_t)i);
+    u = (float)(ra_ >> 8) * (1.0f / 16777216.0f);
+    v = fmaf((float)(rand_v_bits(ra_) >> 8) * (1.0f / 16777216.0f), dv[j], v0[j]);
 }
 
 // Binomial(N, p) by inversion of U, one WAVE per draw (all 64 lanes call with the same arguments and receive the same value).
@@ -643,8 +656,9 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
             const int y0max = min(yhi, p.hm) - 1;
 #pragma unroll 2
             for (int i = lo + (int)threadIdx.x; i < hi; i += LTHREADS) {
-                const float u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
-                const float v = fmaf((float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f), vr.dv, vr.v0);
+                const uint32_t ra_ = rand_u_bits(key0, (uint32_t)i);
+                const float u = (float)(ra_ >> 8) * (1.0f / 16777216.0f);
+                const float v = fmaf((float)(rand_v_bits(ra_) >> 8) * (1.0f / 16777216.0f), vr.dv, vr.v0);
                 const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
                 const int y0 = min(max((int)floorf(y), ylo), y0max);
@@ -699,8 +713,9 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
                 float u, v;
                 if (cr2) { u = cr2[2 * i]; v = cr2[2 * i + 1]; }
                 else {
-                    u = (float)(hash32(key1 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
-                    v = (float)(hash32(key1 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                    const uint32_t ra_ = rand_u_bits(key1, (uint32_t)i);
+                    u = (float)(ra_ >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(rand_v_bits(ra_) >> 8) * (1.0f / 16777216.0f);
                 }
                 const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
                 const float x = ((2.f * u - 1.f + 1.f) * p.wm - 1.f) * 0.5f;
@@ -863,8 +878,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
                     float u, v;
                     if (cr) { u = cr[2 * ic]; v = cr[2 * ic + 1]; }
                     else {
-                        u = (float)(hash32(key0 + 2u * (uint32_t)ic) >> 8) * (1.0f / 16777216.0f);
-                        v = (float)(hash32(key0 + 2u * (uint32_t)ic + 1u) >> 8) * (1.0f / 16777216.0f);
+                        const uint32_t ra_ = rand_u_bits(key0, (uint32_t)ic);
+                        u = (float)(ra_ >> 8) * (1.0f / 16777216.0f);
+                        v = (float)(rand_v_bits(ra_) >> 8) * (1.0f / 16777216.0f);
                         if (strat) v = fmaf(v, vr.dv, vr.v0);
                     }
                     const float y = ((2.f * v - 1.f + 1.f) * p.hm - 1.f) * 0.5f;
@@ -1105,8 +1121,9 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }
                 else if (over) over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v);
                 else {
-                    u = (float)(hash32(key0 + 2u * (uint32_t)i) >> 8) * (1.0f / 16777216.0f);
-                    v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                    const uint32_t ra_ = rand_u_bits(key0, (uint32_t)i);
+                    u = (float)(ra_ >> 8) * (1.0f / 16777216.0f);
+                    v = (float)(rand_v_bits(ra_) >> 8) * (1.0f / 16777216.0f);
                 }
                 point(xv, sample_bits(tb, p.H, p.W, u, v), u, v);
             };
@@ -1141,7 +1158,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
                     float v;
                     if (cr) v = cr[2 * i + 1];
                     else if (over) { float u; over_point_rng(key0, i, s_pb, s_v0, s_dv, sg_.nparts, u, v); }
-                    else v = (float)(hash32(key0 + 2u * (uint32_t)i + 1u) >> 8) * (1.0f / 16777216.0f);
+                    else v = (float)(rand_v_bits(rand_u_bits(key0, (uint32_t)i)) >> 8) * (1.0f / 16777216.0f);
                     const int y0 = y0_of(v);
                     owned = y0 >= own_lo && y0 < own_hi;
                 }
