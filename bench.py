@@ -458,6 +458,10 @@ def main():
     ap.add_argument("--one-stream", "--no-overlap", dest="one_stream", action="store_true",
                     help="time the one-stream schedule (default: teacher forward + GT criterion on a second HIP stream; the other "
                          "schedule is timed after the metric and reported under `schedules`, with a bitwise comparison of the losses)")
+    ap.add_argument("--clip-pipeline", dest="clip_pipeline", action="store_true", default=os.environ.get("S2D_CLIP_PIPELINE", "0") == "1",
+                    help="process the batch clip by clip, clip b's criteria on a third stream beside clip b + 1's forwards "
+                         "(KDVideoMaskFormer.pipeline_clips)")
+    ap.add_argument("--no-clip-pipeline", dest="clip_pipeline", action="store_false")
     ap.add_argument("--no-other-schedule", action="store_true",
                     help="profiling runs: time only the chosen schedule (no second timing pass, no bitwise comparison), so that a kernel "
                          "trace of the process holds one schedule's launches")
@@ -512,6 +516,7 @@ def main():
     model = build_kd_model(num_queries=Q, num_frames=T, num_points=P, weights=(0.0, 5.0, 5.0), kd_weights=(0.0, 5.0, 5.0),
                            dropout=args.dropout).to(dev)
     model.train()            # student AND teacher in training mode, as in the reference (the teacher is never put in eval(), Appendix C)
+    model.pipeline_clips = args.clip_pipeline
     frames, masks = synth_batch(rank, B, T, H0, W0, N, dev)
     gt = TargetSet.from_list(masks, device=dev)
     calibrate_teacher(model, ops.normalize_pad(frames))

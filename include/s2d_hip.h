@@ -170,7 +170,8 @@ int s2d_msda_backward_sorted_f32(const float *value, const int64_t *shapes_host,
                                  int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn_w, void *workspace,
                                  long workspace_bytes, hipStream_t stream);
 /* The same with row strides: value rows (n, s) are M * D floats at stride ldv, grad_value rows at stride ldg (column slices of
- * the merged projection output / of its gradient buffer: no contiguous copy of value, no concatenation of the gradients). */
+ * the merged projection output / of its gradient buffer: no contiguous copy of value, no concatenation of the gradients).
+ * grad_loc == grad_attn_w == NULL: grad_value only (the caller takes the query-owned half from s2d_msda_fused_backward_query_f32). */
 int s2d_msda_backward_sorted_strided_f32(const float *value, long ldv, const int64_t *shapes_host, const int64_t *level_start_host,
                                          const float *loc, const float *attn_w, const float *grad_out, int N, int S, int M, int D,
                                          int L, int Lq, int P, float *grad_value, long ldg, float *grad_loc, float *grad_attn_w,
@@ -228,6 +229,14 @@ int s2d_msda_fused_prep_f32(const float *offs_logits, int ldoa, const int64_t *s
                             float *loc, float *attn, hipStream_t stream);
 int s2d_msda_fused_chain_f32(const float *attn, const float *grad_loc, const float *grad_attn, const int64_t *shapes_host, int N,
                              int S, int M, int L, int P, float *d_offs_logits, int ldd, hipStream_t stream);
+/* The query-owned half of that backward in ONE launch for the S2D geometry (M = 8, D = 32, L = 3, P = 4; anything else: S2D_ERR_ARG):
+ * d_offs_logits [N][S][ldd] straight from grad_out [N][S][M][32], the value rows (stride ldv) and the raw projection rows -- what
+ * grad_loc / grad_attn of s2d_msda_backward_sorted*_f32 followed by s2d_msda_fused_chain_f32 give (reference: the grad_sampling_loc /
+ * grad_attn_weight half of ms_deformable_col2im_gpu_kernel_*, ops/src/cuda/ms_deform_im2col_cuda.cuh:119-163, and autograd's chain
+ * through ms_deform_attn.py:103-113), without those two tensors in memory.  16-B aligned value / offs_logits / grad_out rows. */
+int s2d_msda_fused_backward_query_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+                                      const float *grad_out, int N, int S, int M, int D, int L, int P, float *d_offs_logits, int ldd,
+                                      hipStream_t stream);
 
 /* ---- bandwidth-bound glue (HBM-bound, 16-B accesses) ----------------------------------------------- */
 

@@ -219,25 +219,6 @@ def weight_grad(dy, x, out=None, beta=0.0, bias_out=None, bias_beta=0.0):
     return out
 
 
-def contract(a, bt):
-    """[M,N] = a[M,K] @ bt[N,K]^T over a LONG contraction K (pixels), small M, N: the K axis is cut into slices that run as the
-    batch of one NT GEMM, partials added in a fixed order (weight_grad without its transposes)"""
-    ops._chk(a); ops._chk(bt)
-    M, K = a.shape
-    N = bt.shape[0]
-    assert bt.shape[1] == K and K % 4 == 0
-    S, chunk = _slices(K, ((M + 127) // 128) * ((N + 127) // 128))
-    chunk = min(chunk, K)
-    while K % chunk:                      # equal slices without padding the operands: the largest divisor of K that is a multiple of 4
-        chunk -= 4
-    S = K // chunk
-    part = torch.empty((S, M, N), device=a.device, dtype=torch.float32)
-    lib().call("s2d_gemm_nt_f32", a, bt, part, M, N, chunk, K, K, N, S, chunk, chunk, M * N, None, None, None, N, 0, 0, 0, 0, None, _st())
-    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    lib().call("s2d_reduce_slices_f32", part, S, M * N, M * N, 0.0, out, _st())
-    return out
-
-
 def bias_grad(dy, out=None, beta=0.0):
     """db [N] = column sums of dy [M,N]"""
     ops._chk(dy)
@@ -484,6 +465,9 @@ def maxpool_backward(x, dy):
 
 
 # --------------------------------------------------------------------------- multi-scale deformable attention (fused form)
+_MSDA_BWD_REC = os.environ.get("S2D_MSDA_BWD_REC", "1") != "0"
+
+
 def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4, merged=False):
     """gradients of ops.msda_fused_forward(value [N,S,C], shapes, offs_logits [N,S,>=288]) -> (d_value [N,S,C],
     d_offs_logits [N,S,M*L*P*3]).  value / offs_logits may be the column slices of the merged projection output (read in place
@@ -509,10 +493,18 @@ def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4, merged=F
         doa = torch.empty((N, S, ldd), device=dev, dtype=torch.float32)
         gv = torch.empty((N, S, C), device=dev, dtype=torch.float32)
         ldo, ldg = ldd, C
-    gl, ga = torch.empty_like(loc), torch.empty_like(attn)
     go = grad_out.contiguous()
     nb = lib().call("s2d_msda_backward_workspace_bytes", sh, N, M, L, S, P)
     ws = torch.empty((nb,), device=dev, dtype=torch.uint8)
+    # the S2D geometry: the query-owned half (d offsets, d logits) in one record-form launch on the raw projection rows, no grad_loc /
+    # grad_attn tensors and no chain pass (S2D_MSDA_BWD_REC=0: the two-step form below, which serves every other geometry)
+    if _MSDA_BWD_REC and M == 8 and D == 32 and L == 3 and P == 4 and S * value.stride(1) * 4 < 0x7fffffff:
+        lib().call("s2d_msda_backward_sorted_strided_f32", value, value.stride(1), sh, lsi, loc, attn, go, N, S, M, D, L, S, P, gv, ldg, None, None,
+                   ws, nb, _st())
+        lib().call("s2d_msda_fused_backward_query_f32", value, value.stride(1), sh, offs_logits, offs_logits.stride(1), go, N, S, M, D, L, P,
+                   doa, ldo, _st())
+        return (gv, doa, buf) if merged else (gv, doa)
+    gl, ga = torch.empty_like(loc), torch.empty_like(attn)
     lib().call("s2d_msda_backward_sorted_strided_f32", value, value.stride(1), sh, lsi, loc, attn, go, N, S, M, D, L, S, P, gv, ldg, gl, ga,
                ws, nb, _st())
     lib().call("s2d_msda_fused_chain_f32", attn, gl, ga, sh, N, S, M, L, P, doa, ldo, _st())

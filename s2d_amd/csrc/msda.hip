@@ -497,6 +497,159 @@ void msda_fused_rec_kernel(const float *__restrict__ value, int ldv, Levels lv, 
     *reinterpret_cast<f32x4 *>(out + (((long)n * S + q) * M + m) * D + j * 4) = acc;
 }
 
+// Record form of the query-owned half of the fused backward (round 5): d(loss)/d(offsets, logits) of one (query, head) from grad_out and
+// the value rows, in the geometry of msda_fused_rec_kernel (a wave = one query, 8 lanes x 4 channels per head, per-wave records in LDS,
+// twelve branch-free steps of four bounds-checked 16-B loads) -- it replaces msda_bwd_loc_kernel + msda_fused_chain_kernel for the S2D
+// geometry and reads the raw projection rows, so grad_loc / grad_attn never exist in memory:
+//   d_k      = <grad_out[q, m, :], value[corner k]>                              (4 channels per lane, summed over the head's 8 lanes)
+//   d a_i    = hh hw d1 + hh lw d2 + lh hw d3 + lh lw d4                         (cuh:150-155)
+//   d off_x  = a_i (hh (d2 - d1) + lh (d4 - d3)),  d off_y = a_i (hw (d3 - d1) + lw (d4 - d2))
+//              -- the W of d/d(loc.x) (cuh:146-149) and the 1 / W of loc = ref + off / W (ms_deform_attn.py:106-109) cancel
+//   d logit_i = a_i (d a_i - sum_j a_j d a_j)                                     (softmax backward, j in index order)
+// The 8-lane sums are three DPP adds (quad_perm xor 1, xor 2, row_half_mirror): every lane of a head ends with the same bits.
+// Record of a sample: four corner byte offsets (REC_OOB outside the map), lh, lw, a; lh = lw = 0 for a sample outside every map, whose
+// corners all read zero: its gradients are exactly zero, as the reference skips it (cuh:367).
+__device__ __forceinline__ float head_sum8(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    return x;
+}
+
+template <int L_, int P_, int WAVES_EU>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WAVES_EU, WAVES_EU)))
+void msda_fused_bwd_rec_kernel(const float *__restrict__ value, int ldv, Levels lv, const float *__restrict__ oa, int ldoa,
+                               const float *__restrict__ gout, int S, int blk_per_n, float *__restrict__ doa, int ldd,
+                               unsigned int frame_bytes)
+{
+    constexpr int LP = L_ * P_, M = 8, D = 32;
+    constexpr int REC_WAVE = LP * REC_ROW;
+    static_assert(LP <= 16 && LP > 8, "two samples per lane");
+    extern __shared__ __attribute__((aligned(16))) unsigned char rec_lds[];
+    const int n = blockIdx.y;
+    int tb = xcd_band(blockIdx.x, blk_per_n), lq = 0, ntx = 1;
+#pragma unroll
+    for (; lq < L_; ++lq) {
+        ntx = (lv.W[lq] + 3) >> 2;
+        const int nt = ntx * ((lv.H[lq] + 3) >> 2);
+        if (tb < nt) break;
+        tb -= nt;
+    }
+    if (lq >= L_) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qy = (tb / ntx) * 4 + (w >> 2), qx = (tb % ntx) * 4 + (w & 3);
+    if (qy >= lv.H[lq] || qx >= lv.W[lq]) return;             // whole waves leave; no workgroup barrier below
+    const int q = (int)lv.start[lq] + qy * lv.W[lq] + qx;
+    const int m = lane >> 3, j = lane & 7;
+    const float ref_x = ((float)qx + 0.5f) / (float)lv.W[lq];
+    const float ref_y = ((float)qy + 0.5f) / (float)lv.H[lq];
+    unsigned char *rec = rec_lds + w * REC_WAVE;
+
+    // ---- phase 1: as the forward's (same formulas, same order), the record holds lh, lw instead of the four products ----
+    const float *row = oa + ((long)n * S + q) * ldoa;
+    const float *offp_g = row + m * (LP * 2);
+    const float *lgp = row + M * LP * 2 + m * LP;
+    float own_ox[2], own_oy[2], own_lg[2], own_e[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = j + 8 * r;
+        const bool live = i < LP;
+        const int ic = live ? i : LP - 1;
+        const float2 o = *reinterpret_cast<const float2 *>(offp_g + 2 * ic);
+        own_ox[r] = o.x; own_oy[r] = o.y;
+        own_lg[r] = live ? lgp[ic] : -INFINITY;
+        mx = fmaxf(mx, own_lg[r]);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) own_e[r] = expf(own_lg[r] - mx);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) den += __shfl(own_e[i >> 3], i & 7, 8);
+    const float inv = 1.f / den;
+    const unsigned int ldv4 = (unsigned int)ldv * 4u;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = j + 8 * r;
+        if (i < LP) {
+            const int l = i / P_;
+            int H = lv.H[0], W = lv.W[0], st = (int)lv.start[0];
+#pragma unroll
+            for (int k = 1; k < L_; ++k)
+                if (l == k) { H = lv.H[k]; W = lv.W[k]; st = (int)lv.start[k]; }
+            const float lx = ref_x + own_ox[r] / (float)W, ly = ref_y + own_oy[r] / (float)H;
+            const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = in ? h_im - h0 : 0.f, lw = in ? w_im - w0 : 0.f;
+            const bool t = in && h0 >= 0, b = in && h1 <= H - 1, lft = w0 >= 0, rgt = w1 <= W - 1;
+            const unsigned int p00 = (unsigned int)(st + h0 * W + w0) * ldv4;
+            const u32x4_t off = {t && lft ? p00 : REC_OOB, t && rgt ? p00 + ldv4 : REC_OOB,
+                                 b && lft ? p00 + (unsigned int)W * ldv4 : REC_OOB, b && rgt ? p00 + (unsigned int)(W + 1) * ldv4 : REC_OOB};
+            unsigned char *d = rec + i * REC_ROW + m * REC_HEAD;
+            *reinterpret_cast<u32x4_t *>(d) = off;
+            own_e[r] *= inv;                                                    // a_i from here on
+            *reinterpret_cast<f32x4 *>(d + 16) = f32x4{lh, lw, own_e[r], 0.f};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 2 ----
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value + (long)n * S * ldv), 0, (int)frame_bytes, 0x00020000);
+    const unsigned int lanecol = (unsigned int)(m * D + j * 4) * 4u;
+    const unsigned char *rd = rec + m * REC_HEAD;
+    const f32x4 tg = *reinterpret_cast<const f32x4 *>(gout + (((long)n * S + q) * M + m) * D + j * 4);
+    constexpr int DEPTH = WAVES_EU >= 8 ? 2 : 4;
+    f32x4 pv[DEPTH][4];
+    float2 pl[DEPTH];
+    float pa[DEPTH];
+    auto issue = [&](int i, int sl) {
+        const u32x4_t off = *reinterpret_cast<const u32x4_t *>(rd + i * REC_ROW);
+        pl[sl] = *reinterpret_cast<const float2 *>(rd + i * REC_ROW + 16);
+        pa[sl] = *reinterpret_cast<const float *>(rd + i * REC_ROW + 24);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            pv[sl][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)(off[k] + lanecol), 0, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(i, i);
+    float kw[2] = {0.f, 0.f}, kx[2] = {0.f, 0.f}, ky[2] = {0.f, 0.f};
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const int sl = i % DEPTH;
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = tg[0] * pv[sl][k][0] + tg[1] * pv[sl][k][1] + tg[2] * pv[sl][k][2] + tg[3] * pv[sl][k][3];
+        const float lh = pl[sl].x, lw = pl[sl].y, a = pa[sl];
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        float gw = hh * hw * d[0] + hh * lw * d[1] + lh * hw * d[2] + lh * lw * d[3];
+        float gx = a * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+        float gy = a * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+        if (i + DEPTH < LP) issue(i + DEPTH, sl);
+        gw = head_sum8(gw); gx = head_sum8(gx); gy = head_sum8(gy);
+        dot += a * gw;
+        if ((i & 7) == j) { kw[i >> 3] = gw; kx[i >> 3] = gx; ky[i >> 3] = gy; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float *orow = doa + ((long)n * S + q) * ldd;
+    float *od = orow + m * (LP * 2), *ol = orow + M * LP * 2 + m * LP;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = j + 8 * r;
+        if (i < LP) {
+            *reinterpret_cast<float2 *>(od + 2 * i) = float2{kx[r], ky[r]};
+            ol[i] = own_e[r] * (kw[r] - dot);
+        }
+    }
+}
+
 // One HEAD per workgroup, the coarsest level of that head in LDS.  The gather is bound by the line rate of the vector L1: every bilinear
 // tap of a (query, head) is one 128-B line, 48 per (query, head) at L x P = 12.  A head's 32 channels of the coarsest level are
 // H x W x 128 B -- 115 KB at the S2D geometry (23 x 40) -- so a workgroup that works on ONE head copies that plane into LDS once and
@@ -1372,6 +1525,8 @@ static int launch_backward_sorted(const G &geo, long ncell_cap, const float *val
     hipLaunchKernelGGL((msda_bwd_value_kernel<G>), dim3(cdiv(ntgt * 8, 256)), dim3(256), 0, stream, grad_out, rec, off, geo, ntgt, S, M, L,
                        grad_value, ldg);
     S2D_CHECK_LAUNCH();
+    if (!grad_loc && !grad_attn_w) return S2D_OK;             // grad_value only (the fused backward takes the query-owned half in its own launch)
+    if (!grad_loc || !grad_attn_w) return S2D_ERR_ARG;
     const int nb = cdiv((long)Lq * M * 8, 256);
     hipLaunchKernelGGL((msda_bwd_loc_kernel<G>), dim3(nb, N), dim3(256), 0, stream, value, geo, loc, attn_w, grad_out, S, M, L, Lq, P, nb,
                        grad_loc, grad_attn_w, ldv);
@@ -1788,6 +1943,47 @@ int s2d_msda_fused_forward_f32(const float *value, int ldv, const int64_t *shape
         } else if (share) hipLaunchKernelGGL((msda_fused_kernel<12, false, true>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
         else hipLaunchKernelGGL((msda_fused_kernel<12, false, false>), dim3(nb, N), dim3(256), 0, stream, value, ldv, lv, offs_logits, ldoa, S, M, L, P, nb, out);
     }
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+/* The query-owned half of the fused backward in one launch: d(loss)/d(offs_logits) [N][S][ldd] (2 * M * L * P offset gradients, then
+ * M * L * P logit gradients per row, the layout of offs_logits) from grad_out [N][S][M][32], the value tensor and the raw projection
+ * rows; what s2d_msda_backward_sorted*_f32's grad_loc / grad_attn followed by s2d_msda_fused_chain_f32 give, without those two
+ * tensors.  S2D geometry only (M = 8, D = 32, L = 3, P = 4); other geometries: S2D_ERR_ARG, use the two-step form. */
+int s2d_msda_fused_backward_query_f32(const float *value, int ldv, const int64_t *shapes_host, const float *offs_logits, int ldoa,
+                                      const float *grad_out, int N, int S, int M, int D, int L, int P, float *d_offs_logits, int ldd,
+                                      hipStream_t stream)
+{
+    Levels lv;
+    if (int e = fill_levels(lv, shapes_host, nullptr, L, S)) return e;
+    if (M != 8 || D != 32 || L != 3 || P != 4 || ldoa < M * L * P * 3 || (ldoa & 3) || ldv < M * D || (ldv & 3) || ldd < M * L * P * 3 || (ldd & 3) ||
+        (reinterpret_cast<uintptr_t>(offs_logits) & 15) || (reinterpret_cast<uintptr_t>(d_offs_logits) & 7) || (reinterpret_cast<uintptr_t>(grad_out) & 15) ||
+        (reinterpret_cast<uintptr_t>(value) & 15))
+        return S2D_ERR_ARG;
+    if (N <= 0) return S2D_OK;
+    const long fb = ((long)(S - 1) * ldv + (long)M * D) * 4;
+    if (fb >= 0x7fffffffL) return S2D_ERR_ARG;
+    int ntile = 0;
+    for (int l = 0; l < L; ++l) ntile += ((lv.W[l] + 3) / 4) * ((lv.H[l] + 3) / 4);
+    static S2dDevOnce attr;
+    if (!attr.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_bwd_rec_kernel<3, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 12 * REC_ROW) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_bwd_rec_kernel<3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 12 * REC_ROW) != hipSuccess)
+            return S2D_ERR_LAUNCH;
+        attr.mark();
+    }
+    // 4 waves per SIMD, four samples' loads in flight: 3.98 ms per encoder layer's whole backward at c4 against 4.56 with the loc + chain
+    // pair.  The 8-wave form (S2D_MSDA_BWD_WAVES=8, read per call; the forward's choice) needs 6 spilled registers and 28 B of scratch
+    // per lane at its 64-register budget and runs at 11.8 ms (profiles/r5_experiments/not_adopted.txt).
+    int waves = 4;
+    if (const char *e = getenv("S2D_MSDA_BWD_WAVES")) waves = atoi(e);
+    if (waves != 8)
+        hipLaunchKernelGGL((msda_fused_bwd_rec_kernel<3, 4, 4>), dim3(ntile, N), dim3(1024), 16 * 12 * REC_ROW, stream, value, ldv, lv, offs_logits, ldoa, grad_out, S, ntile,
+                           d_offs_logits, ldd, (unsigned int)fb);
+    else
+        hipLaunchKernelGGL((msda_fused_bwd_rec_kernel<3, 4, 8>), dim3(ntile, N), dim3(1024), 16 * 12 * REC_ROW, stream, value, ldv, lv, offs_logits, ldoa, grad_out, S, ntile,
+                           d_offs_logits, ldd, (unsigned int)fb);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

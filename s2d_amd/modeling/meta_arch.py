@@ -183,6 +183,13 @@ class KDVideoMaskFormer(nn.Module):
         # and bitwise identical to the one-stream schedule (bench.py re-checks that on every run; DESIGN.md section 5,
         # "Streams", has the history of why the default here stays one stream).
         self.overlap_criteria = False
+        # Round 5: clips are independent units, and the two criteria (VALU / LDS-bound point sampling) contend with EACH OTHER on two streams
+        # (measured: 19.3 ms side by side = the sum of the two alone) but not with the matrix-bound forwards.  pipeline_clips walks the batch clip by
+        # clip: clip b's criteria run on a third stream beside clip b + 1's forwards.  Same arithmetic per clip; the batch-wide normalisers
+        # (num_masks, the class loss's weight sum) are applied when the clips' losses are combined.  Off by default (the batch form is what the
+        # parity tests with injected points drive); bench.py turns it on for the timed schedules.
+        self.pipeline_clips = False
+        self._crit_stream = None
         # The teacher's intermediate mask predictions feed only its own attention masks (no loss reads them): by default
         # they are evaluated at the attention masks' source pixels only; True computes the full maps like the reference.
         self.teacher_aux_masks = False
@@ -259,6 +266,8 @@ class KDVideoMaskFormer(nn.Module):
         # The teacher forward (+ its pseudo-target selection) is independent of the student forward and the GT
         # criterion: it runs on a second HIP stream so the launch tails and the small decoder kernels of one network
         # fill the CUs the other leaves idle.  Every kernel is deterministic, so the schedule does not change results.
+        if self.pipeline_clips and images.shape[0] // self.num_frames > 1 and not getattr(self, "keep_kd_targets", False):
+            return self._forward_losses_clip_pipeline(images, gt_targets, kd_nmax, coords_gt, coords_kd)
         main = torch.cuda.current_stream()
         if self.overlap_teacher:
             if self._side is None:
@@ -292,6 +301,119 @@ class KDVideoMaskFormer(nn.Module):
         self.last = dict(student=student, teacher=teacher, kd_count=cnt, kd_kept=kept)
         if getattr(self, "keep_kd_targets", False):       # tests: the pseudo-target planes the KD matcher saw (1.5 GB at c4 otherwise freed)
             self.last["kd_targets"] = tgt
+        return out
+
+    @torch.no_grad()
+    def _forward_losses_clip_pipeline(self, images, gt_targets: TargetSet, kd_nmax, coords_gt=None, coords_kd=None):
+        """forward_losses clip by clip (kd_video_maskformer_model.py:263-326 on each clip; no op of the path crosses clips): student
+        forward of clip b on the main stream, teacher forward + pseudo targets on the side stream, and the clip's two criteria on a third
+        stream beside clip b + 1's forwards (with overlap_teacher / overlap_criteria off everything runs on the main stream, same arithmetic:
+        the two schedules stay bitwise comparable).  Normalisers that the reference takes over the whole batch:
+          * num_masks = clamp(sum of targets over the batch / world, 1) (criterion.py:404-409).  GT pass: the counts are host numbers, the
+            clip's call gets world * n_b / N as its world size, which makes its own normaliser N / world.  KD pass: the counts live on
+            the device, each clip is normalised by its own clamp(n_b / world, 1) and the sum is rescaled by clamp(sum n_b / world, 1);
+          * loss_ce = weighted mean over all B * Q queries (criterion.py:227-251): a clip's mean times its weight sum
+            n_b + (Q - n_b) * eos_coef, summed, over the batch's weight sum."""
+        T = self.num_frames
+        B = images.shape[0] // T
+        Hp, Wp = images.shape[1:3]
+        Q = self.num_queries
+        dev = images.device
+        main = torch.cuda.current_stream()
+        two = self.overlap_teacher
+        if two and self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        if two and self.overlap_criteria and self._crit_stream is None:
+            self._crit_stream = torch.cuda.Stream(device=dev)
+        side = self._side if two else main
+        crit = self._crit_stream if (two and self.overlap_criteria) else main
+        ws0 = self.criterion.world_size
+        world = self.criterion._world()
+        eos = float(self.criterion.eos_coef)
+
+        def clip_coords(c, b, nmax, off):
+            """injected points (parity tests) of clip b: matcher [NL,B,P,2] by clip; over / rand [NL, B * maxm * T, n, 2] are indexed by a
+            row's rank among the KEPT rows of its layer in (clip, slot, frame) order (csrc/loss.hip coord_rows), so clip b's window of a
+            layer starts at the number of rows the earlier clips kept in that layer"""
+            if c is None:
+                return None
+            rows = min(Q, nmax) * T
+            out = {}
+            for k, v in c.items():
+                if k == "matcher":
+                    out[k] = v[:, b:b + 1].contiguous()
+                else:
+                    out[k] = torch.stack([v[l, off[l]:off[l] + rows] for l in range(v.shape[0])]).contiguous()
+            return out
+
+        def kept_rows(nmax):
+            """rows the criterion call just made kept, per layer (tests with injected points only: one small read back)"""
+            ws = self.criterion.last_ctx["point_loss"][-1].view(torch.int32)
+            NL = self.criterion.last_indices[2].shape[0]                  # B = 1 in a clip's call
+            rows = NL * min(Q, nmax) * T
+            return ws[rows * 6:rows * 6 + NL].cpu().tolist()
+
+        inj_gt, inj_kd = coords_gt is not None, coords_kd is not None
+        off_gt = off_kd = None
+        ns = list(gt_targets.host_counts) if gt_targets.host_counts is not None else gt_targets.count.cpu().tolist()
+        n_tot = float(sum(ns))
+        crit.wait_stream(main)            # everything enqueued before this call (the third stream's pool memory included) is ordered
+        keep, parts = [], []
+        for b in range(B):
+            img = images[b * T:(b + 1) * T]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                teacher = self.teacher(img, True, aux_masks=self.teacher_aux_masks)
+                tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                                    self.score_threshold_distillation, self.num_predictions_distillation)
+                if self.distillation_nms:
+                    tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
+            student = self.student(img, True)
+            crit.wait_stream(main); crit.wait_stream(side)
+            gt_b = TargetSet(gt_targets.masks[b:b + 1], gt_targets.count[b:b + 1], gt_targets.nonempty[b:b + 1], [ns[b]])
+            with torch.cuda.stream(crit):
+                NLp = student.class_logits.shape[0]
+                off_gt, off_kd = off_gt or [0] * NLp, off_kd or [0] * NLp
+                self.criterion.world_size = world * (ns[b] / n_tot) if (ns[b] > 0 and n_tot > 0) else world
+                lg = self.criterion(student, gt_b, False, clip_coords(coords_gt, b, gt_targets.masks.shape[1], off_gt), keep_ctx=inj_gt)
+                if inj_gt:
+                    off_gt = [o + k for o, k in zip(off_gt, kept_rows(gt_targets.masks.shape[1]))]
+                self.criterion.world_size = world
+                lk = self.criterion(student, TargetSet(tgt, cnt, ne), True, clip_coords(coords_kd, b, tgt.shape[1], off_kd), keep_ctx=inj_kd)
+                if inj_kd:
+                    off_kd = [o + k for o, k in zip(off_kd, kept_rows(tgt.shape[1]))]
+                self.criterion.last_ctx = None
+                nk = self.criterion.last_indices[2][-1:].to(torch.float32)          # matched pairs of the clip's final layer (KD pass)
+            keep.append((student, teacher, tgt, cnt, kept, ne))
+            parts.append((lg, lk, cnt, nk, float(min(Q, ns[b]))))
+        self.criterion.world_size = ws0
+        with torch.cuda.stream(crit):
+            # combine (tiny device ops, on the criteria's stream)
+            cnts = torch.stack([p_[2].reshape(()).to(torch.float32) for p_ in parts])
+            f_own = torch.clamp(cnts / world, min=1.0)
+            f_all = torch.clamp(cnts.sum() / world, min=1.0)
+            den_gt = [p_[4] + (Q - p_[4]) * eos for p_ in parts]         # host numbers: no upload (a pageable copy would block the host here)
+            den_gt = [d / sum(den_gt) for d in den_gt]
+            nk_all = torch.cat([p_[3] for p_ in parts])
+            den_kd = nk_all + (Q - nk_all) * eos
+            losses = {}
+            for k in parts[0][0]:
+                v = torch.stack([p_[0][k] for p_ in parts])
+                if k == "loss_ce":
+                    acc = parts[0][0][k] * den_gt[0]
+                    for b in range(1, B):
+                        acc = acc + parts[b][0][k] * den_gt[b]
+                    losses[k] = acc
+                else:
+                    losses[k] = v.sum()
+            for k in parts[0][1]:
+                v = torch.stack([p_[1][k] for p_ in parts])
+                losses[k.replace("loss_", "kd_loss_")] = (v * den_kd).sum() / den_kd.sum() if k == "loss_ce" else (v * f_own).sum() / f_all
+            wd = self.criterion.weight_dict
+            out = {k: v * wd[k] for k, v in losses.items() if k in wd}
+        main.wait_stream(crit); main.wait_stream(side)
+        self.last = dict(student=[k_[0] for k_ in keep], teacher=[k_[1] for k_ in keep], kd_count=torch.cat([k_[3].reshape(1) for k_ in keep]),
+                         kd_kept=[k_[4] for k_ in keep], pipeline=True)
         return out
 
     @torch.no_grad()

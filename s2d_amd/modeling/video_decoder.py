@@ -429,7 +429,6 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         NL = self.num_layers + 1
         dev = mf.device
         npix = T * hm * wm
-        mft = [Bk.transpose(mf[b]) for b in range(B)]                               # [C, npix] per clip
         d_mf_all = torch.empty((B, npix, C), device=dev, dtype=torch.float32)     # the clips' feature gradients, written in place by their GEMMs
         d_mf = [None] * B
         # every column block of a level's buffer is written by the walk below when each level serves the same number of layers
@@ -442,10 +441,14 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
 
         # d(mask features) does not depend on the layer walk: per clip and criterion pass, the gradient planes of ALL layers
         # are transposed side by side into one [npix, NL*maxm] matrix and contracted with the matching mask embeddings in one
-        # GEMM (instead of one read-modify-write pass over the 0.5 GB feature gradient per layer)
+        # GEMM (instead of one read-modify-write pass over the 0.5 GB feature gradient per layer).  The same matrix, contracted over the
+        # pixels with the clip's mask features, is d(mask embedding) of the matched queries of all layers: one TN GEMM per clip and
+        # pass (round 5; it was one long-K GEMM per layer, clip and pass, each re-reading the clip's 0.47 GB of features).
+        d_emb = []
         for rows, idx_q in mask_sources:
             maxm = rows.shape[2]
             mp = (maxm + 3) // 4 * 4
+            d_emb.append([])
             for b in range(B):
                 Dt = torch.zeros((npix, NL * mp), device=dev, dtype=torch.float32) if mp != maxm else \
                     torch.empty((npix, NL * mp), device=dev, dtype=torch.float32)
@@ -454,14 +457,15 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
                     lib().call("s2d_transpose_f32", rows[slot, b], maxm, npix, npix, Dt[:, slot * mp:], NL * mp, ops._stream())
                     et[:, slot * mp:slot * mp + maxm] = head_tape[slot][4][b][idx_q[slot * B + b].long()].t()
                 d_mf[b] = ops.gemm_nt(Dt, et, res=d_mf[b], out=d_mf_all[b])
+                d_emb[-1].append(Bk.weight_grad(Dt, mf[b]).view(NL, mp, mf.shape[-1]))      # sum_pix D[slot, m, pix] mf[pix, :]
 
         def heads_backward(rec):
             slot, output, d, mlp_acts, e = rec
             d_e = torch.zeros((B, Q, e.shape[-1]), device=dev, dtype=torch.float32)
-            for rows, idx_q in mask_sources:
+            for (rows, idx_q), de in zip(mask_sources, d_emb):
                 for b in range(B):
                     iq = idx_q[slot * B + b].long()
-                    d_e[b].index_add_(0, iq, Bk.contract(rows[slot, b], mft[b]))   # sum_pix D[q,pix] mf[pix,:]
+                    d_e[b].index_add_(0, iq, de[b][slot, :rows.shape[2]])
             d_d = self.mask_embed.backward(mlp_acts, d_e.view(B * Q, -1))
             if d_cls is not None:
                 dc = d_cls[slot].reshape(B * Q, -1).contiguous()

@@ -11,8 +11,9 @@ model = build_kd_model(num_queries=Q, num_frames=T, num_points=P).to(dev)
 frames, masks = bench.synth_batch(0, B, T, H0, W0, N, dev)
 gt = TargetSet.from_list(masks, device=dev)
 bench.calibrate_teacher(model, ops.normalize_pad(frames))
-for two in (False, True):
+for two, pipe in ((False, False), (True, False), (True, True)):
     model.overlap_teacher = model.overlap_criteria = two
+    model.pipeline_clips = pipe
     for _ in range(2):
         sum(model.forward_losses(ops.normalize_pad(frames), gt).values())
     torch.cuda.synchronize()
@@ -23,9 +24,9 @@ for two in (False, True):
         host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / 5
-    print(f"two_streams={two}: host enqueue {1e3 * sum(host) / 5:.1f} ms/step (min {1e3 * min(host):.1f}), wall {1e3 * wall:.1f} ms/step", flush=True)
+    print(f"two_streams={two} clip_pipeline={pipe}: host enqueue {1e3 * sum(host) / 5:.1f} ms/step (min {1e3 * min(host):.1f}), wall {1e3 * wall:.1f} ms/step", flush=True)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 tot = sum(model.forward_losses(ops.normalize_pad(frames), gt).values())
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)

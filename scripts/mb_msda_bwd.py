@@ -42,3 +42,14 @@ print(f"msda backward c4: sorted {ms_s:.2f} ms, atomics {ms_a:.2f} ms; max |diff
       ", ".join(f"{float((x - y).abs().max() / y.abs().max()):.2e}" for x, y in zip(a, b)))
 fwd = t(lambda: ops.msda_forward(value, shapes, lsi, loc, aw))
 print(f"msda forward (drop-in form) {fwd:.2f} ms")
+
+# the fused form the pixel decoder's backward calls (raw projection rows): the one-launch query half (round 5) vs loc kernel + chain
+from s2d_amd import backward as Bk
+oa = torch.cat([(torch.randn((N, S, M * L * P * 2), generator=g, device="cuda") * 3.0), torch.randn((N, S, M * L * P), generator=g, device="cuda")], -1).contiguous()
+v3 = value.view(N, S, M * D)
+for mode, waves in (("1", "4"), ("1", "8"), ("0", "4")):
+    os.environ["S2D_MSDA_BWD_WAVES"] = waves
+    Bk._MSDA_BWD_REC = mode != "0"
+    ms = t(lambda: Bk.msda_fused_backward(v3, shapes, oa, go))
+    print(f"fused backward, one-launch query half={mode != '0'} waves/SIMD={waves}: {ms:.2f} ms per call", flush=True)
+os.environ.pop("S2D_MSDA_BWD_WAVES"); Bk._MSDA_BWD_REC = True

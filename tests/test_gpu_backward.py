@@ -345,6 +345,20 @@ def test_msda_fused_backward_vs_autograd(shapes, N):
     dv, doa = backward.msda_fused_backward(v_h, shapes, o_h, go.to(DEV))
     assert rel(dv.cpu().numpy(), vd.grad.numpy()) < 1e-5
     assert rel(doa.cpu().numpy(), od.grad.numpy()) < 1e-5
+    # the one-launch query half (record form, round 5) against the two-step form (loc kernel + chain) it replaces, also through the
+    # strided slices of a merged projection buffer; and run-to-run bit equality
+    assert backward._MSDA_BWD_REC
+    both = torch.cat([o_h, v_h], -1).contiguous()
+    dv2, doa2, buf = backward.msda_fused_backward(both[..., 288:], shapes, both[..., :288], go.to(DEV), merged=True)
+    assert torch.equal(dv2, dv) and torch.equal(doa2, doa) and buf.shape[-1] == 288 + C
+    backward._MSDA_BWD_REC = False
+    try:
+        dv0, doa0 = backward.msda_fused_backward(v_h, shapes, o_h, go.to(DEV))
+    finally:
+        backward._MSDA_BWD_REC = True
+    assert torch.equal(dv0, dv)
+    assert rel(doa.cpu().numpy(), doa0.cpu().numpy()) < 2e-6
+    assert rel(doa0.cpu().numpy(), od.grad.numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])

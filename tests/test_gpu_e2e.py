@@ -228,3 +228,37 @@ def test_amp_conv_kernel_vs_fp16_rounded_reference():
         ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double().permute(0, 3, 1, 2), None, stride, pad)
         ref = torch.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
         np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=str((N, H, W, Cin, Cout, k, stride, pad)))
+
+
+def test_clip_pipeline_equals_the_batch_form_and_is_schedule_independent():
+    """KDVideoMaskFormer.pipeline_clips (round 5: clip b's criteria beside clip b + 1's forwards) against the batch form on the same injected points:
+    every one of the 42 losses to 1e-5 relative (the batch-wide normalisers -- num_masks of both passes, the class loss's weight sum -- are applied
+    when the clips are combined; only the order of the sums over clips differs), and its three-stream schedule bitwise equal to itself on one stream"""
+    import torch
+    from s2d_amd.modeling import TargetSet
+    from tests.parity import run_case
+    hip, _ = run_case(None, seed=6, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4))
+    model = hip["model"]
+    images, gts, cg = hip["inputs"]
+    ck = {k: torch.from_numpy(v).to(images.device) for k, v in hip["coords_kd"].items()}
+    model.keep_kd_targets = False
+    ts = lambda: TargetSet.from_list(gts, device=images.device)
+    Q = 16
+    model.pipeline_clips = False
+    model.overlap_teacher = model.overlap_criteria = False
+    ref = {k: float(v) for k, v in model.forward_losses(images, ts(), cg, ck, kd_nmax=Q).items()}
+    for k, v in ref.items():
+        assert v == hip["losses"][k], k                     # the batch form is what run_case ran
+    model.pipeline_clips = True
+    one = {k: float(v) for k, v in model.forward_losses(images, ts(), cg, ck, kd_nmax=Q).items()}
+    model.overlap_teacher = model.overlap_criteria = True
+    outs = []
+    for _ in range(4):
+        outs.append({k: float(v) for k, v in model.forward_losses(images, ts(), cg, ck, kd_nmax=Q).items()})
+    torch.cuda.synchronize()
+    model.pipeline_clips = False
+    model.overlap_teacher = model.overlap_criteria = False
+    assert sorted(one) == sorted(ref) and len(one) == 42
+    for k, v in ref.items():
+        np.testing.assert_allclose(one[k], v, rtol=1e-5, atol=1e-7, err_msg=k)
+    assert all(o == one for o in outs)
