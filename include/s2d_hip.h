@@ -435,6 +435,15 @@ int s2d_rle_strings_u8(const int *positions, const long *frame_off, int F, long 
 int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
                     long chunk, long slice_stride, float *colsum_slices, hipStream_t stream);
 
+/* Weight gradient of y = conv2d_nhwc(x [N][H][W][Cin], w [Cout][KH][KW][Cin], stride, pad), dy [N][Ho][Wo][Cout] (detectron2's Conv2d in the
+ * R50 trunk and the pixel decoder, e.g. mask2former/modeling/pixel_decoder/msdeformattn.py:289-303; the reference leaves it to autograd's
+ * convolution backward), on the TN kernel with the input pixel of every (output position, tap) addressed in place (pixels outside the image
+ * read as zero): no padded copy of x, no copy of dy on the input grid.  ONE launch for all taps: slice s of the positions (chunk each, a
+ * multiple of 32; S = ceil(N * Ho * Wo / chunk) <= 65535) leaves its partial gradients in part[s], laid out [Cout][KH][KW][Cin] like w;
+ * s2d_reduce_slices_f32(part, S, Cout*KH*KW*Cin, Cout*KH*KW*Cin, beta, dw) finishes them in a fixed order.  Cin, Cout % 4 == 0, Ho, Wo > 1. */
+int s2d_conv_wgrad_tn_f32(const float *dy, const float *x, int N, int H, int W, int Ci, int Ho, int Wo, int Co, int KH, int KW, int stride,
+                          int pad, long chunk, float *part, hipStream_t stream);
+
 /* out[c][r] = in[r][c]; in [R][ldi], out [C][ldo].  dW = dY^T . X runs as an NT GEMM on the transposed operands. */
 int s2d_transpose_f32(const float *in, long R, long C, long ldi, float *out, long ldo, hipStream_t stream);
 

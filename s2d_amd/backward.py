@@ -317,6 +317,9 @@ def linear_backward(x, w, dy, need_dx=True, has_bias=True):
 
 
 # --------------------------------------------------------------------------- convolutions (NHWC, weights [Cout,KH,KW,Cin])
+_CONV_WGRAD_IMPLICIT = os.environ.get("S2D_CONV_WGRAD_IMPLICIT", "1") != "0"      # 0: the round-4 form (padded copies, one launch per tap)
+
+
 def conv_input_grad(dy, w, stride, pad, in_hw, gate=None, scale=None):
     """dx [N,H,W,Cin] of y = conv2d_nhwc(x, w, stride, pad): a stride-1 convolution of dy (zero-dilated by `stride`) with
     the flipped, channel-transposed kernel and padding KH-1-pad -- the forward implicit-GEMM kernel again."""
@@ -359,6 +362,19 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
         col = torch.empty((N * Ho * Wo, KH * KW * Ci), device=x.device, dtype=torch.float32)
         lib().call("s2d_im2col_nhwc_f32", x, N, H, W, Ci, KH, KW, stride, pad, col, _st())
         return weight_grad(dy.view(-1, Co), col).view(Co, KH, KW, Ci)
+    P_out = N * Ho * Wo
+    if _CONV_WGRAD_IMPLICIT and Co % 4 == 0 and Ci % 4 == 0 and Ho > 1 and Wo > 1 and _tn_ok(P_out, Co, Ci) and N * H * W * Ci * 4 <= 0xFFFFFF00:
+        # every tap in ONE launch of the TN kernel, the input pixel of an (output position, tap) addressed in place: no padded copies,
+        # a strided convolution walks its own output positions only; the partial tiles arrive in the weight's layout
+        taps = KH * KW
+        S, chunk = _slices(P_out, taps * ((Co + 127) // 128) * ((Ci + 127) // 128 if Ci >= 128 else (Ci + 63) // 64))
+        part = torch.empty((S, Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
+        lib().call("s2d_conv_wgrad_tn_f32", dy, x, N, H, W, Ci, Ho, Wo, Co, KH, KW, stride, pad, chunk, part, _st())
+        if S == 1:
+            return part[0]
+        dw = torch.empty((Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
+        lib().call("s2d_reduce_slices_f32", part, S, Co * taps * Ci, Co * taps * Ci, 0.0, dw, _st())
+        return dw
     Hp, Wp = H + 2 * pad, (W + 2 * pad + 3) // 4 * 4                   # row length % 4: row shifts stay 16-B aligned
     xp = torch.zeros((N, Hp, Wp, Ci), device=x.device, dtype=torch.float32)
     xp[:, pad:pad + H, pad:pad + W] = x

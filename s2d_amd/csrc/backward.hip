@@ -101,10 +101,19 @@ __global__ __launch_bounds__(256) void colsum_slices_kernel(const float *__restr
 //   xhat = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),
 //   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy: each workgroup walks a fixed set of rows in a fixed order and
 //   leaves one partial row per quantity (part [nblocks][2][C]), finished by s2d_reduce_slices_f32 (reproducible).
-constexpr int LNB_ROWS = 64;       // rows per wavefront (a workgroup = 4 wavefronts = 256 rows)
+// Rows per wavefront (a workgroup = 4 wavefronts): 64 for the long tensors, fewer for short ones so that the rows spread over the
+// chip -- the video decoder's 200-row LayerNorms ran as ONE workgroup whose waves walked 64 rows one memory round trip at a time
+// (108 us per call, 37 calls per backward; round 5).  A function of `rows` alone: the partial sums' order stays fixed per shape.
+constexpr int LNB_ROWS = 64;
+static int lnb_rows_per_wave(long rows)
+{
+    int r = 1;
+    while (r < LNB_ROWS && (long)r * 2048 < rows) r *= 2;
+    return r;
+}
 __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                                  const float *__restrict__ dy, const float *__restrict__ gamma, long rows,
-                                                                 int C, float eps, float *__restrict__ dx, float *__restrict__ part)
+                                                                 int C, float eps, float *__restrict__ dx, float *__restrict__ part, int rpw)
 {
     __shared__ float red[4][2][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -116,8 +125,8 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float *__
         ga[k] = c4 < q ? *reinterpret_cast<const f32x4 *>(gamma + c4 * 4) : f32x4(0.f);
         dg[k] = f32x4(0.f); db[k] = f32x4(0.f);
     }
-    const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
-    for (long row = r0; row < r0 + LNB_ROWS && row < rows; ++row) {
+    const long r0 = ((long)blockIdx.x * 4 + wv) * rpw;
+    for (long row = r0; row < r0 + rpw && row < rows; ++row) {
         f32x4 v[4], d[4];
         float s = 0.f;
 #pragma unroll
@@ -180,15 +189,15 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float *__
 template <int RW>
 __global__ __launch_bounds__(256) void layernorm256_backward_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                                     const float *__restrict__ dy, const float *__restrict__ gamma, long rows,
-                                                                    float eps, float *__restrict__ dx, float *__restrict__ part)
+                                                                    float eps, float *__restrict__ dx, float *__restrict__ part, int rpw)
 {
-    constexpr int C = 256;
+    constexpr int C = 256;                                                    // rpw % RW == 0
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + lane * 4);
     f32x4 dg = f32x4(0.f), db = f32x4(0.f);
-    const long r0 = ((long)blockIdx.x * 4 + wv) * LNB_ROWS;
-    for (long rb = r0; rb < r0 + LNB_ROWS && rb < rows; rb += RW) {
+    const long r0 = ((long)blockIdx.x * 4 + wv) * rpw;
+    for (long rb = r0; rb < r0 + rpw && rb < rows; rb += RW) {
         f32x4 v[RW], d[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
@@ -458,19 +467,24 @@ int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, 
     return S2D_OK;
 }
 
-long s2d_layernorm_backward_blocks(long rows) { return (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS); }
+long s2d_layernorm_backward_blocks(long rows)
+{
+    const long per = 4L * lnb_rows_per_wave(rows);
+    return (rows + per - 1) / per;
+}
 
 int s2d_layernorm_backward_f32(const float *x, const float *res, const float *dy, const float *gamma, long rows, int C, float eps,
                                float *dx, float *part, hipStream_t stream)
 {
     if ((C & 3) || C > 1024 || rows < 0) return S2D_ERR_ARG;
     if (rows == 0) return S2D_OK;
-    if (C == 256 && rows >= 4096)
+    const int rpw = lnb_rows_per_wave(rows);
+    if (C == 256 && rpw >= 4)
         hipLaunchKernelGGL(layernorm256_backward_kernel<4>, dim3((unsigned int)s2d_layernorm_backward_blocks(rows)), dim3(256), 0, stream, x, res, dy,
-                           gamma, rows, eps, dx, part);
+                           gamma, rows, eps, dx, part, rpw);
     else
         hipLaunchKernelGGL(layernorm_backward_kernel, dim3((unsigned int)s2d_layernorm_backward_blocks(rows)), dim3(256), 0, stream, x, res, dy, gamma,
-                           rows, C, eps, dx, part);
+                           rows, C, eps, dx, part, rpw);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -308,7 +308,7 @@ extern "C" int s2d_split_weights_f16(const float *W, int N, int K, long ldw, voi
     return s2d_split_weights_launch(W, N, K, ldw, reinterpret_cast<unsigned int *>(out), stream, g_dense_mode == 1);
 }
 
-extern "C" int s2d_abi_version(void) { return 10; }
+extern "C" int s2d_abi_version(void) { return 11; }
 
 extern "C" int s2d_set_dense_mode(int mode)
 {

@@ -29,7 +29,19 @@ struct TnParams {
     long lda, ldb, chunk;
     long sC;                    // elements between the partial tiles of consecutive slices (>= Mo * No)
     float *colsum;              // optional [slices][Mo]: per-slice column sums of A (the bias gradient of the same dY), or NULL
+    // CONV form (s2d_conv_wgrad_tn_f32): A = dY [N * Ho * Wo][Co], B = X [N * H * W][Ci]; workgroup (tile, tap): row m = (n, yo, xo) of A meets
+    // row (n, yo * stride + ky - pad, xo * stride + kx - pad) of B, or zeros when that pixel lies outside the image
+    int taps, KW, stride, pad, H, W, Ho, Wo;
+    unsigned int mgWo, shWo, mgHo, shHo;   // round-up magic numbers of the divisions by Wo and Ho (exact for every 32-bit dividend)
+    long ldc;                   // CONV: elements between output rows of C (taps * No: the partial tile of a tap is a column block of [Mo][taps][No])
 };
+
+// q = m / d for the (magic, shift) pair magic_u32() makes of d
+__device__ __forceinline__ unsigned int div_magic(unsigned int m, unsigned int magic, unsigned int shift)
+{
+    const unsigned int t = __umulhi(m, magic);
+    return (t + ((m - t) >> 1)) >> shift;
+}
 
 // hi / lo fp16 pairs of two values that are consecutive along the contraction
 __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, unsigned int &lo)
@@ -44,7 +56,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
 // BNs = 128 (outputs at least 128 columns wide): a wave owns 64 x 64 of a 128 x 128 tile -- per 32 contraction rows 24 MFMAs against 8
 // loads, 16 splits and 32 LDS stores per thread, where the 128 x 64 tile has 12 MFMAs against 6 loads, 12 splits and 24 stores: the
 // transposing / splitting work per MFMA is what bounds this kernel, not the MFMAs.
-template <int BNs>
+template <int BNs, bool CONV = false>
 __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(TnParams p)
 {
     constexpr int BM = 128, NB = BNs / 64;                  // NB: 32-column MFMA tiles per wave along the output columns
@@ -54,7 +66,11 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l32 = lane & 31, h = lane >> 5;
     const int tiles_n = (p.No + BNs - 1) / BNs;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BNs;
+    // CONV: the taps of one tile are neighbours in the grid, so the A rows they all read and the B rows they share meet in L2
+    const int tap = CONV ? (int)(blockIdx.x % (unsigned int)p.taps) : 0;
+    const int tile = CONV ? (int)(blockIdx.x / (unsigned int)p.taps) : (int)blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BNs;
+    const int tap_dy = CONV ? tap / p.KW - p.pad : 0, tap_dx = CONV ? tap % p.KW - p.pad : 0;
     const long r_lo = (long)blockIdx.y * p.chunk;
     const long r_hi = r_lo + p.chunk < p.rowsA ? r_lo + p.chunk : p.rowsA;
     const int nk = (int)((r_hi - r_lo + TBK - 1) / TBK);
@@ -72,7 +88,7 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
     f32x4 va[4], vb[2 * NB];
     // column sums of A ride along in the workgroups of the first column tile: dY is in registers here anyway (a separate pass would
     // read it again: 1.27 GB for the encoder's linear1)
-    const bool do_cs = p.colsum != nullptr && (blockIdx.x % tiles_n) == 0;
+    const bool do_cs = !CONV && p.colsum != nullptr && (tile % tiles_n) == 0;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int kt) {
         const long r = r_lo + (long)kt * TBK;
@@ -85,13 +101,32 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
                 va[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i) {
+            if constexpr (CONV) {
+                // (n, yo, xo) of the pair's even row by two magic divisions, the odd row by carry
+                const unsigned int me = (unsigned int)(r + 2 * rb_ + 16 * i);
+                unsigned int ry = div_magic(me, p.mgWo, p.shWo);            // n * Ho + yo
+                int xo = (int)(me - ry * (unsigned int)p.Wo);
+                unsigned int nn = div_magic(ry, p.mgHo, p.shHo);
+                int yo = (int)(ry - nn * (unsigned int)p.Ho);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const long m = r + 2 * rb_ + t + 16 * i;
-                const unsigned int off = (unsigned int)((m * p.ldb + b_col) * 4L) | b_bad | (m < r_hi && m < p.rowsB ? 0u : TOOB);
-                vb[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
+                for (int t = 0; t < 2; ++t) {
+                    const int yi = yo * p.stride + tap_dy, xi = xo * p.stride + tap_dx;
+                    const bool ok = (long)me + t < r_hi && (unsigned int)yi < (unsigned int)p.H && (unsigned int)xi < (unsigned int)p.W;
+                    const unsigned int rowb = (nn * (unsigned int)p.H + (unsigned int)yi) * (unsigned int)p.W + (unsigned int)xi;
+                    const unsigned int off = ((rowb * (unsigned int)p.ldb + b_col) * 4u) | b_bad | (ok ? 0u : TOOB);
+                    vb[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
+                    if (++xo == p.Wo) { xo = 0; if (++yo == p.Ho) { yo = 0; ++nn; } }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const long m = r + 2 * rb_ + t + 16 * i;
+                    const unsigned int off = (unsigned int)((m * p.ldb + b_col) * 4L) | b_bad | (m < r_hi && m < p.rowsB ? 0u : TOOB);
+                    vb[2 * i + t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0));
+                }
             }
+        }
     };
     auto store_tile = [&]() {
         if (do_cs) cs += (va[0] + va[1]) + (va[2] + va[3]);          // rows past the slice read as zero
@@ -161,7 +196,8 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
             p.colsum[(long)blockIdx.y * p.Mo + m0 + tid] = t;
         }
     }
-    float *C = p.C + (long)blockIdx.y * p.sC;
+    float *C = p.C + (long)blockIdx.y * p.sC + (CONV ? (long)tap * p.No : 0L);
+    const long ldc = CONV ? p.ldc : (long)p.No;
     // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
     // (the permutation that spreads the transposing stores over the banks); undo it here
 #pragma unroll
@@ -175,7 +211,7 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int row = m0 + 4 * rr + 2 * wm + tm;
-                if (row < p.Mo) C[(long)row * p.No + col] = accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
+                if (row < p.Mo) C[(long)row * ldc + col] = accm[tm][tn][r] + accx[tm][tn][r] * (1.0f / 2048.0f);
             }
     }
 }
@@ -194,11 +230,55 @@ extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, 
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return S2D_ERR_ARG;
     const long S = (rowsA + chunk - 1) / chunk;
     if (S > 65535) return S2D_ERR_ARG;
-    TnParams p{A, B, C_slices, Mo, No, rowsA, rowsB, lda, ldb, chunk, slice_stride, colsum_slices};
+    TnParams p{};
+    p.A = A; p.B = B; p.C = C_slices; p.Mo = Mo; p.No = No; p.rowsA = rowsA; p.rowsB = rowsB; p.lda = lda; p.ldb = ldb; p.chunk = chunk;
+    p.sC = slice_stride; p.colsum = colsum_slices;
     static int wide = -1;                                   // S2D_TN_WIDE=0: the 128 x 64 tile for every shape (A/B runs)
     if (wide < 0) { const char *e = getenv("S2D_TN_WIDE"); wide = e ? atoi(e) : 1; }
     if (wide && No >= 128) hipLaunchKernelGGL(gemm_tn_f16x3_kernel<128>, dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_tn_f16x3_kernel<64>, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+// round-up magic number of an unsigned 32-bit division (Granlund & Montgomery): q = (t + ((m - t) >> 1)) >> shift, t = mulhi(m, magic)
+static void magic_u32(unsigned int d, unsigned int *magic, unsigned int *shift)
+{
+    unsigned int l = 0;
+    while ((1ull << l) < d) ++l;                              // ceil(log2 d)
+    *magic = (unsigned int)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+    *shift = l - 1;                                           // d >= 2 (the entry point rejects one-pixel outputs)
+}
+
+/* Weight gradient of y = conv2d_nhwc(x, w [Cout][KH][KW][Cin], stride, pad) (detectron2's Conv2d in the R50 trunk and the pixel decoder,
+ * e.g. mask2former/modeling/pixel_decoder/msdeformattn.py:289-303; autograd's conv weight gradient in the reference), in the TN kernel's
+ * arithmetic with the input pixel of every (output position, tap) addressed in place: no zero-padded copy of x, no copy of dY scattered
+ * onto the input grid (round 5; a stride-2 convolution walked four times its output positions that way).  One launch: workgroup = (output
+ * tile, tap, slice of the positions); slice s leaves its partial gradients in part[s] laid out [Cout][KH][KW][Cin];
+ * s2d_reduce_slices_f32(part, S, Cout*KH*KW*Cin, ...) finishes all taps.  chunk: positions per slice, a multiple of 32. */
+extern "C" int s2d_conv_wgrad_tn_f32(const float *dy, const float *x, int N, int H, int W, int Ci, int Ho, int Wo, int Co, int KH, int KW,
+                                     int stride, int pad, long chunk, float *part, hipStream_t stream)
+{
+    const long rowsA = (long)N * Ho * Wo, rowsB = (long)N * H * W;
+    if (N <= 0 || H <= 0 || W <= 0 || Ho <= 1 || Wo <= 1 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || chunk <= 0 || (chunk & 31) || (Co & 3) || (Ci & 3) ||
+        Co <= 0 || Ci <= 0)
+        return S2D_ERR_ARG;
+    if ((long)(Ho - 1) * stride + KH - pad > H + pad || (long)(Wo - 1) * stride + KW - pad > W + pad) return S2D_ERR_ARG;      // not the output size of this convolution
+    if (rowsA * Co * 4L > 0xFFFFFF00L || rowsB * Ci * 4L > 0xFFFFFF00L || rowsA >= (1L << 31)) return S2D_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) return S2D_ERR_ARG;
+    const long S = (rowsA + chunk - 1) / chunk;
+    const int taps = KH * KW;
+    if (S > 65535) return S2D_ERR_ARG;
+    TnParams p{};
+    p.A = dy; p.B = x; p.C = part; p.Mo = Co; p.No = Ci; p.rowsA = rowsA; p.rowsB = rowsB; p.lda = Co; p.ldb = Ci; p.chunk = chunk;
+    p.sC = (long)Co * taps * Ci; p.colsum = nullptr;
+    p.taps = taps; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.ldc = (long)taps * Ci;
+    magic_u32((unsigned int)Wo, &p.mgWo, &p.shWo);
+    magic_u32((unsigned int)Ho, &p.mgHo, &p.shHo);
+    const long tiles = (long)cdiv(Co, 128) * cdiv(Ci, Ci >= 128 ? 128 : 64);
+    if (tiles * taps > 0x7fffffffL) return S2D_ERR_ARG;
+    if (Ci >= 128) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<128, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_tn_f16x3_kernel<64, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

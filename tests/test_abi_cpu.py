@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_abi_version_and_workspace_queries(built):
     dll = ctypes.CDLL(built)
-    assert dll.s2d_abi_version() == 10
+    assert dll.s2d_abi_version() == 11
     dll.s2d_attn_workspace_floats.restype = ctypes.c_long
     assert dll.s2d_attn_workspace_floats(2, 8, 117760) == 2 * 8 * 32 * (32 * 128 + 256)
 

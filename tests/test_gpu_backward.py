@@ -153,7 +153,8 @@ def test_transpose_odd_shapes():
 
 
 @pytest.mark.parametrize("N,H,W,Ci,Co,KH,stride,pad", [(2, 23, 40, 64, 64, 3, 1, 1), (2, 24, 41, 128, 64, 3, 2, 1), (3, 16, 20, 256, 128, 1, 1, 0),
-                                                      (2, 17, 21, 64, 128, 1, 2, 0), (1, 46, 80, 256, 256, 3, 1, 1)])
+                                                      (2, 17, 21, 64, 128, 1, 2, 0), (1, 46, 80, 256, 256, 3, 1, 1), (2, 31, 27, 128, 256, 3, 2, 1),
+                                                      (1, 19, 33, 64, 192, 3, 1, 0), (3, 12, 50, 132, 68, 3, 1, 1)])
 def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
     from s2d_amd import backward, ops
     g = torch.Generator().manual_seed(N * H + W + Ci + Co + KH + stride)
@@ -174,9 +175,21 @@ def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
     assert rel(dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()) < 2e-6
     dw = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
     assert rel(dw.permute(0, 3, 1, 2).cpu().numpy(), wd.grad.numpy()) < 5e-6
+    if KH > 1:
+        # the one-launch form with in-place addressing (round 5, the default) against the padded-copy / per-tap form it replaces: the same
+        # products, summed over a different split of the positions; and run-to-run bit equality
+        assert backward._CONV_WGRAD_IMPLICIT
+        assert torch.equal(backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad), dw)
+        backward._CONV_WGRAD_IMPLICIT = False
+        try:
+            dw0 = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
+        finally:
+            backward._CONV_WGRAD_IMPLICIT = True
+        assert rel(dw.cpu().numpy(), dw0.cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("rows,C,with_res", [(1000, 256, True), (77, 256, False), (5000, 1024, True), (3, 8, False)])
+@pytest.mark.parametrize("rows,C,with_res", [(1000, 256, True), (77, 256, False), (5000, 1024, True), (3, 8, False), (200, 256, True),
+                                             (4097, 256, True), (8200, 256, False), (2049, 64, True), (140000, 256, False)])
 def test_layernorm_backward_vs_autograd(rows, C, with_res):
     from s2d_amd import backward
     g = torch.Generator().manual_seed(rows + C)
