@@ -162,9 +162,20 @@ def transpose(x, pad_to=None):
     return out
 
 
-def _slices(M, out_tiles):
-    """number of contraction slices: enough workgroups to fill 256 CUs twice, slices of at least 512 rows, multiple of 32"""
-    S = max(1, min((512 + out_tiles - 1) // out_tiles, M // 512 if M >= 512 else 1, 256))
+def _slices(M, out_tiles, slots=512):
+    """number of contraction slices and rows per slice (a multiple of 32, slices of at least 512 rows).  `slots`: workgroups of the kernel the
+    chip holds at once (256 CUs x 2 for the 128-wide TN tile, x 4 for the 64-wide one).  The launch has out_tiles * S workgroups of equal
+    length: S is taken near the count that fills the chip once, where out_tiles * S falls just BELOW a multiple of `slots` -- 36 tiles x 15
+    slices = 540 workgroups on 512 slots ran as one full round and one of 28 (the 3 x 3 convolutions' weight gradients, round 5)."""
+    smax = max(1, min(M // 512 if M >= 512 else 1, 512))
+    want = max(1, min((slots + out_tiles - 1) // out_tiles, smax))
+    best, best_eff = want, -1.0
+    for S in range(max(1, want - want // 4), min(smax, 2 * want + 2) + 1):       # a function of the shape alone: the order of the partial sums stays fixed
+        wg = S * out_tiles
+        eff = wg / float((wg + slots - 1) // slots * slots)
+        if eff > best_eff + 1e-9:
+            best, best_eff = S, eff
+    S = best
     chunk = ((M + S - 1) // S + 31) // 32 * 32
     S = (M + chunk - 1) // chunk
     return S, chunk
@@ -185,7 +196,7 @@ def weight_grad(dy, x, out=None, beta=0.0, bias_out=None, bias_beta=0.0):
     K = x.shape[1]
     assert x.shape[0] == M
     if N * K <= _TN_MAX_OUT and _tn_ok(M, N, K):                        # no transposed copies: the TN kernel
-        S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128 if K >= 128 else (K + 63) // 64))      # the TN kernel's tiles: 128 x 128 / 128 x 64
+        S, chunk = _slices(M, ((N + 127) // 128) * ((K + 127) // 128 if K >= 128 else (K + 63) // 64), 512 if K >= 128 else 1024)      # the TN kernel's tiles: 128 x 128 / 128 x 64
         part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
         bpart = torch.empty((S, N), device=dy.device, dtype=torch.float32) if bias_out is not None else None
         lib().call("s2d_gemm_tn_f32", dy, x, part, N, K, M, M, N, K, chunk, 0, bpart, _st())
@@ -367,7 +378,7 @@ def conv_weight_grad(dy, x, KH, KW, stride, pad):
         # every tap in ONE launch of the TN kernel, the input pixel of an (output position, tap) addressed in place: no padded copies,
         # a strided convolution walks its own output positions only; the partial tiles arrive in the weight's layout
         taps = KH * KW
-        S, chunk = _slices(P_out, taps * ((Co + 127) // 128) * ((Ci + 127) // 128 if Ci >= 128 else (Ci + 63) // 64))
+        S, chunk = _slices(P_out, taps * ((Co + 127) // 128) * ((Ci + 127) // 128 if Ci >= 128 else (Ci + 63) // 64), 512 if Ci >= 128 else 1024)
         part = torch.empty((S, Co, KH, KW, Ci), device=x.device, dtype=torch.float32)
         lib().call("s2d_conv_wgrad_tn_f32", dy, x, N, H, W, Ci, Ho, Wo, Co, KH, KW, stride, pad, chunk, part, _st())
         if S == 1:
