@@ -56,7 +56,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int &hi, u
 // BNs = 128 (outputs at least 128 columns wide): a wave owns 64 x 64 of a 128 x 128 tile -- per 32 contraction rows 24 MFMAs against 8
 // loads, 16 splits and 32 LDS stores per thread, where the 128 x 64 tile has 12 MFMAs against 6 loads, 12 splits and 24 stores: the
 // transposing / splitting work per MFMA is what bounds this kernel, not the MFMAs.
-template <int BNs, bool CONV = false>
+template <int BNs, bool CONV = false, bool MF16 = false>
 __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(TnParams p)
 {
     constexpr int BM = 128, NB = BNs / 64;                  // NB: 32-column MFMA tiles per wave along the output columns
@@ -149,18 +149,51 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
                 row[0] = hi; row[16] = lo;
             }
     };
+    // MF16: the same products on v_mfma_f32_16x16x32_f16 (one k-step of 32 per 16 x 16 tile instead of two of 16 per 32 x 32 tile: equal cycles
+    // per FLOP, but the chip holds a higher clock under that shape -- MI355X_MICROARCH.md, "clock under load", item 7)
     f32x16 accm[2][NB], accx[2][NB];
+    f32x4 acm[MF16 ? 4 : 1][MF16 ? 2 * NB : 1], acx[MF16 ? 4 : 1][MF16 ? 2 * NB : 1];
+    if constexpr (MF16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
+            for (int t = 0; t < 2 * NB; ++t) { acm[i][t] = f32x4(0.f); acx[i][t] = f32x4(0.f); }
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[i][t][r] = 0.f; accx[i][t][r] = 0.f; }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accm[i][t][r] = 0.f; accx[i][t][r] = 0.f; }
+    }
+    const int l16 = lane & 15, kq = lane >> 4;
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
         store_tile();
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        if constexpr (MF16) {
+            // lane (row l16, k quarter kq) of a 16-row tile reads 8 consecutive k: words 4 kq .. 4 kq + 3 of the row's hi half, + 16 for lo
+            const unsigned int *as = &As[(wm * 64 + l16) * TROWW + 4 * kq];
+            const unsigned int *bs = &Bs[(wn * 32 * NB + l16) * TROWW + 4 * kq];
+            f16x8 bh[2 * NB], bl[2 * NB];
+#pragma unroll
+            for (int t = 0; t < 2 * NB; ++t) {
+                bh[t] = *reinterpret_cast<const f16x8 *>(bs + t * 16 * TROWW);
+                bl[t] = *reinterpret_cast<const f16x8 *>(bs + t * 16 * TROWW + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(as + i * 16 * TROWW);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(as + i * 16 * TROWW + 16);
+#pragma unroll
+                for (int t = 0; t < 2 * NB; ++t) {
+                    acx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t], acx[i][t], 0, 0, 0);
+                    acx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t], acx[i][t], 0, 0, 0);
+                    acm[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t], acm[i][t], 0, 0, 0);
+                }
+            }
+        } else {
         const unsigned int *as = &As[(wm * 64 + l32) * TROWW + 4 * h];
         const unsigned int *bs = &Bs[(wn * 32 * NB + l32) * TROWW + 4 * h];
 #pragma unroll
@@ -183,6 +216,7 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
                 }
             }
         }
+        }
         __syncthreads();
     }
     if (do_cs) {                                             // the 8 threads that share 4 columns, added in a fixed order (As is free: the loop ended on a barrier)
@@ -200,6 +234,24 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
     const long ldc = CONV ? p.ldc : (long)p.No;
     // LDS row r of the A image holds output row 4 (r % 32) + r / 32, LDS row c of the B image output column 4 (c % 16) + c / 16
     // (the permutation that spreads the transposing stores over the banks); undo it here
+    if constexpr (MF16) {
+        // 16 x 16 tile (i, t) of the wave: D[row 4 kq + r][col l16]; A-image LDS row ra = 64 wm + 16 i + 4 kq + r, B-image LDS row cb = 32 NB wn + 16 t + l16
+#pragma unroll
+        for (int t = 0; t < 2 * NB; ++t) {
+            const int cb = 32 * NB * wn + 16 * t + l16;
+            const int col = BNs == 128 ? n0 + 4 * (cb & 31) + (cb >> 5) : n0 + 4 * (cb & 15) + (cb >> 4);
+            if (col >= p.No) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ra = 64 * wm + 16 * i + 4 * kq + r;
+                    const int row = m0 + 4 * (ra & 31) + (ra >> 5);
+                    if (row < p.Mo) C[(long)row * ldc + col] = acm[i][t][r] + acx[i][t][r] * (1.0f / 2048.0f);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < NB; ++tn) {
         // BNs = 128: LDS row c = 64 wn + 32 tn + l32 of the B image <-> output column 4 (c % 32) + c / 32
@@ -218,6 +270,13 @@ __global__ __launch_bounds__(256, BNs == 128 ? 2 : 4) void gemm_tn_f16x3_kernel(
 
 }  // namespace
 
+// S2D_TN_MFMA16 (read per call; A/B runs in one process): 1 = the 16x16x32 form of the matrix instructions, 0 = 32x32x16
+static bool tn_mfma16()
+{
+    const char *e = getenv("S2D_TN_MFMA16");
+    return e ? atoi(e) != 0 : false;
+}
+
 extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, int Mo, int No, long rowsA, long rowsB, long lda, long ldb,
                                long chunk, long slice_stride, float *colsum_slices, hipStream_t stream)
 {
@@ -235,8 +294,14 @@ extern "C" int s2d_gemm_tn_f32(const float *A, const float *B, float *C_slices, 
     p.sC = slice_stride; p.colsum = colsum_slices;
     static int wide = -1;                                   // S2D_TN_WIDE=0: the 128 x 64 tile for every shape (A/B runs)
     if (wide < 0) { const char *e = getenv("S2D_TN_WIDE"); wide = e ? atoi(e) : 1; }
-    if (wide && No >= 128) hipLaunchKernelGGL(gemm_tn_f16x3_kernel<128>, dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_tn_f16x3_kernel<64>, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+    const bool mf16 = tn_mfma16();
+    if (wide && No >= 128) {
+        if (mf16) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<128, false, true>), dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(gemm_tn_f16x3_kernel<128>, dim3(cdiv(Mo, 128) * cdiv(No, 128), (int)S), dim3(256), 0, stream, p);
+    } else {
+        if (mf16) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<64, false, true>), dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(gemm_tn_f16x3_kernel<64>, dim3(cdiv(Mo, 128) * cdiv(No, 64), (int)S), dim3(256), 0, stream, p);
+    }
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }
@@ -277,8 +342,14 @@ extern "C" int s2d_conv_wgrad_tn_f32(const float *dy, const float *x, int N, int
     magic_u32((unsigned int)Ho, &p.mgHo, &p.shHo);
     const long tiles = (long)cdiv(Co, 128) * cdiv(Ci, Ci >= 128 ? 128 : 64);
     if (tiles * taps > 0x7fffffffL) return S2D_ERR_ARG;
-    if (Ci >= 128) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<128, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_tn_f16x3_kernel<64, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+    const bool mf16 = tn_mfma16();
+    if (Ci >= 128) {
+        if (mf16) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<128, true, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_tn_f16x3_kernel<128, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+    } else {
+        if (mf16) hipLaunchKernelGGL((gemm_tn_f16x3_kernel<64, true, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_tn_f16x3_kernel<64, true>), dim3((unsigned int)(tiles * taps), (int)S), dim3(256), 0, stream, p);
+    }
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

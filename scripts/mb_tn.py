@@ -22,7 +22,10 @@ for (M, N, K) in [(309120, 1024, 256), (309120, 256, 1024), (309120, 544, 256), 
     w = torch.nn.Parameter(torch.randn((N, K), device=dev) / K ** 0.5, requires_grad=False)
     fl = 2.0 * M * N * K / 1e12
     a, b = t(lambda: ops.gemm_nt(x, w)), t(lambda: B.weight_grad(dy, x))
-    print(f"{name}: forward {a:.3f} ms ({fl / a * 1e3:.0f} TFLOP/s) | wgrad {b:.3f} ms ({fl / b * 1e3:.0f} TFLOP/s)", flush=True)
+    os.environ["S2D_TN_MFMA16"] = "0" if os.environ.get("S2D_TN_MFMA16", "0") == "1" else "1"
+    c = t(lambda: B.weight_grad(dy, x)); other = os.environ["S2D_TN_MFMA16"]
+    os.environ["S2D_TN_MFMA16"] = "0" if other == "1" else "1"
+    print(f"{name}: forward {a:.3f} ms ({fl / a * 1e3:.0f} TFLOP/s) | wgrad {b:.3f} ms ({fl / b * 1e3:.0f} TFLOP/s) | wgrad with S2D_TN_MFMA16={other}: {c:.3f} ms", flush=True)
     del x, dy
 for (N_, H, W, Ci, Co, s) in [(16, 184, 320, 256, 256, 1), (16, 184, 320, 64, 64, 1), (16, 92, 160, 128, 128, 1), (16, 46, 80, 256, 256, 1),
                               (16, 23, 40, 512, 512, 1), (16, 184, 320, 128, 128, 2), (16, 92, 160, 256, 256, 2)]:
@@ -34,5 +37,8 @@ for (N_, H, W, Ci, Co, s) in [(16, 184, 320, 256, 256, 1), (16, 184, 320, 64, 64
     dy = torch.randn_like(y)
     fl = 2.0 * y.numel() * Ci * 9 / 1e12
     a, b = t(lambda: ops.conv2d_nhwc(x, w, stride=s, pad=1)), t(lambda: B.conv_weight_grad(dy, x, 3, 3, s, 1))
-    print(f"{name}: forward {a:.3f} ms ({fl / a * 1e3:.0f} TFLOP/s) | wgrad {b:.3f} ms ({fl / b * 1e3:.0f} TFLOP/s)", flush=True)
+    os.environ["S2D_TN_MFMA16"] = "0" if os.environ.get("S2D_TN_MFMA16", "0") == "1" else "1"
+    c = t(lambda: B.conv_weight_grad(dy, x, 3, 3, s, 1)); other = os.environ["S2D_TN_MFMA16"]
+    os.environ["S2D_TN_MFMA16"] = "0" if other == "1" else "1"
+    print(f"{name}: forward {a:.3f} ms ({fl / a * 1e3:.0f} TFLOP/s) | wgrad {b:.3f} ms ({fl / b * 1e3:.0f} TFLOP/s) | wgrad with S2D_TN_MFMA16={other}: {c:.3f} ms", flush=True)
     del x, y, dy

@@ -186,6 +186,16 @@ def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
         finally:
             backward._CONV_WGRAD_IMPLICIT = True
         assert rel(dw.cpu().numpy(), dw0.cpu().numpy()) < 2e-6
+        # the opt-in 16x16x32 form of the TN kernel's matrix instructions (S2D_TN_MFMA16=1, read per call): same products, other tile shape
+        import os
+        os.environ["S2D_TN_MFMA16"] = "1"
+        try:
+            dw16 = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
+            dl16 = backward.weight_grad(dy_h.view(-1, Co), dy_h.view(-1, Co))
+        finally:
+            os.environ.pop("S2D_TN_MFMA16")
+        assert rel(dw16.cpu().numpy(), dw.cpu().numpy()) < 2e-6
+        assert rel(dl16.cpu().numpy(), backward.weight_grad(dy_h.view(-1, Co), dy_h.view(-1, Co)).cpu().numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("rows,C,with_res", [(1000, 256, True), (77, 256, False), (5000, 1024, True), (3, 8, False), (200, 256, True),
