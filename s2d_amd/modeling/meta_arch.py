@@ -346,12 +346,9 @@ class KDVideoMaskFormer(nn.Module):
                     out[k] = torch.stack([v[l, off[l]:off[l] + rows] for l in range(v.shape[0])]).contiguous()
             return out
 
-        def kept_rows(nmax):
+        def kept_rows():
             """rows the criterion call just made kept, per layer (tests with injected points only: one small read back)"""
-            ws = self.criterion.last_ctx["point_loss"][-1].view(torch.int32)
-            NL = self.criterion.last_indices[2].shape[0]                  # B = 1 in a clip's call
-            rows = NL * min(Q, nmax) * T
-            return ws[rows * 6:rows * 6 + NL].cpu().tolist()
+            return ops.point_loss_kept_rows(self.criterion.last_ctx["point_loss"])[0]
 
         inj_gt, inj_kd = coords_gt is not None, coords_kd is not None
         off_gt = off_kd = None
@@ -359,34 +356,36 @@ class KDVideoMaskFormer(nn.Module):
         n_tot = float(sum(ns))
         crit.wait_stream(main)            # everything enqueued before this call (the third stream's pool memory included) is ordered
         keep, parts = [], []
-        for b in range(B):
-            img = images[b * T:(b + 1) * T]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                teacher = self.teacher(img, True, aux_masks=self.teacher_aux_masks)
-                tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
-                                                    self.score_threshold_distillation, self.num_predictions_distillation)
-                if self.distillation_nms:
-                    tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
-            student = self.student(img, True)
-            crit.wait_stream(main); crit.wait_stream(side)
-            gt_b = TargetSet(gt_targets.masks[b:b + 1], gt_targets.count[b:b + 1], gt_targets.nonempty[b:b + 1], [ns[b]])
-            with torch.cuda.stream(crit):
-                NLp = student.class_logits.shape[0]
-                off_gt, off_kd = off_gt or [0] * NLp, off_kd or [0] * NLp
-                self.criterion.world_size = world * (ns[b] / n_tot) if (ns[b] > 0 and n_tot > 0) else world
-                lg = self.criterion(student, gt_b, False, clip_coords(coords_gt, b, gt_targets.masks.shape[1], off_gt), keep_ctx=inj_gt)
-                if inj_gt:
-                    off_gt = [o + k for o, k in zip(off_gt, kept_rows(gt_targets.masks.shape[1]))]
-                self.criterion.world_size = world
-                lk = self.criterion(student, TargetSet(tgt, cnt, ne), True, clip_coords(coords_kd, b, tgt.shape[1], off_kd), keep_ctx=inj_kd)
-                if inj_kd:
-                    off_kd = [o + k for o, k in zip(off_kd, kept_rows(tgt.shape[1]))]
-                self.criterion.last_ctx = None
-                nk = self.criterion.last_indices[2][-1:].to(torch.float32)          # matched pairs of the clip's final layer (KD pass)
-            keep.append((student, teacher, tgt, cnt, kept, ne))
-            parts.append((lg, lk, cnt, nk, float(min(Q, ns[b]))))
-        self.criterion.world_size = ws0
+        try:                                  # the GT pass borrows the criterion's world size for its batch-wide normaliser
+            for b in range(B):
+                img = images[b * T:(b + 1) * T]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    teacher = self.teacher(img, True, aux_masks=self.teacher_aux_masks)
+                    tgt, cnt, kept, ne = ops.kd_targets(teacher.class_logits[-1], teacher.mask_logits[-1], teacher.dims, Hp, Wp, kd_nmax,
+                                                        self.score_threshold_distillation, self.num_predictions_distillation)
+                    if self.distillation_nms:
+                        tgt, cnt, ne = self._kd_nms(tgt, cnt, ne, kept)
+                student = self.student(img, True)
+                crit.wait_stream(main); crit.wait_stream(side)
+                gt_b = TargetSet(gt_targets.masks[b:b + 1], gt_targets.count[b:b + 1], gt_targets.nonempty[b:b + 1], [ns[b]])
+                with torch.cuda.stream(crit):
+                    NLp = student.class_logits.shape[0]
+                    off_gt, off_kd = off_gt or [0] * NLp, off_kd or [0] * NLp
+                    self.criterion.world_size = world * (ns[b] / n_tot) if (ns[b] > 0 and n_tot > 0) else world
+                    lg = self.criterion(student, gt_b, False, clip_coords(coords_gt, b, gt_targets.masks.shape[1], off_gt), keep_ctx=inj_gt)
+                    if inj_gt:
+                        off_gt = [o + k for o, k in zip(off_gt, kept_rows())]
+                    self.criterion.world_size = world
+                    lk = self.criterion(student, TargetSet(tgt, cnt, ne), True, clip_coords(coords_kd, b, tgt.shape[1], off_kd), keep_ctx=inj_kd)
+                    if inj_kd:
+                        off_kd = [o + k for o, k in zip(off_kd, kept_rows())]
+                    self.criterion.last_ctx = None
+                    nk = self.criterion.last_indices[2][-1:].to(torch.float32)          # matched pairs of the clip's final layer (KD pass)
+                keep.append((student, teacher, tgt, cnt, kept, ne))
+                parts.append((lg, lk, cnt, nk, float(min(Q, ns[b]))))
+        finally:
+            self.criterion.world_size = ws0
         with torch.cuda.stream(crit):
             # combine (tiny device ops, on the criteria's stream)
             cnts = torch.stack([p_[2].reshape(()).to(torch.float32) for p_ in parts])

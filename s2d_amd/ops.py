@@ -710,6 +710,15 @@ def point_loss(mask_logits, tgt, tgt_count, nonempty, idx_q, idx_t, n_match, dim
     return (losses, args) if keep else losses
 
 
+def point_loss_kept_rows(ctx):
+    """rows the forward kept, from the context of point_loss(keep=True): ([NL] per layer, total).  The counts sit in the forward's workspace
+    (lcount[NL + 1], after six int32 arrays of `rows` entries, csrc/loss.hip loss_setup): a small read back, synchronising."""
+    NL, B, Q, T, Nmax = ctx[10], ctx[11], ctx[12], ctx[14], ctx[19]
+    rows = NL * B * min(Q, Nmax) * T
+    c = ctx[-1].view(torch.int32)[rows * 6:rows * 6 + NL + 1].cpu().tolist()
+    return c[:NL], c[NL]
+
+
 def point_loss_backward(ctx, w_mask, w_dice):
     """ctx from point_loss(keep=True) -> grad rows [NL*B*maxm*T, hm*wm]: d(w_mask*loss_mask + w_dice*loss_dice, summed over
     layers) / d(the matched query's logit map of that (layer, clip, slot, frame))"""
@@ -717,7 +726,7 @@ def point_loss_backward(ctx, w_mask, w_dice):
     rows = NL * B * min(Q, Nmax) * T
     # the backward walks the rows whose point samples the forward kept (the first min(rows, 4096) ACTIVE rows); the number of
     # active rows sits in the forward's workspace (lcount[NL], after six int32 arrays of `rows` entries): one 4-byte read back
-    active = int(ctx[-1].view(torch.int32)[rows * 6 + NL])
+    active = point_loss_kept_rows(ctx)[1]
     if active > min(rows, 4096):
         raise NotImplementedError(f"{active} matched (layer, target, frame) rows in one criterion pass: the gradient path keeps 4096")
     g = torch.empty((rows, hm * wm), device=ctx[0].device, dtype=torch.float32)
