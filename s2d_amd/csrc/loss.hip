@@ -263,6 +263,18 @@ struct LossParams {
     int xcap;
     int *pbound;              // [rows][PB_STRIDE]: RNG mode, first oversampled-point index of every map part of the row (strata)
 };
+
+// The row a point stream is keyed by: (layer, clip, slot, frame) with the slot stride fixed at Q instead of maxm = min(Q, Nmax), so that the points
+// of a matched (pair, frame) do not depend on how far the target planes are padded (the training iteration hands the KD pass planes cut to the
+// number of pseudo targets it found; forward + loss alone pads them to Q).  NL == 0: the test hook s2d_point_loss_rng_points, whose rows ARE keys.
+__device__ __forceinline__ uint64_t key_row(const LossParams &p, long rowid)
+{
+    if (p.NL == 0) return (uint64_t)rowid;
+    const long per = (long)p.maxm * p.T;
+    const long lb = rowid / per;
+    return (uint64_t)(lb * ((long)p.Q * p.T) + (rowid - lb * per));
+}
+
 constexpr int PB_STRIDE = 9;  // LOSS_CHUNKS + 1
 struct VRange {
     float v0, dv;             // v band of one map part: v = v0 + dv * r, r uniform in [0, 1)
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(256) void row_strata_kernel(LossParams p, int npart
             const double pj = (yb - ya) / (double)p.hm;
             int nj = rem;
             if (j < nparts - 1) {
-                const uint64_t h = mix64(p.seed ^ mix64(((uint64_t)rowid * 16u + (uint64_t)j) * 0xD1342543DE82EF95ull + 0x5851F42D4C957F2Dull));
+                const uint64_t h = mix64(p.seed ^ mix64((key_row(p, rowid) * 16u + (uint64_t)j) * 0xD1342543DE82EF95ull + 0x5851F42D4C957F2Dull));
                 const double U = (double)(h >> 11) * (1.0 / 9007199254740992.0);      // 53-bit uniform in [0, 1)
                 const double pc = pj / mass;
                 nj = binomial_inv(rem, pc < 1.0 ? pc : 1.0, U);
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
         else stage_part(p.mq + rowid * p.hm * p.wm, p.wm, r0, nr, sm);
         __syncthreads();
         const unsigned int pre = LEVEL > 0 ? p.prefix[rowid] : 0u;
-        const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
+        const uint32_t key0 = rand_key(p.seed, key_row(p, rowid) * 2);
         // this part owns points with y0 in [r0, r0 + rows_per_part); y0 = -1 belongs to part 0
         const int ylo = part == 0 ? -1 : r0, yhi = r0 + g.rows_per_part;
         auto tally = [&](int i, float xv) {
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(LTHREADS) void hist_kernel(LossParams p)
             // the extra uniform points (point_features.py:112): sample their logits now too, so that the later passes
             // of this row never touch the logit map again
             const float *cr2 = coord_rows(p, rowid, false);
-            const uint32_t key1 = rand_key(p.seed, (uint64_t)rowid * 2 + 1);
+            const uint32_t key1 = rand_key(p.seed, key_row(p, rowid) * 2 + 1);
             for (int i = threadIdx.x; i < p.n_rand; i += LTHREADS) {
                 float u, v;
                 if (cr2) { u = cr2[2 * i]; v = cr2[2 * i + 1]; }
@@ -861,7 +873,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_kernel(LossParams p)
         for (int pass = 0; pass < 2; ++pass) {          // pass 0: the 3P oversampled points, pass 1: the extra uniform points
             const bool over = pass == 0;
             const float *cr = coord_rows(p, rowid, over);
-            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
+            const uint32_t key0 = rand_key(p.seed, key_row(p, rowid) * 2 + (over ? 0 : 1));
             // RNG mode, oversampled points: this part's own index range of the row (stratified generation), else every point + test
             const bool strat = over && !cr;
             const int *pb = p.pbound + rowid * PB_STRIDE;
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         for (int pass = 0; pass < 2; ++pass) {
             const bool over = pass == 0;
             const float *cr = coord_rows(p, rowid, over);
-            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2 + (over ? 0 : 1));
+            const uint32_t key0 = rand_key(p.seed, key_row(p, rowid) * 2 + (over ? 0 : 1));
             const int cnt = over ? p.n_over : p.n_rand;
             const float *xs = xb + (over ? 0 : p.n_over);
             const bool walk_range = BWD && over && ranged;    // only the part's own index range; its points need no ownership test
@@ -1221,7 +1233,7 @@ __global__ __launch_bounds__(LTHREADS) void accumulate_stream_kernel(LossParams 
         if (ranged_ties && threadIdx.x == 0) tie_before = before + nties;
         if (nties > 0u && take > before) {                    // uniform over the workgroup
             const float *cr = coord_rows(p, rowid, true);
-            const uint32_t key0 = rand_key(p.seed, (uint64_t)rowid * 2);
+            const uint32_t key0 = rand_key(p.seed, key_row(p, rowid) * 2);
             auto tie_point = [&](int i) {
                 float u, v;
                 if (cr) { u = cr[2 * i]; v = cr[2 * i + 1]; }

@@ -188,6 +188,7 @@ class KDVideoMaskFormer(nn.Module):
         # clip: clip b's criteria run on a third stream beside clip b + 1's forwards.  Same arithmetic per clip; the batch-wide normalisers
         # (num_masks, the class loss's weight sum) are applied when the clips' losses are combined.  Off by default (the batch form is what the
         # parity tests with injected points drive); bench.py turns it on for the timed schedules.
+        self.kd_compact = True           # forward_backward: pseudo-target planes cut to the count found (one small read-back)
         self.pipeline_clips = False
         self._crit_stream = None
         # The teacher's intermediate mask predictions feed only its own attention masks (no loss reads them): by default
@@ -447,6 +448,16 @@ class KDVideoMaskFormer(nn.Module):
         feats = backbone(images, tb)
         mf, ms = head.pixel_decoder.forward_features(feats, tp)
         student = head.predictor(ms, mf, True, True, td)
+        if self.kd_compact and coords_kd is None:
+            # The backward's buffers scale with the number of target SLOTS (gradient planes, their transposes, the contraction length of the
+            # mask-feature / mask-embedding GEMMs): with Q = 100 slots and ~10 pseudo targets nine tenths of them are zero rows.  One 4-byte
+            # read-back on the side stream, behind the student's launches (the host is ahead of the device here; the reference synchronises
+            # at the same place: topk + boolean indexing, kd_video_maskformer_model.py:452-470), cuts the planes to the targets found.
+            # The sampled points do not depend on the padding (csrc/loss.hip key_row): the losses are those of the uncut pass, bit for bit.
+            with torch.cuda.stream(side):
+                m4 = max(4, (int(cnt.max()) + 3) // 4 * 4)
+                if m4 < tgt.shape[1]:
+                    tgt, ne = tgt[:, :m4].contiguous(), ne[:, :m4].contiguous()
         # overlap_criteria (with overlap_teacher): the GT criterion and the backward of its point loss run on the side stream beside
         # the KD criterion's, as in forward_losses -- same host order of the calls, so the same seeds
         crit_side = side if (self.overlap_teacher and self.overlap_criteria) else main

@@ -883,3 +883,40 @@ def test_run_step_trains_both_meta_archs():
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, vm.parameters()))
     engine.run_step(vm, opt2, data, 1)                                   # steps
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, vm.parameters()))
+
+
+def test_training_iteration_with_compact_kd_targets_equals_the_padded_one():
+    """KDVideoMaskFormer.kd_compact (round 5): forward_backward cuts the pseudo-target planes to the number of targets the teacher produced (one
+    small read-back) instead of carrying Q slots through the backward.  The sampled points are keyed by (layer, clip, slot, frame) with a fixed
+    slot stride (csrc/loss.hip key_row), so they do not depend on the padding: all 42 losses are those of the padded iteration BIT FOR BIT
+    every gradient agrees to the summation order of two contractions whose zero rows left."""
+    from s2d_amd import ops
+    from s2d_amd.modeling import TargetSet
+    from tests.parity import run_case
+    hip, _ = run_case(None, seed=9, B=2, T=2, H0=60, W0=90, Q=16, P=256, ns=(3, 4), kd_want=3)
+    model = hip["model"]
+    images, gts, _ = hip["inputs"]
+    assert 0 < max(hip["kd_counts"]) < 12                   # a few pseudo targets per clip, fewer than the 16 slots
+    params = [p for p in model.student.parameters()]
+    model.keep_kd_targets = False
+    model.overlap_teacher = model.overlap_criteria = False
+
+    def once(compact, fn):
+        for p in params:
+            p.grad = None
+        model.kd_compact = compact
+        model.criterion.seed = 0; model.criterion.matcher.seed = 0
+        torch.manual_seed(11); ops._DROP_CALLS[0] = 0
+        out = fn(images, TargetSet.from_list(gts, device=images.device))
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in out.items()}, [None if p.grad is None else p.grad.clone() for p in params]
+
+    la, ga = once(True, model.forward_backward)
+    lb, gb = once(False, model.forward_backward)
+    model.last_tapes = None
+    assert len(la) == 42 and la == lb
+    assert any(float(la[k]) != 0.0 for k in la if k.startswith("kd_loss_mask"))
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12

@@ -391,3 +391,32 @@ def test_rng_mode_points_are_iid_uniform_in_law():
             assert len(set(counts)) > 1                       # the split is random per row, not the expectation rounded
             assert abs(np.corrcoef(np.sort(uvh[0, :, 0]), np.sort(uvh[1, :, 0]))[0, 1]) > 0.999   # same law ...
             assert not np.array_equal(uvh[0], uvh[1])         # ... different draws
+
+
+def test_rng_mode_point_loss_does_not_depend_on_target_padding():
+    """the sampled points of a matched (pair, frame) are keyed by (layer, clip, slot, frame) with the slot stride fixed at Q (csrc/loss.hip
+    key_row), not at min(Q, Nmax): the same targets in planes padded to 3, 8 and Q slots give the same losses bit for bit in generator mode"""
+    from s2d_amd import ops
+    B, Q, T, H, W, P = 2, 16, 2, 64, 96, 512
+    h, w = H // 4, W // 4
+    ns = [3, 2]
+    seed = 4711
+    masks = synth.smooth_logits(seed, 2, (B, Q, T), (h, w))
+    tg = make_targets(seed, 100, ns, T, H, W)
+    ml = _dev(np.stack([pixel_major(masks), pixel_major((masks * 0.5).astype(np.float32))]))      # two layers
+    rng = np.random.default_rng(seed)
+    pairs = [(np.sort(rng.choice(Q, ns[b], replace=False)), rng.permutation(ns[b])) for b in range(B)]
+    out = []
+    for Nmax in (3, 8, Q):
+        tgt, cnt = pad_targets(tg, Nmax, T, H, W)
+        maxm = min(Q, Nmax)
+        iq = np.zeros((2 * B, maxm), np.int32); it = np.zeros((2 * B, maxm), np.int32); nm = np.array(ns * 2, np.int32)
+        for l in range(2):
+            for b in range(B):
+                iq[l * B + b, :ns[b]], it[l * B + b, :ns[b]] = pairs[b]
+        tgt_d, cnt_d = _dev(tgt), _dev(cnt)
+        ne = ops.target_nonempty(tgt_d, cnt_d)
+        L = ops.point_loss(ml, tgt_d, cnt_d, ne, _dev(iq), _dev(it), _dev(nm), (Q, T, h, w), P, seed=99)
+        out.append(L.cpu().numpy())
+    assert np.isfinite(out[0]).all() and (out[0] > 0).all()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
