@@ -305,6 +305,13 @@ long s2d_attn_backward_workspace_floats(int B, int H, int K);
 int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
                                  const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q,
                                  int K, int C, int H, float *workspace, float *dq, float *dk, float *dv, hipStream_t stream);
+/* The same with row strides on dk / dv (lddk, lddv >= C, multiples of 4, 16-B aligned bases): the gradients land in column slices of a wider
+ * buffer -- the video decoder collects the key / value gradients of the three layers that share a memory level side by side for ONE
+ * projection backward (video_mask2former_transformer_decoder.py:99-111 x 9 layers), without a copy per layer. */
+int s2d_masked_attn_backward_strided_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                                         const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q,
+                                         int K, int C, int H, float *workspace, float *dq, float *dk, long lddk, float *dv, long lddv,
+                                         hipStream_t stream);
 
 /* ---- VideoHungarianMatcher on the device -------------------------------------------------------------- */
 /* A criterion pass handles NL prediction layers x B clips = NL*B independent "problems" (problem = layer*B +

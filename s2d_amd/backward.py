@@ -539,15 +539,18 @@ def msda_fused_backward(value, shapes, offs_logits, grad_out, M=8, P=4, merged=F
 
 
 # --------------------------------------------------------------------------- masked attention
-def masked_attn_backward(q, k, v, out, lse, dout, bits=None, unmasked=None, H=8):
-    """gradients of ops.masked_attn(q, k, v, bits, unmasked) -> (dq [B,Q,C], dk [B,K,C], dv [B,K,C])"""
+def masked_attn_backward(q, k, v, out, lse, dout, bits=None, unmasked=None, H=8, dk_out=None, dv_out=None):
+    """gradients of ops.masked_attn(q, k, v, bits, unmasked) -> (dq [B,Q,C], dk [B,K,C], dv [B,K,C]).  dk_out / dv_out: [B,K,C] views with
+    a row stride (column slices of a wider [B,K,n*C] buffer) the key / value gradients are written into instead of fresh tensors"""
     ops._chk(q); ops._chk(out); ops._chk(dout); ops._chk(lse)
     B, Q, C = q.shape
     K = k.shape[1]
     ws = torch.empty((lib().call("s2d_attn_backward_workspace_floats", B, H, K),), device=q.device, dtype=torch.float32)
     dq = torch.empty_like(q)
-    dk = torch.empty((B, K, C), device=q.device, dtype=torch.float32)
-    dv = torch.empty((B, K, C), device=q.device, dtype=torch.float32)
-    lib().call("s2d_masked_attn_backward_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, out, lse, dout, B, Q, K, C, H, ws, dq, dk, dv,
-               _st())
+    dk = dk_out if dk_out is not None else torch.empty((B, K, C), device=q.device, dtype=torch.float32)
+    dv = dv_out if dv_out is not None else torch.empty((B, K, C), device=q.device, dtype=torch.float32)
+    for t in (dk, dv):
+        assert tuple(t.shape) == (B, K, C) and t.stride(2) == 1 and t.stride(0) == K * t.stride(1) and t.dtype == torch.float32
+    lib().call("s2d_masked_attn_backward_strided_f32", q, k, v, k.stride(1), v.stride(1), bits, unmasked, out, lse, dout, B, Q, K, C, H, ws, dq,
+               dk, dk.stride(1), dv, dv.stride(1), _st())
     return dq, dk, dv

@@ -399,7 +399,8 @@ struct AttnBwdParams {
     const uint32_t *bits, *unmasked;
     int Q, K, C, H, S, tiles_per_split;
     float qscale;                      // 1/sqrt(d) * log2(e)
-    float *dk, *dv, *dq_part;          // dk, dv [B][K][C]; dq_part [B][H][S][128][32]
+    float *dk, *dv, *dq_part;          // dk, dv [B][K][lddk / lddv] (row strides >= C: column slices of a wider gradient buffer); dq_part [B][H][S][128][32]
+    long lddk, lddv;
 };
 constexpr int BT = 64;                 // keys per backward tile
 constexpr float LN2 = 0.6931471805599453f;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdParams p)
         }
     }
     if (quarter == 0 && kok) {
-        float *ko = p.dk + ((long)b * p.K + key) * p.C + hd * 32, *vo = p.dv + ((long)b * p.K + key) * p.C + hd * 32;
+        float *ko = p.dk + ((long)b * p.K + key) * p.lddk + hd * 32, *vo = p.dv + ((long)b * p.K + key) * p.lddv + hd * 32;
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
             const f32x4 a = {dK[d] * LN2, dK[d + 1] * LN2, dK[d + 2] * LN2, dK[d + 3] * LN2};   // qs carries log2(e): back to natural scale
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the tile's dK / dV rows: lane = key, registers = d rows (r & 3) + 8 (r >> 2) + 4 h -> four 16-B runs per lane
         const long key = (long)tile * KT + l32;
         if (key < p.K) {
-            float *ko = p.dk + ((long)b * p.K + key) * p.C + hd * 32 + 4 * h, *vo = p.dv + ((long)b * p.K + key) * p.C + hd * 32 + 4 * h;
+            float *ko = p.dk + ((long)b * p.K + key) * p.lddk + hd * 32 + 4 * h, *vo = p.dv + ((long)b * p.K + key) * p.lddv + hd * 32 + 4 * h;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 f32x4 a, c;
@@ -942,11 +943,13 @@ static int attn_bwd_splits(int K)
 
 long s2d_attn_backward_workspace_floats(int B, int H, int K) { return (long)B * H * attn_bwd_splits(K) * 128 * 32; }
 
-int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
-                                 const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q, int K,
-                                 int C, int H, float *workspace, float *dq, float *dk, float *dv, hipStream_t stream)
+int s2d_masked_attn_backward_strided_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                                         const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q, int K,
+                                         int C, int H, float *workspace, float *dq, float *dk, long lddk, float *dv, long lddv, hipStream_t stream)
 {
-    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0 || ldk < C || ldv < C || (ldk & 3) || (ldv & 3)) return S2D_ERR_ARG;
+    if (Q > 128 || Q <= 0 || C != H * 32 || K <= 0 || ldk < C || ldv < C || (ldk & 3) || (ldv & 3) || lddk < C || lddv < C || (lddk & 3) || (lddv & 3) ||
+        ((reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
+        return S2D_ERR_ARG;
     if (B == 0) return S2D_OK;
     AttnBwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = lse; p.ldk = ldk; p.ldv = ldv; p.bits = bits; p.unmasked = unmasked;
@@ -955,7 +958,7 @@ int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v,
     const int tiles = (K + BT - 1) / BT;
     p.tiles_per_split = (tiles + p.S - 1) / p.S;
     p.qscale = 0.17677669529663687f * 1.4426950408889634f;
-    p.dk = dk; p.dv = dv; p.dq_part = workspace;
+    p.dk = dk; p.dv = dv; p.dq_part = workspace; p.lddk = lddk; p.lddv = lddv;
     static int mfma = -1;                                    // S2D_ATTN_BWD_MFMA=0: the two scalar fp32 kernels (A/B runs, tests)
     if (mfma < 0) { const char *e = getenv("S2D_ATTN_BWD_MFMA"); mfma = e ? atoi(e) : 1; }
     if (mfma) {
@@ -978,6 +981,13 @@ int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v,
                        0.17677669529663687f, dq);      // dS carries natural-scale probabilities; dQ = dS K / sqrt(d)
     S2D_CHECK_LAUNCH();
     return S2D_OK;
+}
+
+int s2d_masked_attn_backward_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,
+                                 const uint32_t *unmasked, const float *out, const float *lse, const float *dout, int B, int Q, int K,
+                                 int C, int H, float *workspace, float *dq, float *dk, float *dv, hipStream_t stream)
+{
+    return s2d_masked_attn_backward_strided_f32(q, k, v, ldk, ldv, bits, unmasked, out, lse, dout, B, Q, K, C, H, workspace, dq, dk, C, dv, C, stream);
 }
 
 int s2d_masked_attn_f32(const float *q, const float *k, const float *v, long ldk, long ldv, const uint32_t *bits,

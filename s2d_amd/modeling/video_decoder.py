@@ -121,9 +121,10 @@ class CrossAttentionLayer(nn.Module):
             tape.append((self, tgt, q_in, q, k, v, bits, unmasked, a, lse, x))
         return ops.layernorm(x.view(B, Q, C), self.norm.weight, self.norm.bias)
 
-    def backward(self, saved, d_out):
+    def backward(self, saved, d_out, dk_out=None, dv_out=None):
         """-> (d_tgt, d_query_pos [Q,C], d_k [B,K,C], d_v [B,K,C]); the in-projection's key / value rows get their gradients
-        from the decoder's batched memory projection (`_project_memory_backward`)"""
+        from the decoder's batched memory projection (`_project_memory_backward`).  dk_out / dv_out: strided [B,K,C] views the key / value
+        gradients are written into (the decoder's per-level buffers) instead of fresh tensors"""
         from .. import backward as Bk
         _, tgt, q_in, q, k, v, bits, unmasked, a, lse, x = saved
         B, Q, C = tgt.shape
@@ -133,7 +134,7 @@ class CrossAttentionLayer(nn.Module):
         d2 = d_x.view(-1, C)
         Bk.acc_wbgrad(m.out_proj.weight, m.out_proj.bias, d2, a.view(-1, C))
         d_a = Bk.input_grad(d2, m.out_proj.weight).view(B, Q, C)
-        dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead)
+        dq, dk, dv = Bk.masked_attn_backward(q, k, v, a, lse, d_a, bits, unmasked, H=self.nhead, dk_out=dk_out, dv_out=dv_out)
         dq2 = dq.view(-1, C)
         Wq = m.in_proj_weight[:C]
         self._dWq, self._dbq = Bk.weight_grad(dq2, q_in.view(-1, C)), Bk.bias_grad(dq2)            # merged with the k / v rows later
@@ -480,10 +481,10 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
             lvl, c0 = i % 3, (i // 3) * C
             d_output = self.transformer_ffn_layers[i].backward(layer_tape[3 * i + 2], d_output)
             d_output, dq1 = self.transformer_self_attention_layers[i].backward(layer_tape[3 * i + 1], d_output)
-            d_output, dq2, dk, dv = self.transformer_cross_attention_layers[i].backward(layer_tape[3 * i], d_output)
+            # the key / value gradients land in their column block of the level's buffer (no copy per layer)
+            d_output, dq2, _, _ = self.transformer_cross_attention_layers[i].backward(layer_tape[3 * i], d_output, dk_out=d_ks[lvl][..., c0:c0 + C],
+                                                                                      dv_out=d_vs[lvl][..., c0:c0 + C])
             d_qe += dq1 + dq2
-            d_ks[lvl][..., c0:c0 + C] = dk
-            d_vs[lvl][..., c0:c0 + C] = dv
             d_output = d_output + heads_backward(head_tape[i])
         Bk.acc(self.query_embed.weight, d_qe)
         Bk.acc(self.query_feat.weight, Bk.sum_slices(d_output.contiguous()))
