@@ -499,11 +499,23 @@ int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, i
 int s2d_im2col_nhwc_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride, int pad, float *col,
                         hipStream_t stream);
 
+/* Depth-to-space step of a stride-2 3 x 3 convolution's input gradient (the R50 trunk's res3.0 / res4.0 / res5.0 conv2, STRIDE_IN_1X1 False):
+ * the gradient is ONE stride-1 2 x 2 convolution of dY with 4 C output channels (a block of C per parity class (y & 1, x & 1) of the input
+ * pixel; four ninths of the products of the zero-dilated form), G [N][Hg][Wg][4 C] with Hg = (H - 1) / 2 + 2, Wg = (W - 1) / 2 + 2, and
+ * dx[n][y][x][c] = G[n][y / 2 + 1][x / 2 + 1][((y & 1) * 2 + (x & 1)) * C + c] * scale[c] (scale may be NULL), zeroed where gate [N][H][W][C]
+ * (may be NULL) is <= 0.  C % 4 == 0. */
+int s2d_pixel_shuffle2_gate_f32(const float *G, int N, int Hg, int Wg, int C, int H, int W, const float *scale, const float *gate, float *dx,
+                                hipStream_t stream);
+
 /* dz = dy * (y > 0) * scale[channel]: the gradient through y = relu(z * scale + bias), the conv / linear epilogue
  * (FrozenBN scale; scale NULL = 1; y NULL = no ReLU); dres (may be NULL) = dy * (y > 0), the gradient of a residual
  * added before the ReLU.  n elements, C innermost. */
 int s2d_relu_scale_backward_f32(const float *dy, const float *y, const float *scale, long n, int C, float *dz, float *dres,
                                 hipStream_t stream);
+
+/* out = a + (y > 0 ? g : 0) over n elements (n % 4 == 0; out may alias a): a ResNet stage output's own gradient g joins the gradient a that the
+ * next block returned already gated by that output's ReLU (y = the stage output), in one pass. */
+int s2d_relu_gate_add_f32(const float *a, const float *g, const float *y, long n, float *out, hipStream_t stream);
 
 /* ---- training-step callers after the loss: optimizer + EMA ------------------------------ */
 

@@ -301,6 +301,43 @@ def _flipped_weight(w):
     return ent[0]
 
 
+_WS2 = {}
+_WS2_IDX = {}
+_CONV_DGRAD_S2 = os.environ.get("S2D_CONV_DGRAD_S2", "1") != "0"       # 0: stride-2 3 x 3 input gradients through the zero-dilated form
+
+
+def _stride2_dgrad_weight(w):
+    """the 2 x 2 kernel [4 Cin, 2, 2, Cout] of a stride-2 / pad-1 3 x 3 convolution's input gradient: output block (py, px) serves the input
+    pixels (2a + py, 2b + px); along one axis an even pixel 2a meets tap 1 of output a, an odd pixel 2a + 1 tap 2 of output a and tap 0 of output
+    a + 1 -- with the convolution's pad 1 and the result read at (a + 1, b + 1), tap slot 0 sits on output a and slot 1 on output a + 1.
+    Cached per weight version and marked static (like _flipped_weight)."""
+    base = w._base if w._base is not None else w
+    w = w.detach()
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+    ent = _WS2.get(key)
+    ver = ops.version_of(base)
+    if ent is not None and ent[2]() is base and ent[1] == ver:
+        return ent[0]
+    Co, _, _, Ci = w.shape
+    kmap = ((1, 9), (2, 0))                                             # [parity][slot] -> tap along one axis; 9 = no tap (a zero plane)
+    idx = _WS2_IDX.get(w.device)
+    if idx is None:
+        taps = [(kmap[py][jy], kmap[px][jx]) for py in range(2) for px in range(2) for jy in range(2) for jx in range(2)]
+        idx = _WS2_IDX[w.device] = torch.tensor([9 if 9 in t else t[0] * 3 + t[1] for t in taps], device=w.device, dtype=torch.long)
+    wp = torch.cat([w.permute(3, 1, 2, 0).reshape(Ci, 9, Co), torch.zeros((Ci, 1, Co), device=w.device, dtype=torch.float32)], 1)
+    w2 = wp.index_select(1, idx).view(Ci, 4, 2, 2, Co).permute(1, 0, 2, 3, 4).reshape(4 * Ci, 2, 2, Co).contiguous()
+    if ent is None or ent[2]() is not base:
+        w2 = ops.mark_static(w2)
+        w2._s2d_version = 0
+        _sweep(_WS2)
+        _WS2[key] = [w2, ver, weakref.ref(base)]
+        return w2
+    ent[0].copy_(w2)                                                    # same buffer, new contents (see _transposed_weight)
+    ent[0]._s2d_version += 1
+    ent[1] = ver
+    return ent[0]
+
+
 def input_grad(dy, w, res=None, gate=None, gate_scale=1.0, scale=None):
     """dx [M,K] = dy[M,N] @ w[N,K] (+ res: the gradient arriving over a residual connection).  gate [M,K]: the output of the
     ReLU (and dropout) that produced this layer's input -- dx is zeroed where gate <= 0 and multiplied by gate_scale
@@ -338,6 +375,17 @@ def conv_input_grad(dy, w, stride, pad, in_hw, gate=None, scale=None):
     N, Ho, Wo, Co = dy.shape
     Co2, KH, KW, Ci = w.shape
     H, W = in_hw
+    if stride == 2 and KH == 3 and KW == 3 and pad == 1 and _CONV_DGRAD_S2 and Ci % 4 == 0 and Co % 4 == 0:
+        # dx[2a + py][2b + px] only meets the taps of its parity class (1, 2, 2 or 4 of the 9): one stride-1 2 x 2 convolution of dy with a
+        # block of Cin output channels per class, then depth-to-space (with the scale / gate of the epilogue forms): 16 products per
+        # output position of dy instead of the 36 of the zero-dilated form, no dilated copy
+        G = ops.conv2d_nhwc(dy, _stride2_dgrad_weight(w), stride=1, pad=1)             # [N, Ho + 1, Wo + 1, 4 Cin]
+        dx = torch.empty((N, H, W, Ci), device=dy.device, dtype=torch.float32)
+        if gate is not None:
+            ops._chk(gate)
+            assert tuple(gate.shape) == (N, H, W, Ci)
+        lib().call("s2d_pixel_shuffle2_gate_f32", G, N, Ho + 1, Wo + 1, Ci, H, W, scale, gate, dx, _st())
+        return dx
     wf = _flipped_weight(w)                                            # [Cin,KH,KW,Cout], once per weight version, pre-split by the dense kernels
     if KH == 1 and KW == 1 and pad == 0:
         assert gate is None and scale is None
@@ -449,6 +497,16 @@ def relu_scale_backward(dy, y=None, scale=None, want_res=False):
     dres = torch.empty_like(dy) if want_res else None
     lib().call("s2d_relu_scale_backward_f32", dy, y, scale, dy.numel(), C, dz, dres, _st())
     return (dz, dres) if want_res else dz
+
+
+def relu_gate_add(a, g, y):
+    """a + g * (y > 0) in one pass (a: a gradient that arrives gated already, g: another gradient of the same ReLU output y)"""
+    for t in (a, g, y):
+        ops._chk(t)
+    assert a.shape == g.shape == y.shape
+    out = torch.empty_like(a)
+    lib().call("s2d_relu_gate_add_f32", a, g, y, a.numel(), out, _st())
+    return out
 
 
 def groupnorm_backward(x, dy, G, gamma, eps=1e-5):

@@ -270,6 +270,32 @@ __global__ __launch_bounds__(256) void relu_scale_backward_kernel(const float *_
     }
 }
 
+// out = a + (y > 0 ? g : 0): a stage output's own gradient g (from the pixel decoder) joins the gradient a that arrives gated from the next
+// block, in one pass (the gate pass + the add were two passes over up to 1 GB each)
+__global__ __launch_bounds__(256) void relu_gate_add_kernel(const float *__restrict__ a, const float *__restrict__ g, const float *__restrict__ y,
+                                                            long n4, float *__restrict__ out)
+{
+    constexpr int U = 4;
+    const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+    f32x4 va[U], vg[U], vy[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long i = base + u * 256;
+        va[u] = i < n4 ? reinterpret_cast<const f32x4 *>(a)[i] : f32x4(0.f);
+        vg[u] = i < n4 ? reinterpret_cast<const f32x4 *>(g)[i] : f32x4(0.f);
+        vy[u] = i < n4 ? reinterpret_cast<const f32x4 *>(y)[i] : f32x4(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long i = base + u * 256;
+        if (i >= n4) continue;
+        f32x4 t = va[u];
+        t[0] += vy[u][0] > 0.f ? vg[u][0] : 0.f; t[1] += vy[u][1] > 0.f ? vg[u][1] : 0.f;
+        t[2] += vy[u][2] > 0.f ? vg[u][2] : 0.f; t[3] += vy[u][3] > 0.f ? vg[u][3] : 0.f;
+        reinterpret_cast<f32x4 *>(out)[i] = t;
+    }
+}
+
 // Adjoint of F.interpolate(up [N,hu,wu,C] -> (H,W), bilinear, align_corners=False) (the top-down add of the pixel decoder,
 // msdeformattn.py:349), as a gather so that it is reproducible: low-resolution pixel (yl, xl) collects w_y * w_x * dy from
 // every high-resolution pixel whose source taps include it (the forward's own source rule decides the weights).
@@ -351,6 +377,29 @@ __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float *__re
         }
     }
     *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
+}
+
+// dx[n][y][x][c] = G[n][y / 2 + 1][x / 2 + 1][((y & 1) * 2 + (x & 1)) * C + c] (* scale[c]) (-> 0 where gate <= 0): the depth-to-space step of a
+// stride-2 3 x 3 convolution's input gradient computed as ONE stride-1 2 x 2 convolution of dY with 4 C output channels (one block of C per
+// parity class of the input pixel; s2d_amd/backward.py conv_input_grad), 16-B accesses, one thread per four channels of an input pixel.
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float *__restrict__ G, int N, int Hg, int Wg, int C, int H, int W,
+                                                             const float *__restrict__ scale, const float *__restrict__ gate,
+                                                             float *__restrict__ dx)
+{
+    const int q = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W * q) return;
+    const int c4 = (int)(i % q);
+    const long pix = i / q;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const long g = (((long)n * Hg + (y >> 1) + 1) * Wg + (x >> 1) + 1) * (4L * C) + (long)(((y & 1) * 2 + (x & 1)) * C + c4 * 4);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(G + g);
+    if (scale) v = v * *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
+    if (gate) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(gate + i * 4);
+        v[0] = t[0] > 0.f ? v[0] : 0.f; v[1] = t[1] > 0.f ? v[1] : 0.f; v[2] = t[2] > 0.f ? v[2] : 0.f; v[3] = t[3] > 0.f ? v[3] : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(dx + i * 4) = v;
 }
 
 // col[p][(ky*KW + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside), p = (n*Ho + oy)*Wo + ox: the
@@ -453,6 +502,26 @@ int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, i
     const long total = (long)N * H * W * (C / 4);
     if (total == 0) return S2D_OK;
     hipLaunchKernelGGL(maxpool_backward_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, dy, N, H, W, C, (H + 1) / 2, (W + 1) / 2, dx);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_pixel_shuffle2_gate_f32(const float *G, int N, int Hg, int Wg, int C, int H, int W, const float *scale, const float *gate, float *dx,
+                                hipStream_t stream)
+{
+    if ((C & 3) || N < 0 || H < 1 || W < 1 || Hg != (H - 1) / 2 + 2 || Wg != (W - 1) / 2 + 2) return S2D_ERR_ARG;
+    const long total = (long)N * H * W * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, G, N, Hg, Wg, C, H, W, scale, gate, dx);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_relu_gate_add_f32(const float *a, const float *g, const float *y, long n, float *out, hipStream_t stream)
+{
+    if ((n & 3) || n < 0) return S2D_ERR_ARG;
+    if (n == 0) return S2D_OK;
+    hipLaunchKernelGGL(relu_gate_add_kernel, dim3(cdiv(n / 4, 1024)), dim3(256), 0, stream, a, g, y, n / 4, out);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -221,7 +221,7 @@ class ResNet50(nn.Module):
                 if d is None:
                     d, gated = g, False
                 elif gated:
-                    d = d + B.relu_scale_backward(g, saved[5])       # d arrives gated by this block's output: gate the stage output's own gradient too
+                    d = B.relu_gate_add(d, g, saved[5])               # d arrives gated by this block's output: gate the stage output's own gradient too (one pass)
                 else:
                     d = d + g
             # every block but the first hands its input gradient back gated by that input (the previous block's ReLU output), in its conv1

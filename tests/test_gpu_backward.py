@@ -175,6 +175,22 @@ def test_conv_backward_vs_autograd(N, H, W, Ci, Co, KH, stride, pad):
     assert rel(dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()) < 2e-6
     dw = backward.conv_weight_grad(dy_h, x_h, KH, KH, stride, pad)
     assert rel(dw.permute(0, 3, 1, 2).cpu().numpy(), wd.grad.numpy()) < 5e-6
+    if KH == 3 and stride == 2 and pad == 1:
+        # the input gradient as ONE 2 x 2 convolution of dY + depth-to-space (round 5, the default) against the zero-dilated form, also with
+        # the epilogue's per-channel scale and ReLU gate
+        assert backward._CONV_DGRAD_S2
+        sc = (torch.rand((Ci,), generator=g) + 0.5).to(DEV)
+        gate = torch.randn((N, H, W, Ci), generator=g).to(DEV)
+        dxg = backward.conv_input_grad(dy_h, w_h, stride, pad, (H, W), gate=gate, scale=sc)
+        backward._CONV_DGRAD_S2 = False
+        try:
+            dx0 = backward.conv_input_grad(dy_h, w_h, stride, pad, (H, W))
+            dxg0 = backward.conv_input_grad(dy_h, w_h, stride, pad, (H, W), gate=gate, scale=sc)
+        finally:
+            backward._CONV_DGRAD_S2 = True
+        assert rel(dx.cpu().numpy(), dx0.cpu().numpy()) < 2e-6
+        assert rel(dxg.cpu().numpy(), dxg0.cpu().numpy()) < 2e-6
+        assert torch.equal((dxg == 0), (dxg0 == 0)) or float(((dxg == 0) != (dxg0 == 0)).float().mean()) < 1e-6
     if KH > 1:
         # the one-launch form with in-place addressing (round 5, the default) against the padded-copy / per-tap form it replaces: the same
         # products, summed over a different split of the positions; and run-to-run bit equality
@@ -920,3 +936,12 @@ def test_training_iteration_with_compact_kd_targets_equals_the_padded_one():
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+
+
+def test_relu_gate_add():
+    from s2d_amd import backward
+    g = torch.Generator().manual_seed(5)
+    for shape in ((2, 7, 9, 64), (1, 3, 5, 4), (3, 33, 17, 256)):
+        a, b, y = (torch.randn(shape, generator=g).to(DEV) for _ in range(3))
+        out = backward.relu_gate_add(a, b, y)
+        assert torch.equal(out, a + torch.where(y > 0, b, torch.zeros_like(b)))
