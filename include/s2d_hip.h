@@ -249,6 +249,9 @@ int s2d_normalize_pad_nhwc4_f32(const uint8_t *frames, int F, int H0, int W0, in
 
 /* 3x3/2 pad 1 max pool, NHWC (detectron2 BasicStem). y [N,(H+1)/2,(W+1)/2,C]. */
 int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float *y, hipStream_t stream);
+/* The same, also writing the arg-max tap (ky * 3 + kx, the first maximum in scan order) of every output element: argmax [N][Ho][Wo][C] bytes,
+ * 4-byte aligned.  The training step keeps it for s2d_maxpool3x3s2_backward_idx_nhwc_f32. */
+int s2d_maxpool3x3s2_nhwc_idx_f32(const float *x, int N, int H, int W, int C, float *y, unsigned char *argmax, hipStream_t stream);
 
 /* y = GroupNorm_G(x)*gamma+beta [+ bilinear_resize(up [N,hu,wu,C] -> (H,W), align_corners=False)] [relu]; x NHWC.
  * nn.GroupNorm(32,256) at msdeformattn.py:213-226 and detectron2 get_norm("GN") at :261-281; the fused
@@ -493,6 +496,10 @@ int s2d_resize_bilinear_backward_nhwc_f32(const float *dy, int N, int H, int W, 
  * in window scan order (torch's rule).  Gather form: reproducible. */
 int s2d_maxpool3x3s2_backward_nhwc_f32(const float *x, const float *dy, int N, int H, int W, int C, float *dx,
                                        hipStream_t stream);
+/* ... from the arg-max taps the forward stored (s2d_maxpool3x3s2_nhwc_idx_f32) instead of x: 4 bytes + (where the pixel is an arg-max) one dy row
+ * per window, against 9 input rows per window for the recomputing form. */
+int s2d_maxpool3x3s2_backward_idx_nhwc_f32(const unsigned char *argmax, const float *dy, int N, int H, int W, int C, float *dx,
+                                           hipStream_t stream);
 
 /* explicit im2col for convolutions with few input channels (the 7x7 stem): col [N*Ho*Wo][KH*KW*C] from x [N,H,W,C], zero
  * outside the image; the weight gradient is then one contraction dY^T . col (s2d_amd/backward.py:conv_weight_grad) */

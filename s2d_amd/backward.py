@@ -540,11 +540,18 @@ def groupnorm_up_relu_backward(x, y, dy, G, gamma, up_hw=None, relu=False, eps=1
     return groupnorm_backward(x, g, G, gamma, eps) + (dup,)
 
 
-def maxpool_backward(x, dy):
-    """gradient of ops.maxpool3x3s2_nhwc"""
-    ops._chk(x); ops._chk(dy)
+def maxpool_backward(x, dy, idx=None):
+    """gradient of ops.maxpool3x3s2_nhwc.  idx: the arg-max taps of ops.maxpool3x3s2(x, want_idx=True) -- the backward then reads them instead
+    of recomputing every window's arg-max from x (x only gives the shape)"""
+    ops._chk(dy)
     N, H, W, C = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+    if idx is not None:
+        ops._chk(idx, torch.uint8)
+        assert tuple(idx.shape) == tuple(dy.shape)
+        lib().call("s2d_maxpool3x3s2_backward_idx_nhwc_f32", idx, dy, N, H, W, C, dx, _st())
+        return dx
+    ops._chk(x)
     lib().call("s2d_maxpool3x3s2_backward_nhwc_f32", x, dy, N, H, W, C, dx, _st())
     return dx
 

@@ -402,6 +402,36 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float *__rest
     *reinterpret_cast<f32x4 *>(dx + i * 4) = v;
 }
 
+// The same from the forward's stored arg-max taps (s2d_maxpool3x3s2_nhwc_idx_f32): per window one 4-byte index word and, where this pixel is a
+// channel's arg-max, the dy row.
+__global__ __launch_bounds__(256) void maxpool_backward_idx_kernel(const unsigned int *__restrict__ idx, const float *__restrict__ dy, int N, int H,
+                                                                   int W, int C, int Ho, int Wo, float *__restrict__ dx)
+{
+    const int q = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W * q) return;
+    const int c4 = (int)(i % q);
+    const long pix = i / q;
+    const int px = (int)(pix % W), py = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    f32x4 acc = f32x4(0.f);
+    for (int oy = py / 2; oy <= (py + 1) / 2; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = px / 2; ox <= (px + 1) / 2; ++ox) {
+            if (ox >= Wo) continue;
+            const unsigned int tap = (unsigned int)((py - (2 * oy - 1)) * 3 + (px - (2 * ox - 1)));
+            const long w = (((long)n * Ho + oy) * Wo + ox) * q + c4;
+            const unsigned int am = idx[w];
+            const unsigned int hit = ((am & 0xFFu) == tap ? 1u : 0u) | (((am >> 8) & 0xFFu) == tap ? 2u : 0u) | (((am >> 16) & 0xFFu) == tap ? 4u : 0u) |
+                                     ((am >> 24) == tap ? 8u : 0u);
+            if (hit) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + w * 4);
+                acc[0] += (hit & 1u) ? g[0] : 0.f; acc[1] += (hit & 2u) ? g[1] : 0.f; acc[2] += (hit & 4u) ? g[2] : 0.f; acc[3] += (hit & 8u) ? g[3] : 0.f;
+            }
+        }
+    }
+    *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
+}
+
 // col[p][(ky*KW + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside), p = (n*Ho + oy)*Wo + ox: the
 // explicit im2col of a convolution with few input channels (the 7x7 stem: C = 4, 49 taps), whose weight gradient is then
 // ONE sliced contraction dY^T . col instead of 49 of them with a 4-wide output.
@@ -522,6 +552,17 @@ int s2d_relu_gate_add_f32(const float *a, const float *g, const float *y, long n
     if ((n & 3) || n < 0) return S2D_ERR_ARG;
     if (n == 0) return S2D_OK;
     hipLaunchKernelGGL(relu_gate_add_kernel, dim3(cdiv(n / 4, 1024)), dim3(256), 0, stream, a, g, y, n / 4, out);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_maxpool3x3s2_backward_idx_nhwc_f32(const unsigned char *argmax, const float *dy, int N, int H, int W, int C, float *dx, hipStream_t stream)
+{
+    if ((C & 3) || N < 0 || H < 1 || W < 1 || !argmax || (reinterpret_cast<uintptr_t>(argmax) & 3)) return S2D_ERR_ARG;
+    const long total = (long)N * H * W * (C / 4);
+    if (total == 0) return S2D_OK;
+    hipLaunchKernelGGL(maxpool_backward_idx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned int *>(argmax), dy, N, H,
+                       W, C, (H + 1) / 2, (W + 1) / 2, dx);
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

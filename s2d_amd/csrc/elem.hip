@@ -33,9 +33,12 @@ __global__ void normalize_pad_kernel(const uint8_t *__restrict__ in, int F, int 
 }
 
 // 3x3 / stride 2 / pad 1 max pool, NHWC, C % 4 == 0 (detectron2 BasicStem)
-template <typename I>
+// IDX: also the arg-max tap (ky * 3 + kx, the FIRST maximum in scan order: where torch's max_pool2d backward routes the gradient) of every
+// output element, one byte each -- the training step's backward then reads 4 bytes + one dy row per window instead of recomputing the
+// arg-max of up to four windows from 36 input rows per input pixel (round 5)
+template <typename I, bool IDX = false>
 __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
-                               float *__restrict__ out)
+                               float *__restrict__ out, unsigned int *__restrict__ idx = nullptr)
 {
     const int c4n = C / 4;
     const I i = (I)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,6 +50,8 @@ __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W
     const int oy = (int)(t % (I)Ho);
     const int n = (int)(t / (I)Ho);
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned int am = 0u;
+    bool seen = false;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int iy = oy * 2 - 1 + dy;
@@ -56,10 +61,19 @@ __global__ void maxpool_kernel(const float *__restrict__ in, int N, int H, int W
             const int ix = ox * 2 - 1 + dx;
             if (ix < 0 || ix >= W) continue;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((long)n * H + iy) * W + ix) * C + c * 4);
-            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            if constexpr (IDX) {
+                const unsigned int tap = (unsigned int)(dy * 3 + dx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (v[j] > m[j] || !seen) { m[j] = v[j]; am = (am & ~(0xFFu << (8 * j))) | (tap << (8 * j)); }
+                seen = true;
+            } else {
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
         }
     }
     *reinterpret_cast<f32x4 *>(out + (long)i * 4) = m;
+    if constexpr (IDX) idx[i] = am;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -483,6 +497,19 @@ int s2d_maxpool3x3s2_nhwc_f32(const float *x, int N, int H, int W, int C, float 
         hipLaunchKernelGGL(maxpool_kernel<unsigned int>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
     else
         hipLaunchKernelGGL(maxpool_kernel<long>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y);
+    S2D_CHECK_LAUNCH();
+    return S2D_OK;
+}
+
+int s2d_maxpool3x3s2_nhwc_idx_f32(const float *x, int N, int H, int W, int C, float *y, unsigned char *argmax, hipStream_t stream)
+{
+    if ((C & 3) || !argmax || (reinterpret_cast<uintptr_t>(argmax) & 3)) return S2D_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    if (total == 0) return S2D_OK;
+    if (total >= (1L << 31)) return S2D_ERR_ARG;
+    hipLaunchKernelGGL((maxpool_kernel<unsigned int, true>), dim3(cdiv(total, 256)), dim3(256), 0, stream, x, N, H, W, C, Ho, Wo, y,
+                       reinterpret_cast<unsigned int *>(argmax));
     S2D_CHECK_LAUNCH();
     return S2D_OK;
 }

@@ -128,15 +128,16 @@ class BasicStem(nn.Module):
 
     def forward(self, x, tape=None):
         c = self.conv1(x)
-        y = ops.maxpool3x3s2(c)
         if tape is not None:
-            tape.append((self, x, c))
-        return y
+            y, idx = ops.maxpool3x3s2(c, want_idx=True)               # the arg-max taps: the backward routes by them
+            tape.append((self, x, c, idx))
+            return y
+        return ops.maxpool3x3s2(c)
 
     def backward(self, saved, dy):
         from .. import backward as B
-        _, x, c = saved
-        self.conv1.backward(x, c, B.maxpool_backward(c, dy), relu=True, need_dx=False)   # the image needs no gradient
+        _, x, c, idx = saved
+        self.conv1.backward(x, c, B.maxpool_backward(c, dy, idx), relu=True, need_dx=False)   # the image needs no gradient
 
 
 class BottleneckBlock(nn.Module):

@@ -547,10 +547,15 @@ def conv2d_nhwc_gate(x, w, gate, stride=1, pad=0, scale=None, gate_scale=1.0):
     return y
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, want_idx=False):
+    """3x3 / stride 2 / pad 1 max pool (NHWC).  want_idx: -> (y, arg-max taps u8 [N,Ho,Wo,C]) for backward.maxpool_backward"""
     _chk(x)
     N, H, W, C = x.shape
     y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=torch.float32)
+    if want_idx:
+        idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+        lib().call("s2d_maxpool3x3s2_nhwc_idx_f32", x, N, H, W, C, y, idx, _stream())
+        return y, idx
     lib().call("s2d_maxpool3x3s2_nhwc_f32", x, N, H, W, C, y, _stream())
     return y
 

@@ -284,6 +284,11 @@ def test_maxpool_backward_vs_autograd(N, H, W, C):
     (y * dy.double()).sum().backward()
     h = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
     dx = backward.maxpool_backward(h(x), h(dy))
+    # ... and from the arg-max taps the forward stores for the training step (round 5): the same routing, the same sums
+    from s2d_amd import ops
+    y_h, idx = ops.maxpool3x3s2(h(x), want_idx=True)
+    assert torch.equal(y_h, ops.maxpool3x3s2(h(x))) and idx.dtype == torch.uint8 and int(idx.max()) <= 8
+    assert torch.equal(backward.maxpool_backward(h(x), h(dy), idx), dx)
     # routing is exact; a pixel that is the arg-max of several windows adds 2..4 gradients (fp32 here, float64 in the check)
     got, want = dx.permute(0, 3, 1, 2).cpu().numpy(), xd.grad.numpy()
     np.testing.assert_array_equal(got != 0, want != 0)
