@@ -445,29 +445,33 @@ class VideoMultiScaleMaskedTransformerDecoder(nn.Module):
         # GEMM (instead of one read-modify-write pass over the 0.5 GB feature gradient per layer).  The same matrix, contracted over the
         # pixels with the clip's mask features, is d(mask embedding) of the matched queries of all layers: one TN GEMM per clip and
         # pass (round 5; it was one long-K GEMM per layer, clip and pass, each re-reading the clip's 0.47 GB of features).
-        d_emb = []
+        # The matched queries' embeddings of all layers are gathered once per pass, and the embedding gradients of all layers scattered back
+        # once per pass (unmatched slots carry zero rows and any valid query index: they add exact zeros) -- it was one indexed copy and one
+        # index_add per (layer, clip, pass).
+        Cm = mf.shape[-1]
+        E_all = torch.stack([head_tape[s_][4] for s_ in range(NL)])                 # [NL, B, Q, Cm]
+        D_E = torch.zeros_like(E_all)
         for rows, idx_q in mask_sources:
             maxm = rows.shape[2]
             mp = (maxm + 3) // 4 * 4
-            d_emb.append([])
+            ex = idx_q.view(NL, B, maxm).long()[..., None].expand(NL, B, maxm, Cm)
+            eg = E_all.gather(2, ex)                                                  # [NL, B, maxm, Cm]
+            if mp != maxm:
+                eg = torch.nn.functional.pad(eg, (0, 0, 0, mp - maxm))
+            de_pass = []
             for b in range(B):
                 Dt = torch.zeros((npix, NL * mp), device=dev, dtype=torch.float32) if mp != maxm else \
                     torch.empty((npix, NL * mp), device=dev, dtype=torch.float32)
-                et = torch.zeros((C, NL * mp), device=dev, dtype=torch.float32)
                 for slot in range(NL):
                     lib().call("s2d_transpose_f32", rows[slot, b], maxm, npix, npix, Dt[:, slot * mp:], NL * mp, ops._stream())
-                    et[:, slot * mp:slot * mp + maxm] = head_tape[slot][4][b][idx_q[slot * B + b].long()].t()
+                et = eg[:, b].reshape(NL * mp, Cm).t().contiguous()                   # [Cm, NL * mp]
                 d_mf[b] = ops.gemm_nt(Dt, et, res=d_mf[b], out=d_mf_all[b])
-                d_emb[-1].append(Bk.weight_grad(Dt, mf[b]).view(NL, mp, mf.shape[-1]))      # sum_pix D[slot, m, pix] mf[pix, :]
+                de_pass.append(Bk.weight_grad(Dt, mf[b]).view(NL, mp, Cm)[:, :maxm])  # sum_pix D[slot, m, pix] mf[pix, :]
+            D_E.scatter_add_(2, ex, torch.stack(de_pass, 1))
 
         def heads_backward(rec):
             slot, output, d, mlp_acts, e = rec
-            d_e = torch.zeros((B, Q, e.shape[-1]), device=dev, dtype=torch.float32)
-            for (rows, idx_q), de in zip(mask_sources, d_emb):
-                for b in range(B):
-                    iq = idx_q[slot * B + b].long()
-                    d_e[b].index_add_(0, iq, de[b][slot, :rows.shape[2]])
-            d_d = self.mask_embed.backward(mlp_acts, d_e.view(B * Q, -1))
+            d_d = self.mask_embed.backward(mlp_acts, D_E[slot].reshape(B * Q, -1))
             if d_cls is not None:
                 dc = d_cls[slot].reshape(B * Q, -1).contiguous()
                 Bk.acc_wgrad(self.class_embed.weight, dc, d); Bk.acc_bgrad(self.class_embed.bias, dc)
